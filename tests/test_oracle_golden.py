@@ -1,0 +1,158 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the reference itself (tests/golden/*.npz,
+tests/golden/make_golden.py) and against the reference's own known-answer tests."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import agd_oracle
+from tests.helpers import NP_DT, RTOL, SCALA_GOLDEN, SINGLE_MAPS, load, problem, relerr, scala_5x5
+
+
+def _calc(p, proj, lam, gamma, dt, col_proj=None):
+    projs = proj if isinstance(proj, list) else [proj]
+    ax, obj0, ssq, x = oracle.matching_calculate(
+        p["m"], p["n"], p["colptr"], p["rowidx"], p["a"], p["c"], lam, gamma, projs, col_proj=col_proj, dtype=dt
+    )
+    grad, obj, reg, dvtg, mx, sm = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], gamma, dt)
+    return grad, x, np.array([obj, reg, obj0, dvtg, mx, sm], dtype=np.float64)
+
+
+@pytest.mark.parametrize("fixture", ["g1_syn2000.npz", "g1_long.npz"])
+def test_calculate_matches_reference(fixture):
+    z = load(fixture)
+    p = problem(z)
+    worst = {"f32": 0.0, "f64": 0.0}
+    for key in z["cases"]:
+        mk, g, ln, dn = str(key).split("|")
+        grad, x, scal = _calc(p, SINGLE_MAPS[mk], z[f"lam_{ln}"], float(g), NP_DT[dn])
+        for got, name in ((grad, "grad"), (x, "x"), (scal, "scal")):
+            e = relerr(got, z[f"{key}|{name}"])
+            worst[dn] = max(worst[dn], e)
+            assert e < RTOL[dn], (key, name, e)
+    print("worst rel err", worst)
+
+
+def test_projection_operators_match_reference():
+    z = load("gp_projections.npz")
+    ops = {
+        "simplex_z1": ("simplex", {"z": 1.0}),
+        "simplex_z0.3": ("simplex", {"z": 0.3}),
+        "simplex_eq_z1": ("simplex_eq", {"z": 1.0}),
+        "box": ("box", {"lower": -0.2, "upper": 0.7}),
+        "cone_lo": ("cone", {"lower": 0.1}),
+        "cone_up": ("cone", {"upper": 0.1}),
+    }
+    for bn in z["blocks"]:
+        for on, (pt, pp) in ops.items():
+            for dn, dt in NP_DT.items():
+                got = oracle.project_dense(z[f"in|{bn}"].astype(dt), pt, pp)
+                want = z[f"out|{bn}|{on}|{dn}"]
+                tol = 1e-12 if dn == "f64" else 2e-6
+                assert np.allclose(got, want, rtol=0, atol=tol), (bn, on, dn, np.abs(got - want).max())
+
+
+def test_simplex_known_answer_negative_values():
+    # reference tests/projections/test_simplex.py:270-284
+    x = np.array([[-0.0133, -0.0133, 0.0006, -0.0133, -0.0133], [0.0006, 0.0007, -0.0133, 0.0006, 0.0009]], dtype=np.float32)
+    want = np.array([[0, 0, 0.0006, 0, 0], [0.0006, 0.0007, 0, 0.0006, 0.0009]], dtype=np.float32)
+    got = oracle.project_dense(x, "simplex", {"z": 1.0})
+    assert np.allclose(got, want, atol=1e-5)
+
+
+def test_beta_seq_bit_exact():
+    want = load("g4_beta_seq.npz")["beta"]
+    got = agd_oracle.beta_seq(want.shape[0])
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+
+
+def _trace(p, z, key, dt):
+    g, it, s0, s1, dsteps, dfac, eq, jac = z[f"{key}|params"]
+    proj = z[f"{key}|proj"]
+    pt = str(proj[0])
+    pp = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in proj[1:]}
+    a, b = p["a"], p["b"]
+    if jac:
+        a, b = z[f"{key}|A_scaled"], z[f"{key}|b_scaled"]
+    q = dict(p, a=a, b=b)
+    decay = {"decay_steps": int(dsteps), "decay_factor": float(dfac)} if dsteps else None
+
+    def calc(lam, gamma):
+        grad, x, scal = _calc(q, (pt, pp), lam, gamma, dt)
+        return grad, scal[0], (x, scal)
+
+    return agd_oracle.maximize(
+        calc, np.zeros(p["m"], dtype=dt), int(it), float(g), s0, s1, decay=decay, eq_mask=z["eq_mask"] if eq else None, dtype=dt
+    )
+
+
+def test_agd_traces_match_reference_f64():
+    z = load("g2_syn2000.npz")
+    p = problem(z)
+    for key in z["variants"]:
+        key = str(key)
+        if not key.endswith("f64"):
+            continue
+        r = _trace(p, z, key, np.float64)
+        assert relerr(r["dual_obj_log"], z[f"{key}|dual_obj_log"]) < 1e-8, key
+        assert np.allclose(r["step_log"], z[f"{key}|step_log"], rtol=1e-6, atol=0), key
+        assert relerr(r["dual_val"], z[f"{key}|dual_val"]) < 1e-7, key
+        x, scal = r["last"][2]
+        assert relerr(x, z[f"{key}|x"]) < 1e-7, key
+        assert relerr(scal, z[f"{key}|scal"]) < 1e-8, key
+        assert abs(r["gamma"] - float(z[f"{key}|final_gamma"])) < 1e-15
+
+
+def test_agd_traces_match_reference_f32_prefix():
+    # fp32 traces are chaotic through the Lipschitz step-size rule; the first 20 iterations are pinned.
+    z = load("g2_syn2000.npz")
+    p = problem(z)
+    for key in ("simplex1|f32", "box01|f32", "simplex1_decay|f32"):
+        r = _trace(p, z, key, np.float32)
+        assert relerr(r["dual_obj_log"][:20], z[f"{key}|dual_obj_log"][:20]) < 5e-5, key
+        assert np.allclose(r["step_log"][:20], z[f"{key}|step_log"][:20], rtol=5e-3), key
+
+
+def test_scala_known_answer_trace():
+    # reference tests/objectives/test_dualip_matching_simplex.py:102-141 (goldens inherited from the Scala solver)
+    p = scala_5x5()
+
+    def calc(lam, gamma):
+        grad, x, scal = _calc(p, ("simplex", {"z": 1}), lam, gamma, np.float32)
+        return grad, scal[0], None
+
+    r = agd_oracle.maximize(calc, 0.1 * np.ones(5, dtype=np.float32), 30, 1e-3, dtype=np.float32)
+    for i, want in SCALA_GOLDEN:
+        assert abs(r["dual_obj_log"][i - 1] - want) < 1e-5, (i, r["dual_obj_log"][i - 1], want)
+
+
+def test_mixed_map_matches_key_boundary_split():
+    z = load("g3_syn2000.npz")
+    p = problem(z)
+    half = int(z["mixed_boundary"])
+    col_proj = np.zeros(p["n"], dtype=np.int32)
+    col_proj[half:] = 1
+    projs = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})]
+    for dn, dt in NP_DT.items():
+        grad, x, scal = _calc(p, projs, z["lam"], 0.02, dt, col_proj=col_proj)
+        key = f"mixed|w2|{dn}"
+        assert relerr(grad, z[f"{key}|single_grad"]) < RTOL[dn]
+        assert relerr(x, z[f"{key}|single_x"]) < RTOL[dn]
+        want = z[f"{key}|single_scal"]
+        assert relerr(scal[[0, 1, 3, 4, 5]], want[[0, 1, 3, 4, 5]]) < RTOL[dn]
+
+
+def test_movielens_like_trace_f64():
+    z = load("g7_movielens_like.npz")
+    p = problem(z)
+    g, it, s0, s1 = z["params"]
+
+    def calc(lam, gamma):
+        grad, x, scal = _calc(p, ("simplex", {"z": 1.0}), lam, gamma, np.float64)
+        return grad, scal[0], (x, scal)
+
+    r = agd_oracle.maximize(calc, np.zeros(p["m"]), int(it), float(g), s0, s1, dtype=np.float64)
+    # the step-size rule makes the iteration chaotic: round-off (summation order) grows ~10x every 5 iterations
+    # after iteration 60 on this problem, so the tight check is on the first 60 iterations.
+    assert relerr(r["dual_obj_log"][:60], z["f64|dual_obj_log"][:60]) < 1e-10
+    assert np.allclose(r["step_log"][:60], z["f64|step_log"][:60], rtol=1e-9)
+    assert relerr(r["dual_obj_log"], z["f64|dual_obj_log"]) < 1e-3
