@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- dual-ascent iterations/sec of the matching LP on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): the synthetic matching LP of the reference's benchmark (benchmark/config.py:9-22,
+generate_synthetic_data.py) at BASELINE.json's headline size -- 100M entities x 10k destinations, sparsity 1e-3
+(~1e9 non-zeros), mixed box / simplex projection map, gamma = 1e-3, fp32 -- column-sharded over the N GPUs
+(strong scaling: the global problem is fixed).  One "step" = one full dual-ascent iteration: fused CSC pass
+(gather, projection, scatter-add, reductions) + slab reduction + [RCCL sum-all-reduce of m+2 doubles when N > 1] +
+device-side step-size/AGD update.  Inputs are resident in HBM before the timed region.
+
+The JSON line carries, besides the contract fields:
+  roofline     -- HBM roofline of the fused kernel: algorithmic bytes per launch (12 E + 4 n + 16 m) /
+                  average launch duration measured with HIP events on the launch stream inside the timed region.
+  cpu_baseline -- the CPU oracle (oracle/, OpenMP over all host cores) on a bounded sample of the same workload
+                  (rank 0, N = 1 only), scaled to whole-problem iterations/s.  Reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--entities", type=int, default=int(os.environ.get("DUALIP_BENCH_ENTITIES", 100_000_000)))
+    ap.add_argument("--destinations", type=int, default=10_000)
+    ap.add_argument("--sparsity", type=float, default=1e-3)
+    ap.add_argument("--proj", choices=["mixed", "box", "simplex"], default="mixed")
+    ap.add_argument("--gamma", type=float, default=1e-3)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-sample-cols", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-iters", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def projection_map(kind, n_global, lo, hi):
+    """Global map restricted to the local columns [lo, hi): first half box[0,1], second half simplex z=1 (config 4)."""
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.utils.dist_utils import global_to_local_projection_map
+
+    if kind == "box":
+        gm = create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n_global, indices=range(n_global))
+    elif kind == "simplex":
+        gm = create_projection_map("simplex", {"z": 1.0}, n_global, indices=range(n_global))
+    else:
+        half = n_global // 2
+        gm = {
+            **create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n_global, indices=range(half)),
+            **create_projection_map("simplex", {"z": 1.0}, n_global, indices=range(half, n_global)),
+        }
+    return global_to_local_projection_map(gm, range(lo, hi))
+
+
+def cpu_baseline(args, inp, pm_local, total_nnz):
+    """Oracle (kind 'port') on the first --cpu-sample-cols local columns, all host cores."""
+    import oracle
+    from oracle import agd_oracle
+
+    A = inp.A
+    ncols = min(args.cpu_sample_cols, A.shape[1])
+    colptr = A.ccol_indices()[: ncols + 1].cpu().numpy().astype(np.int64)
+    k1 = int(colptr[-1])
+    rowidx = A.row_indices()[:k1].cpu().numpy().astype(np.int64)
+    a = A.values()[:k1].cpu().numpy()
+    c = inp.c.values()[:k1].cpu().numpy()
+    b = inp.b_vec.cpu().numpy()
+    m = A.shape[0]
+    npdt = np.float32 if args.dtype == "f32" else np.float64
+    projs, col_proj = [], np.full(ncols, -1, dtype=np.int32)
+    for q, (_, e) in enumerate(pm_local.items()):
+        projs.append((e.proj_type, e.proj_params))
+        idx = e.indices
+        lo_i, hi_i = (idx.start, min(idx.stop, ncols)) if isinstance(idx, range) else (min(idx), min(max(idx) + 1, ncols))
+        if lo_i < ncols:
+            col_proj[lo_i:hi_i] = q
+    threads = oracle.max_threads()
+    lam = np.zeros(m, dtype=npdt)
+    sizer = agd_oracle.StepSizer(npdt)
+    times = []
+    for it in range(args.cpu_sample_iters + 1):
+        t0 = time.perf_counter()
+        ax, obj0, ssq, _ = oracle.matching_calculate(m, ncols, colptr, rowidx, a, c, lam, args.gamma, projs, col_proj=col_proj, dtype=npdt, want_x=False, threads=threads)
+        grad, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, b, args.gamma, npdt)
+        step = sizer(grad, lam, 1e-3, 1e-1)
+        lam = np.maximum(lam + grad * npdt(step), 0).astype(npdt)
+        times.append(time.perf_counter() - t0)
+    per_iter = float(np.mean(times[1:]))
+    sample_its = 1.0 / per_iter
+    return {
+        "value": sample_its * (k1 / max(total_nnz, 1)),
+        "unit": "iterations/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle/ (C, OpenMP {threads} threads) on the first {ncols} entities ({k1} non-zeros) of the same problem, "
+        f"{args.cpu_sample_iters} iterations at {per_iter * 1e3:.1f} ms; value = sample it/s x sample_nnz/total_nnz",
+        "sample_ms_per_iteration": per_iter * 1e3,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction, MatchingSolverDualObjectiveFunctionDistributed
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+
+    n, m = args.entities, args.destinations
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    # contiguous, chunk-aligned column ranges (every rank builds its own shard of the SAME global problem)
+    chunks = (n + CHUNK_COLS - 1) // CHUNK_COLS
+    per = [chunks // world + (1 if r < chunks % world else 0) for r in range(world)]
+    lo = min(n, sum(per[:rank]) * CHUNK_COLS)
+    hi = min(n, lo + per[rank] * CHUNK_COLS)
+
+    def reduce_loads(v):
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        return v
+
+    t_gen = time.perf_counter()
+    prob = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_range=(lo, hi), reduce_loads=reduce_loads)
+    inp = prob["input_args"]
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    pm_local = projection_map(args.proj, n, lo, hi)
+    inp.projection_map = pm_local
+    nnz_local = prob["nnz"]
+    nnz_t = torch.tensor([nnz_local], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(nnz_t)
+    total_nnz = int(nnz_t.item())
+
+    t_setup = time.perf_counter()
+    b_vec = inp.b_vec
+    if world > 1:
+        inp.b_vec = None
+        f = MatchingSolverDualObjectiveFunctionDistributed(inp, b_vec, args.gamma, host_device=device)
+        local = f.local_objective
+    else:
+        f = MatchingSolverDualObjectiveFunction(inp, args.gamma)
+        local = f
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    total_iters = args.warmup + args.steps
+    solver = AcceleratedGradientDescent(
+        max_iter=total_iters, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False
+    )
+    run = solver.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
+    run.advance(args.warmup)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    fence()
+    local.profile(True)
+    t0 = time.perf_counter()
+    run.advance(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = local.profile_read()
+    local.profile(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    result = run.finish()
+    run.close()
+
+    vs = 4 if args.dtype == "f32" else 8
+    alg_bytes = nnz_local * (2 * vs + 4) + (hi - lo) * 4 + 4 * m * vs  # a, c, 32-bit row per nnz; colptr; lambda/grad/b/y
+    avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.proj}_{args.entities}_{world}")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "dual_ascent_iterations_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic matching LP (reference benchmark generator model), {n} entities x {m} destinations, sparsity {args.sparsity}, "
+                f"{args.proj} projection map, gamma={args.gamma}, column-sharded over {world} GPU(s)",
+                "entities": n,
+                "destinations": m,
+                "nnz": total_nnz,
+                "projection": args.proj,
+                "parallelism": f"column-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "matching_fused_kernel",
+                "kernel_avg_ms": avg_kernel_s * 1e3,
+                "kernel_launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+            "aux": {
+                "generate_s": t_gen,
+                "setup_s": t_setup,
+                "final_dual_objective": result.dual_objective,
+                "layout": local.info(),
+                "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, inp, pm_local, total_nnz)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""ctypes binding of libdualip_hip.so (include/dualip_hip.h).
+
+The library is the product's only compute path: there is no Python/ATen fallback.  If the shared object cannot be
+loaded (not built, hipcc missing) every entry point raises -- loudly -- instead of computing on the CPU.
+
+``import torch`` happens before the library is opened so that ``libamdhip64.so.7`` resolves to the HIP runtime
+PyTorch-ROCm already loaded (same streams, same allocations).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL open, see module docstring)
+
+from . import _build
+
+DL_F32, DL_F64 = 0, 1
+DL_I32, DL_I64 = 0, 1
+PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLEX_EQ = range(6)
+LOG_COLS = 8
+
+_c_i64 = ctypes.c_int64
+_c_vp = ctypes.c_void_p
+_c_dbl = ctypes.c_double
+_c_int = ctypes.c_int
+
+
+class ProjDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("flags", ctypes.c_int32), ("p0", ctypes.c_double), ("p1", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/dualip_hip.h one to one (tests check the export list against the header)
+_SIGNATURES = {
+    "dl_last_error_string": (ctypes.c_char_p, []),
+    "dl_version": (_c_int, []),
+    "dl_matching_create": (
+        _c_int,
+        [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, ctypes.POINTER(ProjDesc), ctypes.c_int32, _c_vp, _c_vp],
+    ),
+    "dl_matching_destroy": (_c_int, [_c_vp]),
+    "dl_matching_info": (_c_i64, [_c_vp, _c_int]),
+    "dl_matching_calculate": (_c_int, [_c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),
+    "dl_matching_profile": (_c_int, [_c_vp, _c_int]),
+    "dl_matching_profile_read": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
+    "dl_dual_epilogue": (_c_int, [_c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),
+    "dl_agd_create": (_c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_int, _c_i64, _c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp]),
+    "dl_agd_destroy": (_c_int, [_c_vp]),
+    "dl_agd_x": (_c_vp, [_c_vp]),
+    "dl_agd_y": (_c_vp, [_c_vp]),
+    "dl_agd_grad": (_c_vp, [_c_vp]),
+    "dl_agd_get": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp]),
+    "dl_agd_step": (_c_int, [_c_vp, _c_vp, _c_vp, _c_dbl, _c_i64, _c_int, _c_dbl, _c_vp]),
+    "dl_agd_run_matching": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.POINTER(_c_dbl), _c_i64, _c_dbl, _c_vp, _c_vp]),
+    "dl_agd_read_log": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
+    "dl_agd_read_max_step": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), _c_vp]),
+    "dl_project_dense": (_c_int, [_c_i64, _c_i64, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_vp]),
+    "dl_jacobi_precondition": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Open libdualip_hip.so (building it with hipcc when the in-tree binary is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        path = _build.build()
+    except Exception as exc:  # no silent fallback: the HIP path is the product
+        if os.path.exists(_build.LIB_PATH):
+            path = _build.LIB_PATH  # stale but present (e.g. hipcc unavailable on this box): use the shipped binary
+        else:
+            raise HipLibraryError(f"libdualip_hip.so is not built and could not be built: {exc}") from exc
+    try:
+        handle = ctypes.CDLL(path)
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Map a C-ABI status to the exception type the reference raises for the same mistake."""
+    if rc == 0:
+        return
+    msg = load().dl_last_error_string().decode("utf-8", "replace")
+    if rc in (1, 2, 3):
+        raise ValueError(msg)
+    if rc == 5:
+        raise MemoryError(msg)
+    raise RuntimeError(f"libdualip_hip status {rc}: {msg}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return DL_F32
+    if dtype == torch.float64:
+        return DL_F64
+    raise ValueError(f"dualip_amd supports float32 and float64 values, got {dtype}")
+
+
+def idx_code(dtype: torch.dtype) -> int:
+    if dtype == torch.int32:
+        return DL_I32
+    if dtype == torch.int64:
+        return DL_I64
+    raise ValueError(f"CSC indices must be int32 or int64, got {dtype}")
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise HipLibraryError(
+            f"{what} lives on '{t.device}': dualip_amd computes on an AMD GPU through libdualip_hip.so only "
+            "(there is no CPU fallback); move the inputs to a ROCm device"
+        )
+
+
+def stream_ptr(device=None) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())

@@ -1,0 +1,393 @@
+// agd_kernels.hip -- the m-sized side of the dual ascent on gfx950: dual epilogue, accelerated-gradient step with the
+// Lipschitz-history step size (device resident, no host round trip), dense-block projection operator and
+// Jacobi row scaling.
+#include "common.h"
+#include <cstring>
+#include "wave.h"
+
+namespace dl {
+
+constexpr int kAgdThreads = 1024;
+constexpr int kLipsMax = 14;  // max_history_length - 1 (optimizers/agd_utils.py:69)
+
+struct AgdDevState {
+    double max_step;
+    double initial_step;
+    double last_step;
+    int32_t n_lips;  // valid entries in the ring, oldest first starting at head
+    int32_t head;
+    int64_t steps_done;
+    double lips[kLipsMax];  // values rounded to the working precision
+};
+
+template <class T>
+__device__ __forceinline__ T rnd(double v) { return (T)v; }
+
+// block-wide sum / max of doubles, result in every thread
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_allreduce(v, OpAdd());
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < NT / 64; ++w) t += sh[w];
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    v = wave_allreduce(v, OpMax());
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = sh[0];
+    for (int w = 1; w < NT / 64; ++w) t = sh[w] > t ? sh[w] : t;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dual epilogue (matching.py:25-34, 164-178)
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(kAgdThreads) void dual_epilogue_kernel(int64_t m, const double* __restrict__ packed, const T* __restrict__ b,
+                                                                    const T* __restrict__ lam, double gamma, T* __restrict__ grad_out,
+                                                                    double* __restrict__ scal_out) {
+    __shared__ double sh[kAgdThreads / 64];
+    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0;
+    for (int64_t j = threadIdx.x; j < m; j += kAgdThreads) {
+        const T gj = (T)((T)packed[j] - b[j]);
+        grad_out[j] = gj;
+        dvtg += (double)(T)(lam[j] * gj);
+        gmax = (double)gj > gmax ? (double)gj : gmax;
+        spos += gj > (T)0 ? (double)gj : 0.0;
+    }
+    dvtg = block_sum<kAgdThreads>(dvtg, sh);
+    gmax = block_max<kAgdThreads>(gmax, sh);
+    spos = block_sum<kAgdThreads>(spos, sh);
+    if (threadIdx.x == 0) {
+        const T nrm = (T)sqrt(packed[m + 1]);
+        const T reg = (T)((T)(gamma / 2.0) * (T)(nrm * nrm));  // (gamma/2) * norm(x)**2, matching.py:157
+        const T obj0 = (T)packed[m];
+        const T dv = (T)dvtg;
+        const T obj = (T)((T)(obj0 + reg) + dv);               // matching.py:33
+        scal_out[0] = (double)obj;
+        scal_out[1] = (double)reg;
+        scal_out[2] = (double)obj0;
+        scal_out[3] = (double)dv;
+        scal_out[4] = (m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;  // builtins.max(max(grad), 0), matching.py:168
+        scal_out[5] = (double)(T)spos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one AGD iteration (agd.py:163-187; agd_utils.py:12-89)
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+struct AgdArgs {
+    int64_t m;
+    const double* __restrict__ packed;  // [m+2]: A x, c.x, sum x^2
+    const T* __restrict__ b;
+    T* __restrict__ x;        // in: point of evaluation; out: next point
+    const T* __restrict__ y;  // y_{i-1}
+    T* __restrict__ y_new;    // in: y_{i-2} (the dual stored with the previous history entry); out: y_i
+    T* __restrict__ g_new;    // in: previous gradient; out: this gradient  (same buffer when in_place_g)
+    const T* __restrict__ g_old;
+    const uint8_t* __restrict__ eq_mask;
+    const float* __restrict__ beta;
+    AgdDevState* st;
+    double* __restrict__ log_row;  // kLogCols doubles for this iteration (may be null)
+    double gamma;
+    int64_t iter;  // 1-based
+    int decay_now;
+    double decay_factor;
+};
+
+template <class T>
+__global__ __launch_bounds__(kAgdThreads) void agd_step_kernel(AgdArgs<T> p) {
+    __shared__ double sh[kAgdThreads / 64];
+    __shared__ double step_sh;
+    const bool has_prev = p.st->steps_done > 0;
+    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, dg2 = 0.0, dy2 = 0.0, g2 = 0.0;
+    for (int64_t j = threadIdx.x; j < p.m; j += kAgdThreads) {
+        const T gj = (T)((T)p.packed[j] - p.b[j]);
+        dvtg += (double)(T)(p.x[j] * gj);
+        gmax = (double)gj > gmax ? (double)gj : gmax;
+        spos += gj > (T)0 ? (double)gj : 0.0;
+        g2 += (double)gj * (double)gj;
+        if (has_prev) {
+            const T dg = (T)(p.g_old[j] - gj);
+            const T dy = (T)(p.y_new[j] - p.y[j]);  // y_new still holds the previous history dual
+            dg2 += (double)dg * (double)dg;
+            dy2 += (double)dy * (double)dy;
+        }
+        p.g_new[j] = gj;
+    }
+    dvtg = block_sum<kAgdThreads>(dvtg, sh);
+    gmax = block_max<kAgdThreads>(gmax, sh);
+    spos = block_sum<kAgdThreads>(spos, sh);
+    g2 = block_sum<kAgdThreads>(g2, sh);
+    dg2 = block_sum<kAgdThreads>(dg2, sh);
+    dy2 = block_sum<kAgdThreads>(dy2, sh);
+
+    if (threadIdx.x == 0) {
+        AgdDevState& st = *p.st;
+        const T nrm = (T)sqrt(p.packed[p.m + 1]);
+        const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));
+        const T obj0 = (T)p.packed[p.m];
+        const T dv = (T)dvtg;
+        const T obj = (T)((T)(obj0 + reg) + dv);
+        // ---- calculate_step_size (agd_utils.py:65-89) ----
+        if (has_prev) {
+            const T num = (T)sqrt(dg2), den = (T)sqrt(dy2);
+            const T L = (T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
+            if (st.n_lips == kLipsMax) {
+                st.lips[st.head] = (double)L;  // overwrite the oldest
+                st.head = (st.head + 1) % kLipsMax;
+            } else {
+                st.lips[(st.head + st.n_lips) % kLipsMax] = (double)L;
+                st.n_lips += 1;
+            }
+        }
+        double step;
+        if (st.n_lips < kLipsMax) {
+            step = st.initial_step;  // incomplete history (agd_utils.py:57-58)
+        } else {
+            // builtins.max over the list, oldest first: a NaN is only kept when it comes first
+            double lmax = st.lips[st.head];
+            for (int q = 1; q < kLipsMax; ++q) {
+                const double v = st.lips[(st.head + q) % kLipsMax];
+                if (v > lmax) lmax = v;
+            }
+            if (isnan(lmax) || isinf(lmax)) step = st.initial_step;
+            else {
+                const double cand = lmax != 0.0 ? 1.0 / lmax : st.max_step;
+                step = cand < st.max_step ? cand : st.max_step;
+            }
+        }
+        st.last_step = step;
+        if (p.decay_now) st.max_step = step * p.decay_factor;  // agd.py:106-107
+        st.steps_done += 1;
+        step_sh = step;
+        if (p.log_row) {
+            p.log_row[0] = (double)obj;
+            p.log_row[1] = step;
+            p.log_row[2] = (double)reg;
+            p.log_row[3] = (double)dv;
+            p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;
+            p.log_row[5] = (double)(T)spos;
+            p.log_row[6] = (double)(T)sqrt(g2);
+            p.log_row[7] = (double)obj0;
+        }
+    }
+    __syncthreads();
+    const T stp = (T)step_sh;
+    const float bt = p.beta[p.iter - 1];
+    const T beta = (T)bt;
+    const T omb = (T)(float)(1.0f - bt);  // 1.0 - fp32 0-dim tensor stays fp32 (agd.py:184)
+    for (int64_t j = threadIdx.x; j < p.m; j += kAgdThreads) {
+        const T gj = p.g_new[j];
+        T yn = (T)(p.x[j] + (T)(gj * stp));                         // agd.py:181
+        const bool eq = p.eq_mask && p.eq_mask[j];
+        if (!eq) yn = yn > (T)0 ? yn : (T)0;                        // project_on_nn_cone, agd.py:13-21
+        const T yo = p.y[j];
+        p.x[j] = (T)((T)(yn * omb) + (T)(yo * beta));               // agd.py:184
+        p.y_new[j] = yn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ProjectionOperator.__call__ on a dense [L x K] block: one column per thread (coalesced across columns)
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void project_dense_kernel(int64_t L, int64_t K, const T* __restrict__ in, T* __restrict__ out, int kind, T p0, T p1, T ztol) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    if (kind != DL_PROJ_SIMPLEX && kind != DL_PROJ_SIMPLEX_EQ) {
+        for (int64_t i = 0; i < L; ++i) {
+            T v = in[i * K + k];
+            switch (kind) {
+                case DL_PROJ_BOX: v = v < p0 ? p0 : v; v = v > p1 ? p1 : v; break;
+                case DL_PROJ_CONE_LOWER: v = v < p0 ? p0 : v; break;
+                case DL_PROJ_CONE_UPPER: v = v > p0 ? p0 : v; break;
+                default: break;
+            }
+            out[i * K + k] = v;
+        }
+        return;
+    }
+    const T z = p0;
+    T S = (T)0, v1 = (T)(-INFINITY);
+    for (int64_t i = 0; i < L; ++i) {
+        T u = in[i * K + k];
+        u = u > (T)0 ? u : (T)0;
+        S = (T)(S + u);
+        v1 = u > v1 ? u : v1;
+    }
+    const bool projected = kind == DL_PROJ_SIMPLEX_EQ || S > ztol;
+    T th = (T)0;
+    bool onehot = false;
+    if (projected && L > 0) {
+        const T th_a = (T)(v1 - z), th_b = (T)((T)(S - z) / (T)L);
+        th = th_a > th_b ? th_a : th_b;
+        int64_t cnt_prev = 0;
+        for (int64_t it = 0; it <= L + 1; ++it) {
+            T sumA = (T)0;
+            int64_t cnt = 0;
+            for (int64_t i = 0; i < L; ++i) {
+                T u = in[i * K + k];
+                u = u > (T)0 ? u : (T)0;
+                if (u > th) {
+                    sumA = (T)(sumA + u);
+                    ++cnt;
+                }
+            }
+            if (it == 0 && cnt == 1) {
+                onehot = true;
+                break;
+            }
+            if (cnt == cnt_prev || cnt == 0) break;
+            th = (T)((T)(sumA - z) / (T)cnt);
+            cnt_prev = cnt;
+        }
+    }
+    for (int64_t i = 0; i < L; ++i) {
+        T u = in[i * K + k];
+        u = u > (T)0 ? u : (T)0;
+        T x = u;
+        if (projected) {
+            if (onehot) x = u > th ? z : (T)0;
+            else {
+                const T d = (T)(u - th);
+                x = d > (T)0 ? d : (T)0;
+            }
+        }
+        out[i * K + k] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Jacobi row scaling (preprocessing/precondition.py:8-28, sparse_utils.py:429-450)
+// ---------------------------------------------------------------------------------------------------------
+template <class T, class IdxT>
+__global__ void row_sumsq_kernel(int64_t nnz, const IdxT* __restrict__ rowidx, const T* __restrict__ a, double* __restrict__ acc) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const T v = a[k];
+        atomicAdd(&acc[(int64_t)rowidx[k]], (double)(T)(v * v));
+    }
+}
+template <class T>
+__global__ void row_norm_finish_kernel(int64_t m, const double* __restrict__ acc, T* __restrict__ norms, T* __restrict__ b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const T nr = (T)sqrt((double)(T)acc[i]);
+    norms[i] = nr;
+    b[i] = (T)(b[i] * (T)((T)1 / nr));
+}
+template <class T, class IdxT>
+__global__ void row_scale_kernel(int64_t nnz, const IdxT* __restrict__ rowidx, T* __restrict__ a, const T* __restrict__ norms) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        a[k] = (T)(a[k] * (T)((T)1 / norms[(int64_t)rowidx[k]]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side launchers used by api.hip
+// ---------------------------------------------------------------------------------------------------------
+int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* b, const void* lam, double gamma, void* grad_out,
+                    double* scal_out, hipStream_t st) {
+    if (val_dtype == DL_F32)
+        hipLaunchKernelGGL(dual_epilogue_kernel<float>, dim3(1), dim3(kAgdThreads), 0, st, m, packed, (const float*)b, (const float*)lam, gamma,
+                           (float*)grad_out, scal_out);
+    else
+        hipLaunchKernelGGL(dual_epilogue_kernel<double>, dim3(1), dim3(kAgdThreads), 0, st, m, packed, (const double*)b, (const double*)lam, gamma,
+                           (double*)grad_out, scal_out);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+size_t agd_state_bytes() { return sizeof(AgdDevState); }
+
+int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st) {
+    AgdDevState h;
+    memset(&h, 0, sizeof(h));
+    h.max_step = max_step;
+    h.initial_step = initial_step;
+    h.last_step = initial_step;
+    DL_HIP(hipMemcpyAsync(dev_state, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    DL_HIP(hipStreamSynchronize(st));  // h is a stack object
+    return 0;
+}
+
+int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st) {
+    AgdDevState h;
+    DL_HIP(hipMemcpyAsync(&h, dev_state, sizeof(h), hipMemcpyDeviceToHost, st));
+    DL_HIP(hipStreamSynchronize(st));
+    *out = h.max_step;
+    return 0;
+}
+
+int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
+                    hipStream_t st) {
+    double* log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
+    if (s->val_dtype == DL_F32) {
+        AgdArgs<float> p{s->m,   packed, (const float*)b, (float*)s->x, (const float*)s->y, (float*)s->y_old, (float*)s->g_old, (const float*)s->g,
+                         s->eq_mask, s->beta, (AgdDevState*)s->state, log_row, gamma, iter, decay_now, decay_factor};
+        hipLaunchKernelGGL(agd_step_kernel<float>, dim3(1), dim3(kAgdThreads), 0, st, p);
+    } else {
+        AgdArgs<double> p{s->m,   packed, (const double*)b, (double*)s->x, (const double*)s->y, (double*)s->y_old, (double*)s->g_old, (const double*)s->g,
+                          s->eq_mask, s->beta, (AgdDevState*)s->state, log_row, gamma, iter, decay_now, decay_factor};
+        hipLaunchKernelGGL(agd_step_kernel<double>, dim3(1), dim3(kAgdThreads), 0, st, p);
+    }
+    DL_HIP(hipGetLastError());
+    // rotate: the buffer that received y_i becomes y; the old y becomes the "previous history dual"
+    void* t = s->y;
+    s->y = s->y_old;
+    s->y_old = t;
+    t = s->g;
+    s->g = s->g_old;
+    s->g_old = t;
+    return 0;
+}
+
+int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st) {
+    if (K <= 0 || L <= 0) return 0;
+    const int threads = 256;
+    const int blocks = (int)((K + threads - 1) / threads);
+    if (val_dtype == DL_F32)
+        hipLaunchKernelGGL(project_dense_kernel<float>, dim3(blocks), dim3(threads), 0, st, L, K, (const float*)in, (float*)out, p->kind, (float)p->p0,
+                           (float)p->p1, (float)(p->p0 + 1e-6));
+    else
+        hipLaunchKernelGGL(project_dense_kernel<double>, dim3(blocks), dim3(threads), 0, st, L, K, (const double*)in, (double*)out, p->kind, p->p0, p->p1,
+                           p->p0 + 1e-6);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+template <class T, class IdxT>
+static int jacobi_typed(int64_t m, int64_t nnz, const void* rowidx, void* a, void* b, void* norms, hipStream_t st) {
+    double* acc = nullptr;
+    DL_HIP(hipMalloc(&acc, sizeof(double) * (size_t)(m > 0 ? m : 1)));
+    DL_HIP(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)(m > 0 ? m : 1), st));
+    const int threads = 256;
+    int64_t blocks64 = (nnz + threads - 1) / threads;
+    const int blocks = (int)(blocks64 > 4096 ? 4096 : (blocks64 > 0 ? blocks64 : 1));
+    hipLaunchKernelGGL((row_sumsq_kernel<T, IdxT>), dim3(blocks), dim3(threads), 0, st, nnz, (const IdxT*)rowidx, (const T*)a, acc);
+    hipLaunchKernelGGL(row_norm_finish_kernel<T>, dim3((int)((m + threads - 1) / threads > 0 ? (m + threads - 1) / threads : 1)), dim3(threads), 0, st, m, acc,
+                       (T*)norms, (T*)b);
+    hipLaunchKernelGGL((row_scale_kernel<T, IdxT>), dim3(blocks), dim3(threads), 0, st, nnz, (const IdxT*)rowidx, (T*)a, (const T*)norms);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(acc);
+    if (e != hipSuccess) return hip_fail(e, "jacobi launch");
+    if (e2 != hipSuccess) return hip_fail(e2, "jacobi sync");
+    return 0;
+}
+
+int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st) {
+    if (val_dtype == DL_F32) {
+        return idx_dtype == DL_I32 ? jacobi_typed<float, int32_t>(m, nnz, rowidx, a, b, norms, st) : jacobi_typed<float, int64_t>(m, nnz, rowidx, a, b, norms, st);
+    }
+    return idx_dtype == DL_I32 ? jacobi_typed<double, int32_t>(m, nnz, rowidx, a, b, norms, st) : jacobi_typed<double, int64_t>(m, nnz, rowidx, a, b, norms, st);
+}
+
+}  // namespace dl

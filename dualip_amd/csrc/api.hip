@@ -1,0 +1,509 @@
+// api.hip -- extern "C" surface of libdualip_hip.so (include/dualip_hip.h) and the one-off set-up work:
+// row-index re-encoding, wave-tile packing and workgroup partitioning.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace dl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return -(int)e;
+}
+
+// implemented in matching_kernels.hip / agd_kernels.hip
+int matching_calculate(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st);
+int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* b, const void* lam, double gamma, void* grad_out,
+                    double* scal_out, hipStream_t st);
+size_t agd_state_bytes();
+int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st);
+int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st);
+int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
+                    hipStream_t st);
+int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
+int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
+
+// ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
+template <class SrcT, class DstT>
+__global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t m, int* __restrict__ bad) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = (int64_t)src[k];
+        if (r < 0 || r >= m) {
+            *bad = 1;
+            dst[k] = 0;
+        } else {
+            dst[k] = (DstT)r;
+        }
+    }
+}
+
+template <class SrcT>
+static int reencode_rows(dl_matching* h, const void* rowidx, hipStream_t st, int* bad_dev) {
+    const int threads = 256;
+    int64_t b64 = (h->nnz + threads - 1) / threads;
+    const int blocks = (int)(b64 > 8192 ? 8192 : (b64 > 0 ? b64 : 1));
+    if (h->row_bytes == 2)
+        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint16_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint16_t*)h->rowidx, h->m, bad_dev);
+    else
+        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint32_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint32_t*)h->rowidx, h->m, bad_dev);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+static int owned_malloc(dl_matching* h, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    h->owned_bytes += bytes;
+    return 0;
+}
+
+static void matching_free(dl_matching* h) {
+    if (!h) return;
+    if (h->rowidx) (void)hipFree(h->rowidx);
+    if (h->tiles) (void)hipFree(h->tiles);
+    if (h->wg_tile_begin) (void)hipFree(h->wg_tile_begin);
+    if (h->projs) (void)hipFree(h->projs);
+    if (h->partial) (void)hipFree(h->partial);
+    if (h->partial_scal) (void)hipFree(h->partial_scal);
+    for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
+    delete h;
+}
+
+// Greedy packing of whole columns into <= 64-lane tiles (host, one-off).  Tiles never straddle projection entries.
+static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, std::vector<TileDesc>& tiles,
+                      std::vector<uint64_t>& tile_nnz_prefix, int64_t* n_long) {
+    tiles.clear();
+    tile_nnz_prefix.clear();
+    tile_nnz_prefix.push_back(0);
+    uint64_t cur_start = 0, cur_mask = 0;
+    uint32_t cur_cnt = 0, cur_proj = kNoProj;
+    uint64_t running = 0;
+    *n_long = 0;
+    auto flush = [&]() {
+        if (cur_cnt == 0) return;
+        TileDesc d;
+        uint64_t mask = cur_mask;
+        if (cur_cnt < 64) mask |= 1ull << cur_cnt;  // sentinel: lanes >= count form their own dummy segment
+        d.w0 = cur_start | ((uint64_t)cur_cnt << 40) | ((uint64_t)cur_proj << 48);
+        d.w1 = mask;
+        tiles.push_back(d);
+        running += cur_cnt;
+        tile_nnz_prefix.push_back(running);
+        cur_cnt = 0;
+        cur_mask = 0;
+    };
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t k0 = colptr[j], k1 = colptr[j + 1];
+        const int64_t len = k1 - k0;
+        if (len < 0) return fail(DL_E_LAYOUT, "ccol_indices is not monotone at column %lld", (long long)j);
+        if (len == 0) continue;
+        if ((uint64_t)k1 >= (1ull << 40)) return fail(DL_E_ARG, "nnz exceeds 2^40");
+        int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
+        if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
+        const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
+        if (len > kTileLanes) {
+            flush();
+            TileDesc d;
+            d.w0 = (uint64_t)k0 | kTileLongFlag | ((uint64_t)pj << 48);
+            d.w1 = (uint64_t)len;
+            tiles.push_back(d);
+            running += (uint64_t)len;
+            tile_nnz_prefix.push_back(running);
+            *n_long += 1;
+            continue;
+        }
+        if (cur_cnt > 0 && (cur_cnt + (uint32_t)len > (uint32_t)kTileLanes || pj != cur_proj)) flush();
+        if (cur_cnt == 0) {
+            cur_start = (uint64_t)k0;
+            cur_proj = pj;
+        }
+        cur_mask |= 1ull << cur_cnt;
+        cur_cnt += (uint32_t)len;
+    }
+    flush();
+    return 0;
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" {
+
+const char* dl_last_error_string(void) { return g_err; }
+int dl_version(void) { return 100; }
+
+int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx, int idx_dtype,
+                       const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj, const int32_t* col_proj,
+                       dl_stream_t stream) {
+    if (!out) return fail(DL_E_ARG, "out is null");
+    *out = nullptr;
+    if (m < 0 || n < 0 || nnz < 0) return fail(DL_E_ARG, "negative size");
+    if (!colptr || (nnz > 0 && (!rowidx || !a || !c))) return fail(DL_E_ARG, "null CSC array");
+    if (idx_dtype != DL_I32 && idx_dtype != DL_I64) return fail(DL_E_ARG, "bad idx_dtype %d", idx_dtype);
+    if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype %d", val_dtype);
+    if (n_proj < 0 || n_proj >= (int32_t)kNoProj || (n_proj > 0 && !projs_host)) return fail(DL_E_ARG, "bad projection table");
+    if (m >= (1ll << 32)) return fail(DL_E_ARG, "m must be < 2^32");
+    for (int32_t q = 0; q < n_proj; ++q) {
+        const int k = projs_host[q].kind;
+        if (k < DL_PROJ_NONE || k > DL_PROJ_SIMPLEX_EQ) return fail(DL_E_PROJ, "Unknown projection operator kind %d", k);
+        if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !(projs_host[q].p0 > 0.0))
+            return fail(DL_E_PROJ, "Simplex radius z must be positive.");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dl_matching* h = new (std::nothrow) dl_matching();
+    if (!h) return fail(DL_E_NOMEM, "out of host memory");
+    h->m = m;
+    h->n = n;
+    h->nnz = nnz;
+    h->val_dtype = val_dtype;
+    h->a = a;
+    h->c = c;
+    h->n_proj = n_proj;
+    const char* nodpp = getenv("DUALIP_HIP_NO_DPP");
+    h->use_dpp = !(nodpp && nodpp[0] == '1');
+    (void)hipGetDevice(&h->device);
+    int rc = 0;
+#define CK(expr)                    \
+    do {                            \
+        rc = (expr);                \
+        if (rc) {                   \
+            matching_free(h);       \
+            return rc;              \
+        }                           \
+    } while (0)
+#define CKH(expr)                                   \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) {                     \
+            matching_free(h);                       \
+            return hip_fail(_e, #expr);             \
+        }                                           \
+    } while (0)
+
+    // ---- column pointers and per-column projection ids to the host (one-off) ----
+    std::vector<int64_t> colptr_h((size_t)n + 1);
+    if (idx_dtype == DL_I64) {
+        CKH(hipMemcpyAsync(colptr_h.data(), colptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
+        CKH(hipStreamSynchronize(st));
+    } else {
+        std::vector<int32_t> tmp((size_t)n + 1);
+        CKH(hipMemcpyAsync(tmp.data(), colptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
+        CKH(hipStreamSynchronize(st));
+        for (size_t i = 0; i <= (size_t)n; ++i) colptr_h[i] = tmp[i];
+    }
+    if (colptr_h[0] != 0 || colptr_h[(size_t)n] != nnz) {
+        matching_free(h);
+        return fail(DL_E_LAYOUT, "ccol_indices[0] must be 0 and ccol_indices[n] must equal nnz");
+    }
+    std::vector<int32_t> col_proj_h;
+    if (col_proj) {
+        col_proj_h.resize((size_t)n);
+        CKH(hipMemcpyAsync(col_proj_h.data(), col_proj, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        CKH(hipStreamSynchronize(st));
+    }
+
+    // ---- tiles ----
+    std::vector<TileDesc> tiles;
+    std::vector<uint64_t> prefix;
+    CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, tiles, prefix, &h->n_long));
+    h->n_tiles = (int64_t)tiles.size();
+    if (h->n_tiles >= (1ll << 32)) {
+        matching_free(h);
+        return fail(DL_E_ARG, "too many tiles");
+    }
+
+    // ---- workgroups: one per CU, contiguous tile ranges of equal non-zero count ----
+    hipDeviceProp_t prop;
+    CKH(hipGetDeviceProperties(&prop, h->device));
+    int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* wg_env = getenv("DUALIP_HIP_NUM_WG");
+    if (wg_env && atoi(wg_env) > 0) n_cu = atoi(wg_env);
+    int64_t want = (h->n_tiles + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
+    h->n_wg = (int)(want < n_cu ? want : n_cu);
+    if (h->n_wg < 1) h->n_wg = h->n_tiles > 0 ? 1 : 0;
+    std::vector<uint32_t> wg_begin((size_t)h->n_wg + 1, 0);
+    {
+        const uint64_t total = prefix.back();
+        size_t t = 0;
+        for (int w = 0; w <= h->n_wg; ++w) {
+            const uint64_t target = h->n_wg ? (total * (uint64_t)w) / (uint64_t)h->n_wg : 0;
+            while (t < tiles.size() && prefix[t] < target) ++t;
+            wg_begin[(size_t)w] = (uint32_t)t;
+        }
+        if (h->n_wg) wg_begin[(size_t)h->n_wg] = (uint32_t)tiles.size();
+    }
+
+    // ---- LDS plan ----
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    auto lds_need = [&](bool lam, bool grad) { return (((lam ? (size_t)m : 0) + (grad ? (size_t)m : 0)) * vs + 15) / 16 * 16 + kLdsScratch; };
+    const char* mode_env = getenv("DUALIP_HIP_LDS_MODE");  // "both" | "grad" | "none": force a smaller plan (testing)
+    int max_mode = 2;
+    if (mode_env) max_mode = !strcmp(mode_env, "none") ? 0 : (!strcmp(mode_env, "grad") ? 1 : 2);
+    if (max_mode >= 2 && lds_need(true, true) <= kLdsBudget) {
+        h->lam_lds = true;
+        h->grad_lds = true;
+    } else if (max_mode >= 1 && lds_need(false, true) <= kLdsBudget) {
+        h->lam_lds = false;
+        h->grad_lds = true;
+    } else {
+        h->lam_lds = false;
+        h->grad_lds = false;
+    }
+    h->lds_bytes = lds_need(h->lam_lds, h->grad_lds);
+    h->mpad = (m + 63) / 64 * 64;
+    if (h->mpad == 0) h->mpad = 64;
+
+    // ---- device metadata ----
+    h->row_bytes = m <= 65536 ? 2 : 4;
+    const char* row_env = getenv("DUALIP_HIP_ROW32");
+    if (row_env && row_env[0] == '1') h->row_bytes = 4;
+    CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
+    CK(owned_malloc(h, (void**)&h->tiles, sizeof(TileDesc) * tiles.size()));
+    CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));
+    CK(owned_malloc(h, (void**)&h->projs, sizeof(ProjDev) * (size_t)(n_proj > 0 ? n_proj : 1)));
+    const size_t slabs = h->grad_lds ? (size_t)(h->n_wg > 0 ? h->n_wg : 1) : 1;
+    CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * vs));
+    CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    int* bad_dev = nullptr;
+    CKH(hipMalloc(&bad_dev, sizeof(int)));
+    hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
+    if (e == hipSuccess && !tiles.empty()) e = hipMemcpyAsync(h->tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->wg_tile_begin, wg_begin.data(), sizeof(uint32_t) * wg_begin.size(), hipMemcpyHostToDevice, st);
+    std::vector<ProjDev> pd((size_t)(n_proj > 0 ? n_proj : 1));
+    for (int32_t q = 0; q < n_proj; ++q) pd[(size_t)q] = ProjDev{projs_host[q].kind, 0, projs_host[q].p0, projs_host[q].p1};
+    if (e == hipSuccess) e = hipMemcpyAsync(h->projs, pd.data(), sizeof(ProjDev) * pd.size(), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+        (void)hipFree(bad_dev);
+        matching_free(h);
+        return hip_fail(e, "metadata upload");
+    }
+    if (nnz > 0) {
+        rc = idx_dtype == DL_I64 ? reencode_rows<int64_t>(h, rowidx, st, bad_dev) : reencode_rows<int32_t>(h, rowidx, st, bad_dev);
+        if (rc) {
+            (void)hipFree(bad_dev);
+            matching_free(h);
+            return rc;
+        }
+    }
+    int bad = 0;
+    e = hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // also keeps the host vectors alive until the uploads finished
+    (void)hipFree(bad_dev);
+    if (e != hipSuccess) {
+        matching_free(h);
+        return hip_fail(e, "create sync");
+    }
+    if (bad) {
+        matching_free(h);
+        return fail(DL_E_LAYOUT, "row index out of range [0, m)");
+    }
+#undef CK
+#undef CKH
+    *out = h;
+    return 0;
+}
+
+int dl_matching_destroy(dl_matching* h) {
+    matching_free(h);
+    return 0;
+}
+
+int64_t dl_matching_info(const dl_matching* h, int what) {
+    if (!h) return -1;
+    switch (what) {
+        case 0: return h->n_tiles;
+        case 1: return h->n_wg;
+        case 2: return (int64_t)h->lds_bytes;
+        case 3: return h->lam_lds ? 1 : 0;
+        case 4: return h->grad_lds ? 1 : 0;
+        case 5: return (int64_t)h->owned_bytes;
+        case 6: return h->n_long;
+        case 7: return h->row_bytes;
+        default: return -1;
+    }
+}
+
+int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, dl_stream_t stream) {
+    if (!h || !packed_out || (h->m > 0 && !lambda)) return fail(DL_E_ARG, "null argument");
+    if (!(gamma > 0.0) && !(gamma < 0.0)) return fail(DL_E_ARG, "gamma must be non-zero");
+    return matching_calculate(h, lambda, gamma, packed_out, x_out, (hipStream_t)stream);
+}
+
+int dl_matching_profile(dl_matching* h, int enable) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    h->prof_on = enable != 0;
+    h->prof_used = 0;
+    return 0;
+}
+
+int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host) {
+    if (!h || !total_ms_host || !launches_host) return fail(DL_E_ARG, "null argument");
+    double total = 0.0;
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        DL_HIP(hipEventSynchronize(h->prof_stop[i]));
+        float ms = 0.f;
+        DL_HIP(hipEventElapsedTime(&ms, h->prof_start[i], h->prof_stop[i]));
+        total += (double)ms;
+    }
+    *total_ms_host = total;
+    *launches_host = (int64_t)h->prof_used;
+    return 0;
+}
+
+int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void* b, const void* lambda, double gamma, void* grad_out,
+                     double* scal_out, dl_stream_t stream) {
+    if (m < 0 || !packed || !scal_out || (m > 0 && (!b || !lambda || !grad_out))) return fail(DL_E_ARG, "null argument");
+    if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype");
+    return launch_epilogue(m, val_dtype, packed, b, lambda, gamma, grad_out, scal_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static void agd_free(dl_agd* s) {
+    if (!s) return;
+    void* ptrs[] = {s->x, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, const float* beta_seq_host, double initial_step_size,
+                  double max_step_size, const uint8_t* eq_mask, const void* lambda0, dl_stream_t stream) {
+    if (!out) return fail(DL_E_ARG, "out is null");
+    *out = nullptr;
+    if (m < 0 || max_iter < 0 || (max_iter > 0 && !beta_seq_host) || (m > 0 && !lambda0)) return fail(DL_E_ARG, "bad argument");
+    if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype");
+    hipStream_t st = (hipStream_t)stream;
+    dl_agd* s = new (std::nothrow) dl_agd();
+    if (!s) return fail(DL_E_NOMEM, "out of host memory");
+    s->m = m;
+    s->max_iter = max_iter;
+    s->val_dtype = val_dtype;
+    s->eq_mask = eq_mask;
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    const size_t vb = (size_t)(m > 0 ? m : 1) * vs;
+    hipError_t e = hipSuccess;
+    void** vecs[] = {&s->x, &s->y, &s->y_old, &s->g, &s->g_old};
+    for (void** v : vecs)
+        if (e == hipSuccess) e = hipMalloc(v, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->beta, sizeof(float) * (size_t)(max_iter > 0 ? max_iter : 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->log, sizeof(double) * kLogCols * (size_t)(max_iter > 0 ? max_iter : 1));
+    if (e == hipSuccess) e = hipMalloc(&s->state, agd_state_bytes());
+    if (e == hipSuccess) e = hipMalloc((void**)&s->packed, sizeof(double) * (size_t)(m + 2));
+    if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->x, lambda0, vb, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->y, lambda0, vb, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->y_old, 0, vb, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->g, 0, vb, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->g_old, 0, vb, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->log, 0, sizeof(double) * kLogCols * (size_t)(max_iter > 0 ? max_iter : 1), st);
+    if (e == hipSuccess && max_iter > 0) e = hipMemcpyAsync(s->beta, beta_seq_host, sizeof(float) * (size_t)max_iter, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) {
+        agd_free(s);
+        return hip_fail(e, "dl_agd_create");
+    }
+    int rc = agd_state_init(s->state, initial_step_size, max_step_size, st);  // synchronises (covers beta_seq_host too)
+    if (rc) {
+        agd_free(s);
+        return rc;
+    }
+    *out = s;
+    return 0;
+}
+
+int dl_agd_destroy(dl_agd* s) {
+    agd_free(s);
+    return 0;
+}
+
+const void* dl_agd_x(const dl_agd* s) { return s ? s->x : nullptr; }
+const void* dl_agd_y(const dl_agd* s) { return s ? s->y : nullptr; }
+const void* dl_agd_grad(const dl_agd* s) { return s ? s->g : nullptr; }
+
+int dl_agd_get(const dl_agd* s, int which, void* dst, dl_stream_t stream) {
+    if (!s || which < 0 || which > 2 || (s->m > 0 && !dst)) return fail(DL_E_ARG, "bad argument");
+    const void* src = which == 0 ? s->x : (which == 1 ? s->y : s->g);
+    const size_t vs = s->val_dtype == DL_F32 ? 4 : 8;
+    if (s->m > 0) DL_HIP(hipMemcpyAsync(dst, src, vs * (size_t)s->m, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int dl_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
+                dl_stream_t stream) {
+    if (!s || !packed || (s->m > 0 && !b)) return fail(DL_E_ARG, "null argument");
+    if (iter < 1 || iter > s->max_iter) return fail(DL_E_STATE, "iteration %lld outside 1..max_iter=%lld", (long long)iter, (long long)s->max_iter);
+    return launch_agd_step(s, packed, b, gamma, iter, decay_now, decay_factor, (hipStream_t)stream);
+}
+
+int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_iter, int64_t n_iters, double* gamma_io_host,
+                        int64_t gamma_decay_steps, double decay_factor, void* x_out, dl_stream_t stream) {
+    if (!s || !f || !gamma_io_host || (s->m > 0 && !b)) return fail(DL_E_ARG, "null argument");
+    if (s->m != f->m || s->val_dtype != f->val_dtype) return fail(DL_E_STATE, "optimizer state and objective disagree on m / dtype");
+    if (first_iter < 1 || n_iters < 0 || first_iter + n_iters - 1 > s->max_iter) return fail(DL_E_STATE, "iteration range outside 1..max_iter");
+    hipStream_t st = (hipStream_t)stream;
+    double gamma = *gamma_io_host;
+    for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
+        void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
+        int rc = matching_calculate(f, s->x, gamma, s->packed, xo, st);
+        if (rc) return rc;
+        const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
+        rc = launch_agd_step(s, s->packed, b, gamma, it, decay_now, decay_factor, st);
+        if (rc) return rc;
+        if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
+    }
+    *gamma_io_host = gamma;
+    return 0;
+}
+
+int dl_agd_read_log(dl_agd* s, int64_t first, int64_t count, double* rows_host, dl_stream_t stream) {
+    if (!s || !rows_host || first < 0 || count < 0 || first + count > s->max_iter) return fail(DL_E_ARG, "bad log range");
+    hipStream_t st = (hipStream_t)stream;
+    if (count > 0) DL_HIP(hipMemcpyAsync(rows_host, s->log + first * kLogCols, sizeof(double) * kLogCols * (size_t)count, hipMemcpyDeviceToHost, st));
+    DL_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int dl_agd_read_max_step(dl_agd* s, double* out_host, dl_stream_t stream) {
+    if (!s || !out_host) return fail(DL_E_ARG, "null argument");
+    return agd_state_read_max_step(s->state, out_host, (hipStream_t)stream);
+}
+
+int dl_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* proj_host, dl_stream_t stream) {
+    if (L < 0 || K < 0 || !proj_host || ((L * K) > 0 && (!in || !out))) return fail(DL_E_ARG, "bad argument");
+    if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype");
+    const int k = proj_host->kind;
+    if (k < DL_PROJ_NONE || k > DL_PROJ_SIMPLEX_EQ) return fail(DL_E_PROJ, "Unknown projection operator kind %d", k);
+    if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !(proj_host->p0 > 0.0)) return fail(DL_E_PROJ, "Simplex radius z must be positive.");
+    return launch_project_dense(L, K, val_dtype, in, out, proj_host, (hipStream_t)stream);
+}
+
+int dl_jacobi_precondition(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* row_norms_out, int val_dtype,
+                           dl_stream_t stream) {
+    if (m < 0 || nnz < 0 || (nnz > 0 && (!rowidx || !a)) || (m > 0 && (!b || !row_norms_out))) return fail(DL_E_ARG, "bad argument");
+    if (idx_dtype != DL_I32 && idx_dtype != DL_I64) return fail(DL_E_ARG, "bad idx_dtype");
+    if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype");
+    return launch_jacobi(m, nnz, rowidx, idx_dtype, a, b, row_norms_out, val_dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// common.h -- shared declarations of libdualip_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/dualip_hip.h"
+
+namespace dl {
+
+// ---------------------------------------------------------------------------------------------------------
+// status plumbing (no exception crosses the C ABI)
+// ---------------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DL_HIP(expr)                                          \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return ::dl::hip_fail(_e, #expr); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// wave tiles: the unit of work of one 64-lane wavefront
+// ---------------------------------------------------------------------------------------------------------
+// A SHORT tile is a run of whole, consecutive, non-empty columns with <= 64 non-zeros in total, all of the same
+// projection entry; lane k owns non-zero (nnz_start + k).  A LONG tile is one column with more than 64 non-zeros,
+// walked by the wavefront in 64-wide strides.
+//   w0: [ 0..39] nnz_start   [40..46] count (short tiles, 1..64)   [47] long flag   [48..63] projection id
+//   w1: short: bit k set <=> lane k starts a column (plus a sentinel bit at `count` when count < 64)
+//       long : the column length
+struct TileDesc {
+    uint64_t w0;
+    uint64_t w1;
+};
+constexpr int kTileLanes = 64;
+constexpr uint64_t kTileLongFlag = 1ull << 47;
+constexpr uint32_t kNoProj = 0xFFFFu;
+
+__host__ __device__ inline uint64_t tile_nnz_start(uint64_t w0) { return w0 & ((1ull << 40) - 1); }
+__host__ __device__ inline uint32_t tile_count(uint64_t w0) { return (uint32_t)((w0 >> 40) & 0x7F); }
+__host__ __device__ inline uint32_t tile_proj(uint64_t w0) { return (uint32_t)(w0 >> 48); }
+
+// device copy of dl_proj_desc in the working precision is built on the fly from this
+struct ProjDev {
+    int32_t kind;
+    int32_t pad;
+    double p0;
+    double p1;
+};
+
+constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
+constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
+constexpr size_t kLdsScratch = 512;            // per-workgroup reduction scratch (bytes)
+constexpr int kLogCols = 8;                    // doubles per iteration in the AGD log
+
+// ---------------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------------
+}  // namespace dl
+
+struct dl_matching {
+    int64_t m = 0, n = 0, nnz = 0;
+    int val_dtype = DL_F32;
+    int device = 0;
+    const void* a = nullptr;  // caller-owned
+    const void* c = nullptr;  // caller-owned
+    void* rowidx = nullptr;   // owned, uint16 or uint32
+    int row_bytes = 4;
+    dl::TileDesc* tiles = nullptr;      // owned
+    uint32_t* wg_tile_begin = nullptr;  // owned, [n_wg + 1]
+    dl::ProjDev* projs = nullptr;       // owned
+    int32_t n_proj = 0;
+    int64_t n_tiles = 0, n_long = 0;
+    int n_wg = 0;
+    bool lam_lds = false, grad_lds = false;
+    size_t lds_bytes = 0;
+    int64_t mpad = 0;          // row stride of the partial slabs (elements)
+    void* partial = nullptr;   // owned: [n_wg][mpad] val (grad_lds) or [1][mpad] (global atomics)
+    double* partial_scal = nullptr;  // owned: [n_wg][2]
+    size_t owned_bytes = 0;
+    bool use_dpp = true;
+    // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
+    bool prof_on = false;
+    size_t prof_used = 0;
+    std::vector<hipEvent_t> prof_start, prof_stop;
+};
+
+struct dl_agd {
+    int64_t m = 0, max_iter = 0;
+    int val_dtype = DL_F32;
+    void* x = nullptr;       // owned, val[m]: point of evaluation
+    void* y = nullptr;       // owned
+    void* y_old = nullptr;   // owned: the dual stored with the previous history entry
+    void* g = nullptr;       // owned: gradient of the latest step (A x - b)
+    void* g_old = nullptr;   // owned
+    const uint8_t* eq_mask = nullptr;  // caller-owned
+    float* beta = nullptr;   // owned, float[max_iter]
+    double* log = nullptr;   // owned, [max_iter][kLogCols]
+    void* state = nullptr;   // owned, dl::AgdDevState
+    double* packed = nullptr;  // owned scratch double[m+2] for dl_agd_run_matching
+};

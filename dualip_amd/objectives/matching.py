@@ -1,0 +1,279 @@
+"""Matching-LP dual objective on the HIP path.
+
+Reference: src/dualip/objectives/matching.py (MatchingInputArgs :12-22, MatchingSolverDualObjectiveFunction :37-188,
+MatchingSolverDualObjectiveFunctionDistributed :191-307).  Same class names, constructor arguments, ``calculate``
+signature and ObjectiveResult contents; the computation itself is one fused HIP pass over the CSC arrays
+(``dl_matching_calculate``) plus an m-sized epilogue (``dl_dual_epilogue``) -- see include/dualip_hip.h.
+
+Differences from the reference, all deliberate:
+  * maps with several ProjectionEntry keys project every column with its own entry (the reference overwrites the
+    other keys' columns with uninitialised memory, sparse_utils.py:177,220); columns in no entry are left unprojected;
+  * ``batching`` is accepted and ignored: the kernel's wave tiles replace the power-of-two nnz buckets;
+  * the distributed wrapper issues ONE sum-all-reduce of [A x | c.x | sum x^2] per call and every rank finishes the
+    objective identically (the reference does 3 reduces + barrier and only rank 0 holds the result).
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from dualip_amd import _hip
+from dualip_amd.objectives.base import BaseInputArgs, BaseObjective, ObjectiveResult
+from dualip_amd.projections.base import ProjectionEntry, project
+
+
+@dataclass
+class MatchingInputArgs(BaseInputArgs):
+    """A, c: ``torch.sparse_csc`` (m x n) with identical pattern; one primal variable per stored non-zero."""
+
+    A: torch.Tensor
+    c: torch.Tensor
+    projection_map: dict
+    b_vec: Optional[torch.Tensor]
+    equality_mask: Optional[torch.Tensor] = None
+
+
+def _column_projection_table(projection_map, n: int, device):
+    """Flatten {key: ProjectionEntry} into (descriptors, per-column entry id or None when one entry covers all)."""
+    descs = []
+    entries = list(projection_map.items())
+    for _, entry in entries:
+        descs.append(project(entry.proj_type, **entry.proj_params).descriptor())  # raises ValueError like the reference
+    if len(entries) == 1:
+        idx = entries[0][1].indices
+        if isinstance(idx, range) and idx == range(n):
+            return descs, None
+        if not isinstance(idx, (range, torch.Tensor)) and len(idx) == n and n > 0 and idx[0] == 0 and idx[-1] == n - 1:
+            t = torch.as_tensor(idx)
+            if torch.equal(t, torch.arange(n)):
+                return descs, None
+    col_proj = torch.full((n,), -1, dtype=torch.int32, device=device)
+    for q, (_, entry) in enumerate(entries):
+        idx = entry.indices
+        if isinstance(idx, range):
+            if len(idx):
+                col_proj[idx.start : idx.stop : idx.step] = q
+        else:
+            t = torch.as_tensor(idx, dtype=torch.int64, device=device)
+            if t.numel():
+                if int(t.min()) < 0 or int(t.max()) >= n:
+                    raise ValueError("projection_map index outside [0, n)")
+                col_proj[t] = q
+    return descs, col_proj
+
+
+class MatchingSolverDualObjectiveFunction(BaseObjective):
+    """Dual gradient / objective / regularisation penalty of the matching LP on one GPU.
+
+    With ``b_vec=None`` it computes only the local partial sums (A x, c.x, gamma/2 ||x||^2) -- the building block of
+    the distributed objective, as in the reference (matching.py:57-58, 179-184).
+    """
+
+    _dualip_native = True
+
+    def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True):
+        A, c = matching_input_args.A, matching_input_args.c
+        if A.layout != torch.sparse_csc or c.layout != torch.sparse_csc:
+            raise ValueError("Both A and c must be CSC-format sparse tensors")
+        if A.shape != c.shape or A.values().shape != c.values().shape:
+            raise ValueError("A and c must share the same sparsity pattern")
+        _hip.require_device(A.values(), "A")
+        _hip.require_device(c.values(), "c")
+        self.A, self.c = A, c
+        self.gamma = gamma
+        self.b_vec = matching_input_args.b_vec
+        self.projection_map = matching_input_args.projection_map
+        self.is_distributed = self.b_vec is None
+        self.equality_mask = matching_input_args.equality_mask
+        self.batching = batching
+        self.device = A.values().device
+        self.dtype = A.values().dtype
+        self.m, self.n = int(A.shape[0]), int(A.shape[1])
+        self.nnz = int(A.values().shape[0])
+        if self.b_vec is not None:
+            _hip.require_device(self.b_vec, "b_vec")
+            if self.b_vec.dtype != self.dtype:
+                raise ValueError("b_vec must have the dtype of A")
+
+        # keep the tensors the kernel reads alive and contiguous (values are referenced, not copied)
+        self._a_vals = A.values()
+        self._c_vals = c.values()
+        if not (self._a_vals.is_contiguous() and self._c_vals.is_contiguous()):
+            raise ValueError("CSC value arrays must be contiguous")
+        if self._c_vals.dtype != self.dtype:
+            raise ValueError("A and c must have the same dtype")
+        colptr = A.ccol_indices().contiguous()
+        rowidx = A.row_indices().contiguous()
+        descs, col_proj = _column_projection_table(self.projection_map, self.n, self.device)
+        self._descs = (_hip.ProjDesc * max(len(descs), 1))(*descs)
+
+        lib = _hip.load()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib.dl_matching_create(
+                ctypes.byref(handle),
+                self.m,
+                self.n,
+                self.nnz,
+                _hip.ptr(colptr),
+                _hip.ptr(rowidx),
+                _hip.idx_code(colptr.dtype),
+                _hip.ptr(self._a_vals),
+                _hip.ptr(self._c_vals),
+                _hip.dtype_code(self.dtype),
+                self._descs,
+                len(descs),
+                _hip.ptr(col_proj),
+                _hip.stream_ptr(self.device),
+            )
+        _hip.check(rc)
+        self._handle = handle
+        self._lib = lib
+        self._packed = torch.zeros(self.m + 2, dtype=torch.float64, device=self.device)
+        self._scal = torch.zeros(6, dtype=torch.float64, device=self.device)
+        self._primal = None  # allocated on the first save_primal, then reused (the reference aliases its scratch too)
+
+    # ------------------------------------------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                self._lib.dl_matching_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def info(self) -> dict:
+        """Kernel-side layout facts (tiles, workgroups, LDS plan) for benchmarks and tests."""
+        names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes"]
+        return {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
+
+    def profile(self, enable: bool) -> None:
+        """Bracket every fused-pass launch with HIP events on the launch stream (measurement hook)."""
+        _hip.check(self._lib.dl_matching_profile(self._handle, int(bool(enable))))
+
+    def profile_read(self):
+        """(launches, total milliseconds) of the fused pass since ``profile(True)``; waits for the last launch."""
+        ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+        _hip.check(self._lib.dl_matching_profile_read(self._handle, ctypes.byref(ms), ctypes.byref(cnt)))
+        return int(cnt.value), float(ms.value)
+
+    def _primal_buffer(self) -> torch.Tensor:
+        if self._primal is None:
+            self._primal = torch.empty(self.nnz, dtype=self.dtype, device=self.device)
+        return self._primal
+
+    def _check_dual(self, dual_val: torch.Tensor) -> torch.Tensor:
+        _hip.require_device(dual_val, "dual_val")
+        if dual_val.dtype != self.dtype or dual_val.shape != (self.m,):
+            raise ValueError(f"dual_val must be a {self.dtype} vector of length {self.m}")
+        return dual_val.contiguous()
+
+    def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Local pass only: returns the internal float64 buffer [A x (m) | c.x | sum x^2] (overwritten by the next call)."""
+        if gamma is not None and gamma != self.gamma:
+            self.gamma = gamma
+        lam = self._check_dual(dual_val)
+        with torch.cuda.device(self.device):
+            rc = self._lib.dl_matching_calculate(
+                self._handle, _hip.ptr(lam), float(self.gamma), _hip.ptr(self._packed), _hip.ptr(x_out), _hip.stream_ptr(self.device)
+            )
+        _hip.check(rc)
+        return self._packed
+
+    def finish(self, packed: torch.Tensor, dual_val: torch.Tensor, b_vec: torch.Tensor) -> ObjectiveResult:
+        """grad = A x - b, dual objective and slack statistics from a (possibly all-reduced) packed buffer."""
+        lam = self._check_dual(dual_val)
+        grad = torch.empty(self.m, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.dl_dual_epilogue(
+                self.m,
+                _hip.dtype_code(self.dtype),
+                _hip.ptr(packed),
+                _hip.ptr(b_vec),
+                _hip.ptr(lam),
+                float(self.gamma),
+                _hip.ptr(grad),
+                _hip.ptr(self._scal),
+                _hip.stream_ptr(self.device),
+            )
+        _hip.check(rc)
+        s = self._scal.to(self.dtype)
+        return ObjectiveResult(
+            dual_gradient=grad,
+            dual_objective=s[0],
+            reg_penalty=s[1],
+            dual_val_times_grad=s[3],
+            max_pos_slack=s[4],
+            sum_pos_slack=s[5],
+        )
+
+    def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, **kwargs) -> ObjectiveResult:
+        x_out = self._primal_buffer() if save_primal else None
+        packed = self.calculate_packed(dual_val, gamma, x_out)
+        if not self.is_distributed:
+            res = self.finish(packed, dual_val, self.b_vec)
+        else:
+            res = ObjectiveResult(
+                dual_gradient=packed[: self.m].to(self.dtype),
+                dual_objective=packed[self.m].to(self.dtype),
+                reg_penalty=(packed[self.m + 1] * (self.gamma / 2)).to(self.dtype),
+            )
+        if save_primal:
+            res.primal_var = x_out
+            res.primal_objective = packed[self.m].to(self.dtype)
+        return res
+
+
+class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
+    """Column-sharded objective: one process per GPU, each holding a contiguous block of entities.
+
+    Same constructor as the reference (matching.py:218-225).  ``calculate`` runs the local fused pass, sum-all-reduces
+    the packed [A x | c.x | sum x^2] buffer once over the default process group (RCCL on ROCm) and finishes the
+    objective on every rank, so all ranks can apply the identical dual update without a broadcast.
+    ``local_objective`` may be injected (tests drive the exchange logic on CPU/gloo with an oracle-backed local part).
+    """
+
+    _dualip_native = True
+
+    def __init__(
+        self,
+        local_matching_input_args: MatchingInputArgs,
+        b_vec: torch.Tensor,
+        gamma: float,
+        host_device=None,
+        batching: bool = True,
+        local_objective=None,
+        process_group=None,
+    ):
+        self.gamma = gamma
+        self.host_device = host_device
+        self.equality_mask = local_matching_input_args.equality_mask if local_matching_input_args is not None else None
+        self.process_group = process_group
+        if local_objective is None:
+            if local_matching_input_args.b_vec is not None:
+                raise ValueError("local partitions must be built with b_vec=None (b_vec is shared by all ranks)")
+            local_objective = MatchingSolverDualObjectiveFunction(local_matching_input_args, gamma, batching)
+        self.local_objective = local_objective
+        self.device = local_objective.device
+        self.dtype = local_objective.dtype
+        self.m = local_objective.m
+        # every rank finishes the objective on its own device (the reference moves b to host_device = cuda:0)
+        self.b_vec = b_vec.to(device=self.device, dtype=self.dtype)
+
+    def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out=None) -> torch.Tensor:
+        if gamma is not None and gamma != self.gamma:
+            self.gamma = gamma
+        packed = self.local_objective.calculate_packed(dual_val, self.gamma, x_out)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)
+        return packed
+
+    def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, rank: int = 0, **kwargs) -> ObjectiveResult:
+        if save_primal:
+            raise NotImplementedError("save_primal=True is not yet supported in distributed mode")
+        packed = self.calculate_packed(dual_val, gamma)
+        self.local_objective.gamma = self.gamma
+        return self.local_objective.finish(packed, dual_val, self.b_vec)

@@ -1,0 +1,305 @@
+"""Accelerated (Nesterov) projected gradient ascent on the dual.
+
+Reference: src/dualip/optimizers/agd.py (AcceleratedGradientDescent :66-229, project_on_nn_cone :13-21,
+format_objective_result_summary :24-63).  Constructor arguments, ``maximize(f, initial_value, rank=0)`` and the
+returned SolverResult are those of the reference.
+
+Three execution routes, chosen by what ``f`` is:
+  1. native matching objective on one GPU  -> the whole loop runs on the device (``dl_agd_run_matching``): fused
+     objective pass + step kernel per iteration, no host synchronisation; logs are fetched in chunks;
+  2. native column-sharded objective       -> per iteration: local fused pass, ONE RCCL sum-all-reduce of the packed
+     partial, then the same device step on every rank (identical duals on all ranks, no broadcast);
+  3. any other BaseObjective (user defined) -> generic torch implementation of the same recurrences, on whatever
+     device the objective's tensors live.
+``iteration_callback``: None = print one summary line per iteration (reference default; routes 1/2 print from the
+device log after each chunk), a callable = called every iteration with the full ObjectiveResult (forces one host
+synchronisation per iteration on routes 1/2), False = silent.
+"""
+import ctypes
+import math
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from dualip_amd import _hip
+from dualip_amd.objectives.base import BaseObjective
+from dualip_amd.optimizers.agd_utils import calculate_step_size
+from dualip_amd.types import ObjectiveResult, SolverResult
+
+
+def project_on_nn_cone(y: torch.Tensor, equality_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Clamp the inequality duals at zero; rows flagged in ``equality_mask`` are free."""
+    clamped = y.clamp(min=0)
+    return clamped if equality_mask is None else torch.where(equality_mask, y, clamped)
+
+
+def format_objective_result_summary(iteration: int, objective_result: ObjectiveResult) -> str:
+    """``iter=… | dual_objective=… | dual_grad_norm=… | <optional fields>`` -- one line per iteration."""
+
+    def show(name, val):
+        if val is None:
+            return None
+        try:
+            if isinstance(val, torch.Tensor):
+                return f"{name}={val.item()}" if val.numel() == 1 else f"{name}.shape={tuple(val.shape)}"
+            return f"{name}={val}"
+        except Exception:
+            return f"{name}=<unprintable>"
+
+    try:
+        norm = f"dual_grad_norm={float(objective_result.dual_gradient.norm().item())}"
+    except Exception:
+        norm = "dual_grad_norm=<unprintable>"
+    fields = [f"iter={iteration}", show("dual_objective", objective_result.dual_objective), norm]
+    for name in ("reg_penalty", "primal_objective", "primal_var", "dual_val_times_grad", "max_pos_slack", "sum_pos_slack"):
+        fields.append(show(name, getattr(objective_result, name, None)))
+    return " | ".join(f for f in fields if f is not None)
+
+
+def compute_beta_seq(max_iter: int) -> torch.Tensor:
+    """Momentum weights beta_i = (1 - t_{i+1}) / t_{i+2}, t_0 = 0, t_i = (1 + sqrt(1 + 4 t_{i-1}^2)) / 2.
+
+    Bit-compatible with the reference (agd.py:93-100), whose float32 storage rounds every t_i: the recurrence is
+    evaluated with float32 products/sums, the square root in double, and a float32 division at the end.
+    """
+    f32 = np.float32
+    t = np.zeros(max_iter + 2, dtype=f32)
+    for i in range(1, max_iter + 2):
+        inner = f32(f32(1.0) + f32(f32(4.0) * f32(t[i - 1] * t[i - 1])))
+        t[i] = f32((1.0 + math.sqrt(float(inner))) / 2.0)
+    beta = (f32(1.0) - t[1 : max_iter + 1]) / t[2 : max_iter + 2] if max_iter > 0 else np.zeros(0, dtype=f32)
+    return torch.from_numpy(np.asarray(beta, dtype=f32))
+
+
+class AcceleratedGradientDescent:
+    def __init__(
+        self,
+        max_iter: int,
+        gamma: float,
+        initial_step_size: float = 1e-5,
+        max_step_size: float = 0.1,
+        gamma_decay_type: str = None,
+        gamma_decay_params: dict = {},
+        save_primal: bool = False,
+        iteration_callback: Optional[Callable[[int, ObjectiveResult], None]] = None,
+    ):
+        self.initial_step_size = initial_step_size
+        self.max_step_size = max_step_size
+        self.max_iter = max_iter
+        self.beta_seq = compute_beta_seq(max_iter)
+        self.streams = None
+        self.gamma = gamma
+        self.gamma_decay_type = gamma_decay_type
+        self.gamma_decay_params = gamma_decay_params
+        self.save_primal = save_primal
+        self._user_callback = iteration_callback
+        self.iteration_callback = self._default_iteration_callback if iteration_callback in (None, False) else iteration_callback
+        self.log_chunk = 100  # native routes: iterations between host reads of the device log
+
+    # ---- small pieces shared by all routes --------------------------------------------------------------
+    def _compute_beta_seq(self, max_iter: int) -> torch.Tensor:
+        return compute_beta_seq(max_iter)
+
+    def _check_decay(self):
+        if self.gamma is not None and self.gamma_decay_type is not None and self.gamma_decay_type != "step":
+            raise ValueError(f"Unsupported gamma decay type: {self.gamma_decay_type}")
+
+    def _update_gamma(self, itr: int, step_size: float):
+        if self.gamma_decay_type != "step":
+            raise ValueError(f"Unsupported gamma decay type: {self.gamma_decay_type}")
+        if itr % self.gamma_decay_params["decay_steps"] == 0:
+            factor = self.gamma_decay_params["decay_factor"]
+            self.gamma = self.gamma * factor
+            self.max_step_size = step_size * factor
+
+    def _default_iteration_callback(self, iteration: int, objective_result: ObjectiveResult) -> None:
+        try:
+            print(format_objective_result_summary(iteration, objective_result))
+        except Exception:
+            pass  # logging must never stop the solve
+
+    # ---- entry point ----------------------------------------------------------------------------------------
+    def maximize(self, f: BaseObjective, initial_value: torch.Tensor, rank: int = 0) -> SolverResult:
+        if getattr(f, "_dualip_native", False) and self.gamma is not None and initial_value.is_cuda:
+            return self._maximize_native(f, initial_value, rank)
+        return self._maximize_generic(f, initial_value, rank)
+
+    # ---- route 3: generic torch path ---------------------------------------------------------------------------
+    def _maximize_generic(self, f, initial_value, rank):
+        grad_hist, dual_hist, obj_log, step_log = [], [], [], []
+        x = initial_value.clone()
+        y = initial_value.clone()
+        mask = f.equality_mask
+        result, dual_obj = None, 0.0
+        for i in range(1, self.max_iter + 1):
+            kw = {} if self.gamma is None else {"gamma": self.gamma}
+            if i == self.max_iter and self.save_primal:
+                kw["save_primal"] = True
+            result = f.calculate(dual_val=x, rank=rank, **kw)
+            if rank == 0:
+                if self._user_callback is not False:
+                    self.iteration_callback(i, result)
+                dual_obj = result.dual_objective.cpu().item()
+                obj_log.append(dual_obj)
+                step = calculate_step_size(
+                    result.dual_gradient, y, grad_hist, dual_hist, initial_step_size=self.initial_step_size, max_step_size=self.max_step_size
+                )
+                step_log.append(step)
+                y_next = project_on_nn_cone(x + result.dual_gradient * step, mask)
+                beta = self.beta_seq[i - 1]
+                x = y_next * (1.0 - beta) + y * beta
+                y = y_next
+                if self.gamma is not None and self.gamma_decay_type is not None:
+                    self._update_gamma(i, step)
+            if dist.is_available() and dist.is_initialized():
+                dist.broadcast(x, src=0)
+                dist.broadcast(y, src=0)
+        if rank == 0:
+            return SolverResult(dual_val=y, dual_objective=dual_obj, objective_result=result, dual_objective_log=obj_log, step_size_log=step_log)
+        return SolverResult(dual_val=y, dual_objective=0.0, objective_result=result, dual_objective_log=[], step_size_log=[])
+
+    # ---- routes 1 and 2: device-resident loop ------------------------------------------------------------------
+    def start_device_run(self, f, initial_value: torch.Tensor, rank: int = 0) -> "DeviceRun":
+        """Create the device-resident optimiser state for a native objective without iterating yet
+        (``maximize`` = start_device_run + advance(max_iter) + finish; benchmarks time ``advance`` directly)."""
+        self._check_decay()
+        return DeviceRun(self, f, initial_value, rank)
+
+    def _maximize_native(self, f, initial_value, rank):
+        run = self.start_device_run(f, initial_value, rank)
+        try:
+            per_iteration = callable(self._user_callback)
+            chunk = 1 if per_iteration else max(1, int(self.log_chunk))
+            while run.done < self.max_iter:
+                first = run.done
+                n = run.advance(min(chunk, self.max_iter - run.done))
+                if per_iteration or self._user_callback is None:
+                    rows = run.read_log(first, n)
+                    for k in range(n):
+                        it = first + k + 1
+                        if per_iteration:
+                            self.iteration_callback(it, run.result_from_row(rows[k], with_grad=True))
+                        elif rank == 0:
+                            print(_summary_from_log(it, rows[k]))
+            return run.finish()
+        finally:
+            run.close()
+
+
+def _summary_from_log(iteration: int, row) -> str:
+    return (
+        f"iter={iteration} | dual_objective={row[0]} | dual_grad_norm={row[6]} | reg_penalty={row[2]} | "
+        f"dual_val_times_grad={row[3]} | max_pos_slack={row[4]} | sum_pos_slack={row[5]}"
+    )
+
+
+class DeviceRun:
+    """One maximize() run whose x, y, gradient history, step-size ring and logs live on the GPU (``dl_agd`` in
+    include/dualip_hip.h).  ``advance(n)`` enqueues n iterations and returns without synchronising."""
+
+    def __init__(self, solver: "AcceleratedGradientDescent", f, initial_value: torch.Tensor, rank: int = 0):
+        self.solver, self.f, self.rank = solver, f, rank
+        self.lib = _hip.load()
+        self.sharded = hasattr(f, "local_objective")
+        self.local = f.local_objective if self.sharded else f
+        if not self.sharded and f.b_vec is None:
+            raise ValueError("a matching objective built with b_vec=None only provides local partial sums; wrap it in the distributed objective")
+        self.device, self.dtype, self.m = self.local.device, self.local.dtype, self.local.m
+        self.b_vec = f.b_vec
+        self.max_iter = solver.max_iter
+        if solver.save_primal and self.sharded:
+            raise NotImplementedError("save_primal=True is not yet supported in distributed mode")
+        self.primal = self.local._primal_buffer() if solver.save_primal else None
+        lam0 = initial_value.to(device=self.device, dtype=self.dtype).contiguous()
+        mask = f.equality_mask
+        self._mask_u8 = None if mask is None else mask.to(device=self.device).to(torch.uint8).contiguous()
+        self.decay_steps, self.decay_factor = 0, 1.0
+        if solver.gamma_decay_type == "step":
+            self.decay_steps = int(solver.gamma_decay_params["decay_steps"])
+            self.decay_factor = float(solver.gamma_decay_params["decay_factor"])
+        self._beta_host = solver.beta_seq.contiguous()
+        self.gamma = ctypes.c_double(float(solver.gamma))
+        self.done = 0
+        self._x_dev = None
+        self.state = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(
+                self.lib.dl_agd_create(
+                    ctypes.byref(self.state), self.m, _hip.dtype_code(self.dtype), self.max_iter, _hip.ptr(self._beta_host),
+                    float(solver.initial_step_size), float(solver.max_step_size), _hip.ptr(self._mask_u8), _hip.ptr(lam0), _hip.stream_ptr(self.device),
+                )
+            )
+
+    def close(self):
+        if self.state is not None and self.state.value:
+            self.lib.dl_agd_destroy(self.state)
+        self.state = None
+
+    def _fetch(self, which: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Copy a state vector owned by the C library (0 = x, 1 = y, 2 = gradient) into a torch tensor."""
+        if out is None:
+            out = torch.empty(self.m, dtype=self.dtype, device=self.device)
+        _hip.check(self.lib.dl_agd_get(self.state, which, _hip.ptr(out), _hip.stream_ptr(self.device)))
+        return out
+
+    def advance(self, n: int) -> int:
+        n = min(int(n), self.max_iter - self.done)
+        if n <= 0:
+            return 0
+        lib = self.lib
+        with torch.cuda.device(self.device):
+            stream = _hip.stream_ptr(self.device)
+            last = self.done + n == self.max_iter
+            if not self.sharded:
+                _hip.check(
+                    lib.dl_agd_run_matching(
+                        self.state, self.local._handle, _hip.ptr(self.b_vec), self.done + 1, n, ctypes.byref(self.gamma), self.decay_steps,
+                        self.decay_factor, _hip.ptr(self.primal) if (last and self.primal is not None) else None, stream,
+                    )
+                )
+            else:
+                for it in range(self.done + 1, self.done + n + 1):
+                    self._x_dev = self._fetch(0, out=self._x_dev)
+                    packed = self.f.calculate_packed(self._x_dev, self.gamma.value)  # local pass + ONE sum-all-reduce
+                    decay_now = int(self.decay_steps > 0 and it % self.decay_steps == 0)
+                    _hip.check(lib.dl_agd_step(self.state, _hip.ptr(packed), _hip.ptr(self.b_vec), self.gamma.value, it, decay_now, self.decay_factor, stream))
+                    if decay_now:
+                        self.gamma.value = self.gamma.value * self.decay_factor
+        self.done += n
+        return n
+
+    def read_log(self, first: int, count: int) -> np.ndarray:
+        rows = np.zeros((max(count, 0), _hip.LOG_COLS), dtype=np.float64)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.dl_agd_read_log(self.state, first, count, rows.ctypes.data, _hip.stream_ptr(self.device)))
+        return rows
+
+    def result_from_row(self, row, with_grad: bool) -> ObjectiveResult:
+        t = torch.tensor(row, dtype=torch.float64, device=self.device).to(self.dtype)
+        grad = self._fetch(2) if with_grad else torch.empty(0, dtype=self.dtype, device=self.device)
+        return ObjectiveResult(dual_gradient=grad, dual_objective=t[0], reg_penalty=t[2], dual_val_times_grad=t[3], max_pos_slack=t[4], sum_pos_slack=t[5])
+
+    def finish(self) -> SolverResult:
+        solver = self.solver
+        rows = self.read_log(0, self.done)
+        mx = ctypes.c_double(0.0)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.dl_agd_read_max_step(self.state, ctypes.byref(mx), _hip.stream_ptr(self.device)))
+            dual_val = self._fetch(1)
+            final = self.result_from_row(rows[-1], with_grad=True) if self.done > 0 else None
+        solver.gamma = self.gamma.value
+        if self.decay_steps > 0:
+            solver.max_step_size = mx.value
+        if final is not None and self.primal is not None and self.done == self.max_iter:
+            final.primal_var = self.primal
+            final.primal_objective = torch.tensor(rows[-1][7], dtype=torch.float64, device=self.device).to(self.dtype)
+        obj_log = rows[:, 0].tolist()
+        return SolverResult(
+            dual_val=dual_val,
+            dual_objective=obj_log[-1] if obj_log else 0.0,
+            objective_result=final,
+            dual_objective_log=obj_log,
+            step_size_log=rows[:, 1].tolist(),
+        )

@@ -1,0 +1,96 @@
+"""Solver entry point (reference: src/dualip/run_solver.py:17-146).
+
+``run_solver(input_args, solver_args, compute_args, objective_args)`` moves the inputs to the host device, builds
+the objective, runs the accelerated gradient ascent and returns a SolverResult.  ``compute_device_num > 1`` is the
+one-process-per-GPU mode: call it from every rank of an initialised ``torch.distributed`` group with the GLOBAL
+problem; each rank keeps its own column shard (the reference's multi-device branch cannot be constructed,
+run_solver.py:60-67, so this is the intended behaviour rather than a copy of it).
+"""
+from dataclasses import fields
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from dualip_amd.objectives.base import BaseInputArgs
+from dualip_amd.objectives.matching import (
+    MatchingInputArgs,
+    MatchingSolverDualObjectiveFunction,
+    MatchingSolverDualObjectiveFunctionDistributed,
+)
+from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs, SolverResult
+from dualip_amd.utils.dist_utils import global_to_local_projection_map, split_tensors_to_devices
+
+
+def transfer_tensors_to_device(input_args: BaseInputArgs, device: str):
+    """New instance of the same dataclass with every tensor field moved to ``device``."""
+    moved = {}
+    for f in fields(input_args):
+        value = getattr(input_args, f.name)
+        moved[f.name] = value.to(device) if isinstance(value, torch.Tensor) else value
+    return type(input_args)(**moved)
+
+
+def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device) -> MatchingInputArgs:
+    a_blocks, c_blocks, index_map = split_tensors_to_devices(input_args.A, input_args.c, [input_args.A.device] * world)
+    return MatchingInputArgs(
+        A=a_blocks[rank].to(device),
+        c=c_blocks[rank].to(device),
+        projection_map=global_to_local_projection_map(input_args.projection_map, index_map[rank]),
+        b_vec=None,
+        equality_mask=input_args.equality_mask,
+    )
+
+
+def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_args: ComputeArgs, objective_args: ObjectiveArgs):
+    kind = objective_args.objective_type
+    if kind == "matching":
+        if compute_args.compute_device_num == 1:
+            return MatchingSolverDualObjectiveFunction(matching_input_args=input_args, gamma=solver_args.gamma)
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("compute_device_num > 1 needs an initialised torch.distributed group (one process per GPU)")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world != compute_args.compute_device_num:
+            raise ValueError(f"compute_device_num={compute_args.compute_device_num} but the process group has {world} ranks")
+        device = torch.device("cuda", torch.cuda.current_device())
+        local = _local_shard(input_args, rank, world, device)
+        return MatchingSolverDualObjectiveFunctionDistributed(
+            local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device
+        )
+    if kind == "miplib2017":
+        raise NotImplementedError("the miplib2017 objective is not part of the MI355X matching hot path (SURVEY.md 8f3)")
+    raise ValueError(f"Objective type {kind} not supported")
+
+
+def run_solver(
+    input_args: BaseInputArgs,
+    solver_args: SolverArgs,
+    compute_args: ComputeArgs,
+    objective_args: ObjectiveArgs,
+    mlflow_config: Optional[object] = None,
+) -> SolverResult:
+    if mlflow_config is not None and getattr(mlflow_config, "enabled", False):
+        raise NotImplementedError("MLflow tracking is outside the MI355X hot path (SURVEY.md 2, OUT OF SCOPE)")
+    host_device = compute_args.host_device
+    sharded = compute_args.compute_device_num > 1
+    if not sharded:
+        input_args = transfer_tensors_to_device(input_args, host_device)
+    objective = build_objective(input_args, solver_args, compute_args, objective_args)
+    solver = AcceleratedGradientDescent(
+        initial_step_size=solver_args.initial_step_size,
+        max_iter=solver_args.max_iter,
+        max_step_size=solver_args.max_step_size,
+        gamma=solver_args.gamma,
+        gamma_decay_type=solver_args.gamma_decay_type,
+        gamma_decay_params=solver_args.gamma_decay_params,
+        save_primal=solver_args.save_primal,
+    )
+    if solver_args.initial_dual_path is not None:
+        initial_dual = torch.load(solver_args.initial_dual_path)  # warm start
+    else:
+        initial_dual = torch.zeros_like(input_args.b_vec)
+    device = objective.device if hasattr(objective, "device") else host_device
+    initial_dual = initial_dual.to(device)
+    rank = dist.get_rank() if (sharded and dist.is_initialized()) else 0
+    return solver.maximize(objective, initial_dual, rank=rank)

@@ -1,0 +1,179 @@
+/*
+ * dualip_hip.h -- C ABI of libdualip_hip.so: the MI355X (gfx950) dual-ascent hot path of the matching LP.
+ *
+ * This is the drop-in boundary for the reference's (linkedin/DuaLip v5.0.1, pure PyTorch) hot path.  The
+ * reference has no FFI of its own -- every "kernel" is a sequence of ATen ops -- so each entry point below names
+ * the reference Python function (path:line under /root/reference) whose work it replaces.  INTEGRATION.md shows
+ * the ctypes stub a DuaLip maintainer would add to call them.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = -(hipError_t), >0 = DL_E_* argument/contract error.
+ *     dl_last_error_string() describes the last non-zero status of the calling thread.
+ *   - all array arguments are DEVICE pointers unless the name ends in _host.
+ *   - all work is enqueued on the given hipStream_t (pass torch.cuda.current_stream().cuda_stream); nothing
+ *     synchronises unless documented.  One handle per (process, device); handles are not thread-safe.
+ *   - the caller owns every input/output buffer; a handle owns only derived metadata (re-encoded row indices,
+ *     the wave-tile table, per-workgroup partial slabs, the step-size ring).
+ *   - no C++ exception crosses the boundary; no torch types appear in any signature.
+ */
+#ifndef DUALIP_HIP_H
+#define DUALIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dl_stream_t; /* hipStream_t */
+
+enum { DL_F32 = 0, DL_F64 = 1 };  /* value dtype of A, c, lambda, b, x */
+enum { DL_I32 = 0, DL_I64 = 1 };  /* dtype of the caller's ccol_indices / row_indices (torch CSC gives int64) */
+
+/* projection kinds: reference registry names (src/dualip/projections/{box,cone,simplex}.py) */
+enum {
+    DL_PROJ_NONE = 0,        /* identity: "cone" with neither bound (cone.py:26-28) / column in no ProjectionEntry */
+    DL_PROJ_BOX = 1,         /* "box": clamp(x, p0=lower, p1=upper)               box.py:15-16 */
+    DL_PROJ_CONE_LOWER = 2,  /* "cone" lower=p0: clamp(min=p0)                    cone.py:22-23 */
+    DL_PROJ_CONE_UPPER = 3,  /* "cone" upper=p0: clamp(max=p0)                    cone.py:24-25 */
+    DL_PROJ_SIMPLEX = 4,     /* "simplex": {x>=0, sum x <= p0=z}, 1e-6 slack      simplex.py:126-236,239-255 */
+    DL_PROJ_SIMPLEX_EQ = 5   /* "simplex_eq": {x>=0, sum x == z} over the column's own non-zeros (simplex.py:258-274;
+                                the reference's dependence on the padded bucket height is NOT reproduced) */
+};
+
+enum {
+    DL_OK = 0,
+    DL_E_ARG = 1,        /* null pointer / negative size / bad enum                      (reference: ValueError) */
+    DL_E_PROJ = 2,       /* unknown projection kind or z <= 0                            (ValueError / assert z > 0) */
+    DL_E_LAYOUT = 3,     /* ccol_indices not monotone, row index out of range, nnz mismatch (non-CSC input) */
+    DL_E_STATE = 4,      /* call sequence violates the handle's contract */
+    DL_E_NOMEM = 5
+};
+
+/* One ProjectionEntry's operator (src/dualip/projections/base.py:8-12) without its index list. */
+typedef struct {
+    int32_t kind;   /* DL_PROJ_* */
+    int32_t flags;  /* reserved, 0 */
+    double p0;      /* box: lower | cone: the bound | simplex: z */
+    double p1;      /* box: upper */
+} dl_proj_desc;
+
+typedef struct dl_matching dl_matching; /* opaque: one matching objective (A, c) on one device */
+typedef struct dl_agd dl_agd;           /* opaque: device-resident state of one maximize() run */
+
+const char* dl_last_error_string(void);
+int dl_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Matching objective
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Replaces MatchingSolverDualObjectiveFunction.__init__/_compute_buckets (src/dualip/objectives/matching.py:43-114).
+ *   A and c are CSC (m x n) with the SAME pattern: colptr[n+1], rowidx[nnz] (idx_dtype), a[nnz], c[nnz] (val_dtype);
+ *   one primal variable per stored non-zero.  a and c are referenced, not copied (the reference keeps references
+ *   too; Jacobi pre-conditioning applied in place before or after creation is seen).  rowidx is re-encoded once to
+ *   uint16 (m <= 65536) or uint32; colptr is consumed once to build the wave-tile table (<= 64 non-zeros of whole
+ *   columns per wavefront, tiles never mix projection entries) that replaces the reference's power-of-two buckets.
+ *   col_proj: int32[n], index into projs_host per column, -1 = no entry; NULL = every column uses projs_host[0].
+ * Synchronises `stream` once (one-off host-side tile packing). */
+int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx,
+                       int idx_dtype, const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host,
+                       int32_t n_proj, const int32_t* col_proj, dl_stream_t stream);
+int dl_matching_destroy(dl_matching* h);
+
+/* Size/introspection: what = 0 number of wave tiles, 1 workgroups used, 2 LDS bytes per workgroup,
+ * 3 lambda staged in LDS (0/1), 4 gradient privatised in LDS (0/1), 5 bytes of owned device memory,
+ * 6 number of long (>64 nnz) columns, 7 row-index width in bytes. */
+int64_t dl_matching_info(const dl_matching* h, int what);
+
+/* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays
+ * (matching.py:116-161 with b_vec=None; sparse_utils.py:54-85 left_multiply_sparse, :26-51 elementwise_csc,
+ *  :133-220 apply_F_to_columns, :223-243 row_sums_csc):
+ *     v_k = a_k * (-(1/gamma) * lambda[row_k]) + (-(1/gamma) * c_k);   x = Proj_column(v)
+ *     packed_out[0..m) = A x (double);  packed_out[m] = c . x;  packed_out[m+1] = sum x^2
+ *   lambda: val_dtype[m].  packed_out: double[m+2] (sum-all-reducible across column shards).
+ *   x_out: val_dtype[nnz] or NULL (primal_var; only written when non-NULL, matching.py:185-187). */
+int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out,
+                          dl_stream_t stream);
+
+/* Measurement hook: while enabled, every fused-pass launch of this handle is bracketed by HIP events recorded on
+ * the launch stream (bench.py's roofline leg).  dl_matching_profile_read waits for the last recorded launch and
+ * returns the number of launches and their summed duration in milliseconds since the hook was (re-)enabled. */
+int dl_matching_profile(dl_matching* h, int enable);
+int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host);
+
+/* The rest of calculate() for the non-distributed objective and for rank 0 of the distributed one
+ * (calc_grad matching.py:25-34, slacks :164-178, distributed :280-299):
+ *     grad_out = val(packed[0..m)) - b;  reg = gamma/2 * sum x^2;  dual_obj = c.x + reg + lambda . grad_out
+ *   scal_out (double[6], device): dual_objective, reg_penalty, primal_objective (c.x), dual_val_times_grad,
+ *   max_pos_slack, sum_pos_slack. */
+int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void* b, const void* lambda, double gamma,
+                     void* grad_out, double* scal_out, dl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Accelerated gradient ascent (AcceleratedGradientDescent.maximize, src/dualip/optimizers/agd.py:121-229)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Device-resident optimiser state: x (the point the gradient is taken at), y, the previous gradient/dual pair
+ * and the ring of 14 Lipschitz estimates of calculate_step_size (optimizers/agd_utils.py:65-89), the current
+ * max_step_size (coupled to gamma decay, agd.py:102-109), and per-iteration logs.
+ *   beta_seq_host: float32[max_iter] exactly as agd.py:93-100 computes it (the host side owns that recipe).
+ *   eq_mask: uint8[m] (non-zero = equality row, left unprojected, agd.py:13-21) or NULL.
+ *   lambda0: val_dtype[m] initial dual (x = y = lambda0, agd.py:144-145). */
+int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, const float* beta_seq_host,
+                  double initial_step_size, double max_step_size, const uint8_t* eq_mask, const void* lambda0,
+                  dl_stream_t stream);
+int dl_agd_destroy(dl_agd* s);
+
+/* Pointer to the device vector the next gradient must be evaluated at (x, val_dtype[m]). */
+const void* dl_agd_x(const dl_agd* s);
+/* Pointer to y (val_dtype[m]) -- SolverResult.dual_val after the last step. */
+const void* dl_agd_y(const dl_agd* s);
+/* Pointer to the gradient (A x - b, val_dtype[m]) of the most recent step. */
+const void* dl_agd_grad(const dl_agd* s);
+
+/* Copy one of the state vectors into caller memory (device to device, asynchronous): which = 0 x, 1 y, 2 grad. */
+int dl_agd_get(const dl_agd* s, int which, void* dst, dl_stream_t stream);
+
+/* One iteration of the maximiser after the objective's local pass (and, when sharded, after the sum-all-reduce
+ * of `packed`): epilogue (as dl_dual_epilogue, on x) + calculate_step_size + projected ascent step + momentum
+ * (agd.py:163-187).  `iter` is 1-based.  gamma is the value used by the objective for THIS iteration.
+ * decay_now != 0 applies max_step_size = step * decay_factor after the step (agd.py:106-107; the caller
+ * multiplies its own gamma).  Nothing is copied to the host. */
+int dl_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
+                double decay_factor, dl_stream_t stream);
+
+/* Whole single-device loop without returning to the host between iterations: for iter = first_iter ..
+ * first_iter + n_iters - 1: dl_matching_calculate(x) ; dl_agd_step.  gamma_decay_steps = 0 disables decay
+ * (gamma_decay_type None); otherwise gamma *= decay_factor after every iteration with iter % steps == 0.
+ * *gamma_io_host: gamma in / gamma after the last iteration out.  x_out (val_dtype[nnz] or NULL) receives the
+ * primal of the LAST iteration only (agd.py:155-158 save_primal). */
+int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_iter, int64_t n_iters,
+                        double* gamma_io_host, int64_t gamma_decay_steps, double decay_factor, void* x_out,
+                        dl_stream_t stream);
+
+/* Copy logs to the host (synchronises the stream).  rows [first, first+count) of the per-iteration log; each row
+ * is 8 doubles: dual_objective, step_size, reg_penalty, dual_val_times_grad, max_pos_slack, sum_pos_slack,
+ * ||grad||_2, primal_objective (c.x). */
+int dl_agd_read_log(dl_agd* s, int64_t first, int64_t count, double* rows_host, dl_stream_t stream);
+/* Current max_step_size (after decay coupling); synchronises. */
+int dl_agd_read_max_step(dl_agd* s, double* out_host, dl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stand-alone operators of the reference API
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* ProjectionOperator.__call__ on a dense row-major [L x K] block, one vector per column
+ * (src/dualip/projections/base.py:15-36; box.py, cone.py, simplex.py).  out may alias in. */
+int dl_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* proj_host,
+                     dl_stream_t stream);
+
+/* jacobi_precondition (src/dualip/preprocessing/precondition.py:8-28): row_norms_out[m] = ||A_i||_2,
+ * then a[k] *= 1/row_norms[row_k] and b *= 1/row_norms in place.  rowidx in idx_dtype. */
+int dl_jacobi_precondition(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b,
+                           void* row_norms_out, int val_dtype, dl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUALIP_HIP_H */

@@ -56,3 +56,68 @@ def scala_5x5():
 
 
 SCALA_GOLDEN = [(2, -3.6010155991401818), (16, -3.60842718733725), (23, -3.5080258013053136), (29, -3.4868496294227143)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# torch-side helpers
+# ---------------------------------------------------------------------------------------------------------
+def torch_args(p, dtype, projection_map, device, with_b=True, equality_mask=None):
+    """MatchingInputArgs of the package under test from a numpy problem dict."""
+    import torch
+
+    from dualip_amd.objectives.matching import MatchingInputArgs
+
+    td = {"f32": torch.float32, "f64": torch.float64}[dtype] if isinstance(dtype, str) else dtype
+    colptr = torch.from_numpy(np.ascontiguousarray(p["colptr"], dtype=np.int64))
+    rowidx = torch.from_numpy(np.ascontiguousarray(p["rowidx"], dtype=np.int64))
+    A = torch.sparse_csc_tensor(colptr, rowidx, torch.from_numpy(np.array(p["a"], dtype=np.float64)).to(td), size=(p["m"], p["n"])).to(device)
+    C = torch.sparse_csc_tensor(colptr, rowidx, torch.from_numpy(np.array(p["c"], dtype=np.float64)).to(td), size=(p["m"], p["n"])).to(device)
+    b = torch.from_numpy(np.array(p["b"], dtype=np.float64)).to(td).to(device) if with_b else None
+    em = None if equality_mask is None else torch.from_numpy(np.asarray(equality_mask)).to(device)
+    return MatchingInputArgs(A=A, c=C, projection_map=projection_map, b_vec=b, equality_mask=em)
+
+
+def sub_problem(p, lo, hi):
+    k0, k1 = int(p["colptr"][lo]), int(p["colptr"][hi])
+    return dict(m=p["m"], n=hi - lo, colptr=p["colptr"][lo : hi + 1] - k0, rowidx=p["rowidx"][k0:k1], a=p["a"][k0:k1], c=p["c"][k0:k1], b=p["b"])
+
+
+class OracleLocalObjective:
+    """CPU stand-in for the per-rank fused pass (tests only): same surface as the native local objective
+    (``calculate_packed`` / ``finish``), arithmetic by oracle/.  Lets the world_size-2 gloo tests exercise the
+    exchange + update logic of the distributed objective without a GPU."""
+
+    def __init__(self, p, projs, gamma, np_dtype, col_proj=None):
+        import torch
+
+        self.p, self.projs, self.gamma, self.np_dtype, self.col_proj = p, projs, gamma, np_dtype, col_proj
+        self.m = p["m"]
+        self.device = torch.device("cpu")
+        self.dtype = torch.float32 if np_dtype == np.float32 else torch.float64
+
+    def calculate_packed(self, dual_val, gamma=None, x_out=None):
+        import torch
+
+        import oracle
+
+        if gamma is not None:
+            self.gamma = gamma
+        ax, obj0, ssq, _ = oracle.matching_calculate(
+            self.p["m"], self.p["n"], self.p["colptr"], self.p["rowidx"], self.p["a"], self.p["c"], dual_val.numpy(), self.gamma,
+            self.projs, col_proj=self.col_proj, dtype=self.np_dtype, want_x=False,
+        )
+        return torch.from_numpy(np.concatenate([ax.astype(np.float64), [obj0, ssq]]))
+
+    def finish(self, packed, dual_val, b_vec):
+        import torch
+
+        from dualip_amd.types import ObjectiveResult
+        from oracle import agd_oracle
+
+        pk = packed.numpy()
+        grad, obj, reg, dvtg, mx, sm = agd_oracle.epilogue(pk[: self.m], pk[self.m], pk[self.m + 1], dual_val.numpy(), b_vec.numpy(), self.gamma, self.np_dtype)
+        t = lambda v: torch.tensor(float(v), dtype=self.dtype)  # noqa: E731
+        return ObjectiveResult(
+            dual_gradient=torch.from_numpy(np.asarray(grad, dtype=self.np_dtype)), dual_objective=t(obj), reg_penalty=t(reg),
+            dual_val_times_grad=t(dvtg), max_pos_slack=t(mx), sum_pos_slack=t(sm),
+        )
