@@ -8,7 +8,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdualip_hip.so")
 SOURCES = ["api.hip", "matching_kernels.hip", "agd_kernels.hip"]
-HEADERS = ["common.h", "wave.h", os.path.join("..", "..", "include", "dualip_hip.h")]
+HEADERS = ["common.h", "wave.h", "simplex.h", os.path.join("..", "..", "include", "dualip_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

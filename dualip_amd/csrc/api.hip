@@ -1,5 +1,6 @@
 // api.hip -- extern "C" surface of libdualip_hip.so (include/dualip_hip.h) and the one-off set-up work:
 // row-index re-encoding, wave-tile packing and workgroup partitioning.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -42,10 +43,13 @@ int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma
                     hipStream_t st);
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
+int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
+size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
 template <class SrcT, class DstT>
-__global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t m, int* __restrict__ bad) {
+__global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t m, int* __restrict__ bad,
+                                     unsigned int* __restrict__ row_count) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = (int64_t)src[k];
         if (r < 0 || r >= m) {
@@ -53,19 +57,20 @@ __global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, 
             dst[k] = 0;
         } else {
             dst[k] = (DstT)r;
+            atomicAdd(&row_count[r], 1u);  // one-off histogram: bounds the fixed-point gradient accumulators
         }
     }
 }
 
 template <class SrcT>
-static int reencode_rows(dl_matching* h, const void* rowidx, hipStream_t st, int* bad_dev) {
+static int reencode_rows(dl_matching* h, const void* rowidx, hipStream_t st, int* bad_dev, unsigned int* row_count) {
     const int threads = 256;
     int64_t b64 = (h->nnz + threads - 1) / threads;
     const int blocks = (int)(b64 > 8192 ? 8192 : (b64 > 0 ? b64 : 1));
     if (h->row_bytes == 2)
-        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint16_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint16_t*)h->rowidx, h->m, bad_dev);
+        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint16_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint16_t*)h->rowidx, h->m, bad_dev, row_count);
     else
-        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint32_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint32_t*)h->rowidx, h->m, bad_dev);
+        hipLaunchKernelGGL((reencode_rows_kernel<SrcT, uint32_t>), dim3(blocks), dim3(threads), 0, st, h->nnz, (const SrcT*)rowidx, (uint32_t*)h->rowidx, h->m, bad_dev, row_count);
     DL_HIP(hipGetLastError());
     return 0;
 }
@@ -86,14 +91,22 @@ static void matching_free(dl_matching* h) {
     if (h->projs) (void)hipFree(h->projs);
     if (h->partial) (void)hipFree(h->partial);
     if (h->partial_scal) (void)hipFree(h->partial_scal);
+    if (h->shift_dev) (void)hipFree(h->shift_dev);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
     delete h;
 }
 
 // Greedy packing of whole columns into <= 64-lane tiles (host, one-off).  Tiles never straddle projection entries.
-static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, std::vector<TileDesc>& tiles,
+// tile_nnz_prefix is a COST prefix: non-zeros weighted by the projection's relative cost per tile (the simplex tiles
+// run segmented scans and Newton passes; measured ~2.6x a clamp tile), so that contiguous equal-cost ranges finish together.
+static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs, std::vector<TileDesc>& tiles,
                       std::vector<uint64_t>& tile_nnz_prefix, int64_t* n_long) {
+    auto weight = [&](uint32_t pj) -> uint64_t {
+        if (pj == kNoProj || (int32_t)pj >= n_proj) return 10;
+        const int k = projs[pj].kind;
+        return (k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) ? 26 : 10;
+    };
     tiles.clear();
     tile_nnz_prefix.clear();
     tile_nnz_prefix.push_back(0);
@@ -109,7 +122,7 @@ static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj,
         d.w0 = cur_start | ((uint64_t)cur_cnt << 40) | ((uint64_t)cur_proj << 48);
         d.w1 = mask;
         tiles.push_back(d);
-        running += cur_cnt;
+        running += 64 * weight(cur_proj);  // cost is per tile (per wavefront pass), not per non-zero
         tile_nnz_prefix.push_back(running);
         cur_cnt = 0;
         cur_mask = 0;
@@ -123,13 +136,14 @@ static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj,
         int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
         if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
-        if (len > kTileLanes) {
+        // columns of entries that do not fit the kernel's LDS projection table take the single-column path as well
+        if (len > kTileLanes || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
             flush();
             TileDesc d;
             d.w0 = (uint64_t)k0 | kTileLongFlag | ((uint64_t)pj << 48);
             d.w1 = (uint64_t)len;
             tiles.push_back(d);
-            running += (uint64_t)len;
+            running += (uint64_t)len * weight(pj) * 3;  // every Newton pass re-reads the column
             tile_nnz_prefix.push_back(running);
             *n_long += 1;
             continue;
@@ -184,6 +198,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     h->n_proj = n_proj;
     const char* nodpp = getenv("DUALIP_HIP_NO_DPP");
     h->use_dpp = !(nodpp && nodpp[0] == '1');
+    const char* abl = getenv("DUALIP_HIP_ABLATE");
+    h->ablate = abl ? atoi(abl) : 0;
     (void)hipGetDevice(&h->device);
     int rc = 0;
 #define CK(expr)                    \
@@ -228,7 +244,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // ---- tiles ----
     std::vector<TileDesc> tiles;
     std::vector<uint64_t> prefix;
-    CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, tiles, prefix, &h->n_long));
+    CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
     h->n_tiles = (int64_t)tiles.size();
     if (h->n_tiles >= (1ll << 32)) {
         matching_free(h);
@@ -257,8 +273,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     }
 
     // ---- LDS plan ----
-    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
-    auto lds_need = [&](bool lam, bool grad) { return (((lam ? (size_t)m : 0) + (grad ? (size_t)m : 0)) * vs + 15) / 16 * 16 + kLdsScratch; };
+    auto lds_need = [&](bool lam, bool grad) { return fused_lds_bytes(m, val_dtype, lam, grad); };
     const char* mode_env = getenv("DUALIP_HIP_LDS_MODE");  // "both" | "grad" | "none": force a smaller plan (testing)
     int max_mode = 2;
     if (mode_env) max_mode = !strcmp(mode_env, "none") ? 0 : (!strcmp(mode_env, "grad") ? 1 : 2);
@@ -284,8 +299,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     CK(owned_malloc(h, (void**)&h->tiles, sizeof(TileDesc) * tiles.size()));
     CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));
     CK(owned_malloc(h, (void**)&h->projs, sizeof(ProjDev) * (size_t)(n_proj > 0 ? n_proj : 1)));
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    (void)vs;
     const size_t slabs = h->grad_lds ? (size_t)(h->n_wg > 0 ? h->n_wg : 1) : 1;
-    CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * vs));
+    CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * sizeof(long long)));
+    CK(owned_malloc(h, (void**)&h->shift_dev, 2 * sizeof(unsigned long long) + sizeof(int)));
     CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
@@ -300,25 +318,71 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         matching_free(h);
         return hip_fail(e, "metadata upload");
     }
+    unsigned int* row_count_dev = nullptr;
+    std::vector<unsigned int> row_count_h((size_t)(m > 0 ? m : 1), 0u);
+    e = hipMalloc((void**)&row_count_dev, sizeof(unsigned int) * row_count_h.size());
+    if (e == hipSuccess) e = hipMemsetAsync(row_count_dev, 0, sizeof(unsigned int) * row_count_h.size(), st);
+    if (e != hipSuccess) {
+        (void)hipFree(bad_dev);
+        matching_free(h);
+        return hip_fail(e, "row histogram");
+    }
     if (nnz > 0) {
-        rc = idx_dtype == DL_I64 ? reencode_rows<int64_t>(h, rowidx, st, bad_dev) : reencode_rows<int32_t>(h, rowidx, st, bad_dev);
+        rc = idx_dtype == DL_I64 ? reencode_rows<int64_t>(h, rowidx, st, bad_dev, row_count_dev) : reencode_rows<int32_t>(h, rowidx, st, bad_dev, row_count_dev);
         if (rc) {
             (void)hipFree(bad_dev);
+            (void)hipFree(row_count_dev);
             matching_free(h);
             return rc;
         }
     }
+    e = hipMemcpyAsync(row_count_h.data(), row_count_dev, sizeof(unsigned int) * row_count_h.size(), hipMemcpyDeviceToHost, st);
+    // max |a|, max |c| (bound for the fixed-point gradient accumulation) and max |projection parameter|
+    unsigned long long* mx_dev = nullptr;
+    unsigned long long mx_host[2] = {0, 0};
+    if (e == hipSuccess) e = hipMalloc((void**)&mx_dev, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(mx_dev, 0, 2 * sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(h->shift_dev, 0, sizeof(int), st);
+    if (e == hipSuccess && launch_absmax(val_dtype, nnz, a, mx_dev, st)) e = hipErrorUnknown;
+    if (e == hipSuccess && launch_absmax(val_dtype, nnz, c, mx_dev + 1, st)) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemcpyAsync(mx_host, mx_dev, sizeof(mx_host), hipMemcpyDeviceToHost, st);
     int bad = 0;
-    e = hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // also keeps the host vectors alive until the uploads finished
     (void)hipFree(bad_dev);
+    (void)hipFree(row_count_dev);
+    if (mx_dev) (void)hipFree(mx_dev);
     if (e != hipSuccess) {
         matching_free(h);
         return hip_fail(e, "create sync");
     }
-    if (bad) {
-        matching_free(h);
-        return fail(DL_E_LAYOUT, "row index out of range [0, m)");
+    memcpy(&h->amax, &mx_host[0], sizeof(double));
+    memcpy(&h->cmax, &mx_host[1], sizeof(double));
+    for (unsigned int v : row_count_h) h->row_count_max = v > (unsigned int)h->row_count_max ? (int64_t)v : h->row_count_max;
+    // |x| bounds per projection kind: box -> max(|lower|, |upper|); simplex -> z (+ slack); cone / identity -> via |v| per launch
+    bool used_none = false;
+    std::vector<char> used((size_t)(n_proj > 0 ? n_proj : 1), 0);
+    for (const TileDesc& d : tiles) {
+        const uint32_t pid = tile_proj(d.w0);
+        if (pid == kNoProj) used_none = true;
+        else used[pid] = 1;
+    }
+    h->has_unbounded = used_none;
+    for (int32_t q = 0; q < n_proj; ++q) {
+        if (!used[(size_t)q]) continue;
+        const double p0 = projs_host[q].p0 < 0 ? -projs_host[q].p0 : projs_host[q].p0;
+        const double p1 = projs_host[q].p1 < 0 ? -projs_host[q].p1 : projs_host[q].p1;
+        switch (projs_host[q].kind) {
+            case DL_PROJ_BOX: h->xmax_bounded = std::max(h->xmax_bounded, std::max(p0, p1)); break;
+            case DL_PROJ_SIMPLEX:
+            case DL_PROJ_SIMPLEX_EQ: h->xmax_bounded = std::max(h->xmax_bounded, p0 + 1e-6); break;
+            case DL_PROJ_CONE_LOWER:
+            case DL_PROJ_CONE_UPPER:
+                h->has_unbounded = true;
+                h->pmax_unbounded = std::max(h->pmax_unbounded, p0);
+                break;
+            default: h->has_unbounded = true; break;
+        }
     }
 #undef CK
 #undef CKH

@@ -55,6 +55,7 @@ constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavef
 constexpr int kFusedWaves = kFusedThreads / 64;
 constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
 constexpr size_t kLdsScratch = 512;            // per-workgroup reduction scratch (bytes)
+constexpr int kProjLdsSlots = 256;            // projection table slots in LDS (simplex.h kProjLds)
 constexpr int kLogCols = 8;                    // doubles per iteration in the AGD log
 
 // ---------------------------------------------------------------------------------------------------------
@@ -79,10 +80,17 @@ struct dl_matching {
     bool lam_lds = false, grad_lds = false;
     size_t lds_bytes = 0;
     int64_t mpad = 0;          // row stride of the partial slabs (elements)
-    void* partial = nullptr;   // owned: [n_wg][mpad] val (grad_lds) or [1][mpad] (global atomics)
+    void* partial = nullptr;   // owned: int64 fixed point, [n_wg][mpad] (grad_lds) or [1][mpad] (global atomics)
+    int* shift_dev = nullptr;  // owned: fixed-point exponent of the latest launch
+    double amax = 0.0, cmax = 0.0;      // max |a|, max |c| (read once at creation: A and c must not change afterwards)
+    double xmax_bounded = 0.0;          // largest |x| a bounded projection in use can return
+    double pmax_unbounded = 0.0;        // largest |bound| of the one-sided projections in use
+    bool has_unbounded = false;         // cone / identity columns exist: |x| is bounded through |v| per launch
+    int64_t row_count_max = 0;          // most non-zeros in one row
     double* partial_scal = nullptr;  // owned: [n_wg][2]
     size_t owned_bytes = 0;
     bool use_dpp = true;
+    int ablate = 0;  // developer-only timing ablations, see FusedArgs
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
     bool prof_on = false;
     size_t prof_used = 0;

