@@ -2,6 +2,7 @@
 // row-index re-encoding, wave-tile packing and workgroup partitioning.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -160,6 +161,81 @@ static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj,
     return 0;
 }
 
+
+// Layout 4: 16-byte-aligned 256-element windows of whole columns; 12 dwords per tile (see matching_kernels4.hip).
+static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs,
+                       std::vector<uint32_t>& words, std::vector<uint64_t>& cost_prefix, std::vector<uint32_t>& tile_pid, int64_t* n_long) {
+    auto weight = [&](uint32_t pj) -> uint64_t {
+        if (pj == kNoProj || (int32_t)pj >= n_proj) return 10;
+        const int k = projs[pj].kind;
+        return (k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) ? 26 : 10;
+    };
+    words.clear();
+    cost_prefix.clear();
+    cost_prefix.push_back(0);
+    tile_pid.clear();
+    *n_long = 0;
+    const uint64_t nnz_al4 = (uint64_t)nnz & ~3ull;
+    uint64_t running = 0;
+    bool open = false;
+    uint64_t W = 0, H[4] = {0, 0, 0, 0};
+    uint32_t lo = 0, end = 0, cur_proj = kNoProj;
+    auto set_head = [&](uint32_t e) { H[e & 3] |= 1ull << (e >> 2); };
+    auto emit = [&](uint64_t w0, const uint64_t* h4, uint32_t pid) {
+        words.push_back((uint32_t)w0);
+        words.push_back((uint32_t)(w0 >> 32));
+        for (int j = 0; j < 4; ++j) {
+            words.push_back((uint32_t)h4[j]);
+            words.push_back((uint32_t)(h4[j] >> 32));
+        }
+        words.push_back(pid == kNoProj ? 0xFFFFFFFFu : pid);
+        words.push_back(0u);
+        tile_pid.push_back(pid);
+    };
+    auto flush = [&]() {
+        if (!open) return;
+        if (end < 256) set_head(end);  // sentinel: elements past the last column form their own dummy segment
+        const uint64_t w0 = W | ((uint64_t)end << 40) | ((uint64_t)lo << 49);
+        emit(w0, H, cur_proj);
+        running += 256 * weight(cur_proj);
+        cost_prefix.push_back(running);
+        open = false;
+        H[0] = H[1] = H[2] = H[3] = 0;
+    };
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t k0 = colptr[j], k1 = colptr[j + 1];
+        const int64_t len = k1 - k0;
+        if (len < 0) return fail(DL_E_LAYOUT, "ccol_indices is not monotone at column %lld", (long long)j);
+        if (len == 0) continue;
+        if ((uint64_t)k1 >= (1ull << 40)) return fail(DL_E_ARG, "nnz exceeds 2^40");
+        int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
+        if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
+        const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
+        const bool tail_quad = (uint64_t)k1 > nnz_al4;  // touches the array's last partial quad: no vector loads there
+        if (len > 253 || tail_quad || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
+            flush();
+            const uint64_t h4[4] = {(uint64_t)len, 0, 0, 0};
+            emit((uint64_t)k0 | (1ull << 51), h4, pj);
+            running += (uint64_t)len * weight(pj) * 3;
+            cost_prefix.push_back(running);
+            *n_long += 1;
+            continue;
+        }
+        if (open && ((uint64_t)k1 > W + 256 || pj != cur_proj)) flush();
+        if (!open) {
+            open = true;
+            W = (uint64_t)k0 & ~3ull;
+            lo = (uint32_t)((uint64_t)k0 - W);
+            cur_proj = pj;
+            set_head(0);
+        }
+        set_head((uint32_t)((uint64_t)k0 - W));
+        end = (uint32_t)((uint64_t)k1 - W);
+    }
+    flush();
+    return 0;
+}
+
 }  // namespace dl
 
 using namespace dl;
@@ -243,9 +319,20 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
 
     // ---- tiles ----
     std::vector<TileDesc> tiles;
+    std::vector<uint32_t> words4, tile_pid4;
     std::vector<uint64_t> prefix;
-    CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
-    h->n_tiles = (int64_t)tiles.size();
+    // layout 4 (16-byte loads) needs 16-byte aligned value arrays and at least one full quad; DUALIP_HIP_LAYOUT=1 forces layout 1
+    const char* lay_env = getenv("DUALIP_HIP_LAYOUT");
+    const bool want4 = !(lay_env && lay_env[0] == '1');
+    const bool aligned = (((uintptr_t)a | (uintptr_t)c) & 15u) == 0;
+    h->layout = (want4 && aligned && nnz >= 1024) ? 4 : 1;
+    if (h->layout == 4) {
+        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long));
+        h->n_tiles = (int64_t)(words4.size() / 12);
+    } else {
+        CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
+        h->n_tiles = (int64_t)tiles.size();
+    }
     if (h->n_tiles >= (1ll << 32)) {
         matching_free(h);
         return fail(DL_E_ARG, "too many tiles");
@@ -264,12 +351,13 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     {
         const uint64_t total = prefix.back();
         size_t t = 0;
+        const size_t n_t = (size_t)h->n_tiles;
         for (int w = 0; w <= h->n_wg; ++w) {
             const uint64_t target = h->n_wg ? (total * (uint64_t)w) / (uint64_t)h->n_wg : 0;
-            while (t < tiles.size() && prefix[t] < target) ++t;
+            while (t < n_t && prefix[t] < target) ++t;
             wg_begin[(size_t)w] = (uint32_t)t;
         }
-        if (h->n_wg) wg_begin[(size_t)h->n_wg] = (uint32_t)tiles.size();
+        if (h->n_wg) wg_begin[(size_t)h->n_wg] = (uint32_t)n_t;
     }
 
     // ---- LDS plan ----
@@ -296,7 +384,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const char* row_env = getenv("DUALIP_HIP_ROW32");
     if (row_env && row_env[0] == '1') h->row_bytes = 4;
     CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
-    CK(owned_malloc(h, (void**)&h->tiles, sizeof(TileDesc) * tiles.size()));
+    const size_t tile_bytes = h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size();
+    CK(owned_malloc(h, (void**)&h->tiles, tile_bytes));
     CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));
     CK(owned_malloc(h, (void**)&h->projs, sizeof(ProjDev) * (size_t)(n_proj > 0 ? n_proj : 1)));
     const size_t vs = val_dtype == DL_F32 ? 4 : 8;
@@ -308,7 +397,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
-    if (e == hipSuccess && !tiles.empty()) e = hipMemcpyAsync(h->tiles, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && tile_bytes > 0)
+        e = hipMemcpyAsync(h->tiles, h->layout == 4 ? (const void*)words4.data() : (const void*)tiles.data(), tile_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h->wg_tile_begin, wg_begin.data(), sizeof(uint32_t) * wg_begin.size(), hipMemcpyHostToDevice, st);
     std::vector<ProjDev> pd((size_t)(n_proj > 0 ? n_proj : 1));
     for (int32_t q = 0; q < n_proj; ++q) pd[(size_t)q] = ProjDev{projs_host[q].kind, 0, projs_host[q].p0, projs_host[q].p1};
@@ -367,6 +457,10 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (pid == kNoProj) used_none = true;
         else used[pid] = 1;
     }
+    for (uint32_t pid : tile_pid4) {
+        if (pid == kNoProj) used_none = true;
+        else used[pid] = 1;
+    }
     h->has_unbounded = used_none;
     for (int32_t q = 0; q < n_proj; ++q) {
         if (!used[(size_t)q]) continue;
@@ -406,6 +500,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 5: return (int64_t)h->owned_bytes;
         case 6: return h->n_long;
         case 7: return h->row_bytes;
+        case 8: return h->layout;
         default: return -1;
     }
 }

@@ -71,7 +71,8 @@ struct dl_matching {
     const void* c = nullptr;  // caller-owned
     void* rowidx = nullptr;   // owned, uint16 or uint32
     int row_bytes = 4;
-    dl::TileDesc* tiles = nullptr;      // owned
+    dl::TileDesc* tiles = nullptr;      // owned (layout 1: TileDesc[]; layout 4: 12 dwords per tile)
+    int layout = 1;                     // 1 = one non-zero per lane (64-wide tiles), 4 = four per lane (256-wide tiles)
     uint32_t* wg_tile_begin = nullptr;  // owned, [n_wg + 1]
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;

@@ -1,0 +1,241 @@
+// fused_common.h -- pieces shared by the two tile layouts of the fused pass (matching_kernels.hip: one non-zero per
+// lane, 64-wide tiles; matching_kernels4.hip: four per lane, 256-wide tiles): kernel arguments, the exact fixed-point
+// scatter, SGPR-base addressing and the single-column ("long tile") walker.
+#pragma once
+#include "common.h"
+#include "simplex.h"
+#include "wave.h"
+
+namespace dl {
+
+template <class T>
+struct FusedArgs {
+    const uint32_t* __restrict__ tiles32;  // TileDesc as 4 dwords each
+    const uint32_t* __restrict__ wg_tile_begin;
+    const void* __restrict__ rowidx;
+    const T* __restrict__ a;
+    const T* __restrict__ c;
+    const T* __restrict__ lambda;
+    T* __restrict__ x_out;
+    const ProjDev* __restrict__ projs;
+    long long* __restrict__ partial;     // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
+    double* __restrict__ partial_scal;   // [n_wg][2]
+    int* __restrict__ shift_out;         // fixed-point exponent chosen for this launch
+    double gamma;
+    double amax, cmax;                   // max |a|, max |c|
+    double xmax_bounded;                 // max |x| any bounded projection present can return (box bounds, simplex z)
+    double pmax_unbounded;               // max |bound| of one-sided projections present
+    double row_count_max;                // largest number of non-zeros in one row (of this shard)
+    int has_unbounded;                   // some column's projection does not bound |x| (cone / none): use the |v| bound
+    int64_t m;
+    int64_t mpad;
+    int64_t nnz;
+    int32_t n_proj;
+    int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
+};
+
+// a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
+// float : 1.5 * 2^52 trick -- for |ax * 2^shift| < 2^51 the integer sits in the mantissa of the fma result (3 VALU);
+// double: full 62-bit conversion (the 2^-50 grid of the trick would be coarser than the values themselves).
+template <class T>
+struct FixedBits {
+    static constexpr int value = 50;
+};
+template <>
+struct FixedBits<double> {
+    static constexpr int value = 61;
+};
+__device__ __forceinline__ long long to_fixed(float ax, double scale) {
+    const double magic = 6755399441055744.0;
+    const double d = fma((double)ax, scale, magic);
+    return __double_as_longlong(d) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ long long to_fixed(double ax, double scale) { return __double2ll_rn(ax * scale); }
+
+template <class T>
+__device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax, double scale) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
+}
+
+template <class P>
+__device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
+    return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
+}
+
+// Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
+template <class T, class RowT, bool LAM_LDS>
+__device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
+                                              double scale, int lane, double& obj, double& ssq) {
+    const bool is_simplex = is_simplex_kind(pj.kind);
+    auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
+        av = g.a[k];
+        cv = g.c[k];
+        rv = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
+        const T lam = LAM_LDS ? lam_s[rv] : (T)(s * g.lambda[rv]);
+        T v = (T)(av * lam);
+        return (T)(v + (T)(s * cv));
+    };
+    T th = (T)0;
+    bool projected = false, onehot = false;
+    if (is_simplex) {
+        T S = (T)0, v1 = (T)(-INFINITY);
+        for (uint64_t o = lane; o < len; o += 64) {
+            T av, cv;
+            uint32_t rv;
+            const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
+            S = (T)(S + u);
+            v1 = tmax(v1, u);
+        }
+        S = wave_allreduce(S, OpAdd());
+        v1 = wave_allreduce(v1, OpMax());
+        projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
+        if (projected) {
+            const T z = pj.z;
+            th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
+            long long cnt_prev = 0;
+            for (int it = 0; it < 4096; ++it) {
+                T sumA = (T)0;
+                long long cntl = 0;
+                for (uint64_t o = lane; o < len; o += 64) {
+                    T av, cv;
+                    uint32_t rv;
+                    const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
+                    if (u > th) {
+                        sumA = (T)(sumA + u);
+                        cntl += 1;
+                    }
+                }
+                sumA = wave_allreduce(sumA, OpAdd());
+                const long long cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                if (it == 0 && cntw == 1) {
+                    onehot = true;
+                    break;
+                }
+                if (cntw == cnt_prev || cntw == 0) break;
+                th = (T)((T)(sumA - z) / (T)cntw);
+                cnt_prev = cntw;
+            }
+        }
+    }
+    for (uint64_t o = lane; o < len; o += 64) {
+        T av, cv;
+        uint32_t rv;
+        const T v = value_at(k0 + o, av, cv, rv);
+        T x;
+        if (is_simplex) {
+            const T u = tmax(v, (T)0);
+            if (!projected) x = u;
+            else if (onehot) x = (u > th) ? pj.z : (T)0;
+            else x = tmax((T)(u - th), (T)0);
+        } else {
+            x = project_pointwise(v, pj);
+        }
+        const T ax = (T)(av * x);
+        if (ax != (T)0) scatter_fixed(gacc, rv, ax, scale);
+        obj += (double)(T)(cv * x);
+        ssq += (double)(T)(x * x);
+        if (g.x_out) g.x_out[k0 + o] = x;
+    }
+}
+
+
+// ---- workgroup context shared by both tile layouts ----
+template <class T>
+struct WgCtx {
+    long long* grad_s;
+    T* lam_s;
+    ProjT<T>* proj_s;
+    double* red_s;
+    long long* gacc;
+    T s;           // -1/gamma rounded once to the working precision (matching.py:136)
+    double scale;  // 2^shift of the fixed-point gradient
+};
+
+// Prologue: carve LDS, stage -lambda/gamma, zero the private gradient, cache the projection table, choose the
+// fixed-point exponent from max|lambda| (identical in every workgroup).
+template <class T, bool LAM_LDS, bool GRAD_LDS>
+__device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsigned char* smem, int tid, int lane, int wave, int wg) {
+    WgCtx<T> w;
+    // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
+    w.grad_s = reinterpret_cast<long long*>(smem);
+    size_t off = GRAD_LDS ? (size_t)g.m * 8 : 0;
+    w.lam_s = reinterpret_cast<T*>(smem + off);
+    off += LAM_LDS ? (size_t)g.m * sizeof(T) : 0;
+    off = (off + 15) / 16 * 16;
+    w.proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
+    off += (size_t)kProjLds * sizeof(ProjT<T>);
+    w.red_s = reinterpret_cast<double*>(smem + off);
+    w.s = (T)(-1.0 / g.gamma);
+    double lmax = 0.0;
+    for (int64_t i = tid; i < g.m; i += kFusedThreads) {
+        const T l = g.lambda[i];
+        if constexpr (LAM_LDS) w.lam_s[i] = (T)(w.s * l);
+        const double al = fabs((double)l);
+        lmax = al > lmax ? al : lmax;
+    }
+    if constexpr (GRAD_LDS) {
+        for (int64_t i = tid; i < g.m; i += kFusedThreads) w.grad_s[i] = 0;
+    }
+    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
+        w.proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
+    }
+    lmax = wave_allreduce(lmax, OpMax());
+    if (lane == 0) w.red_s[wave] = lmax;
+    __syncthreads();
+    lmax = w.red_s[0];
+    for (int q = 1; q < kFusedWaves; ++q) lmax = w.red_s[q] > lmax ? w.red_s[q] : lmax;
+    __syncthreads();  // red_s is reused by the epilogue
+    // every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
+    int shift;
+    {
+        double xmax = g.xmax_bounded;
+        if (g.has_unbounded) {
+            const double vmax = fabs(-1.0 / g.gamma) * (g.amax * lmax + g.cmax);
+            const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
+            xmax = ub > xmax ? ub : xmax;
+        }
+        const double bound = g.amax * xmax * g.row_count_max;
+        int e = 0;
+        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+        shift = FixedBits<T>::value - e;
+        shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+    }
+    w.scale = ldexp(1.0, shift);
+    if (wg == 0 && tid == 0) *g.shift_out = shift;
+    w.gacc = GRAD_LDS ? w.grad_s : g.partial;
+    return w;
+}
+
+// Epilogue: scalar partials of the workgroup, then its private gradient slab.
+template <class T, bool GRAD_LDS>
+__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, double obj, double ssq, int tid, int lane, int wave, int wg) {
+    obj = wave_allreduce(obj, OpAdd());
+    ssq = wave_allreduce(ssq, OpAdd());
+    if (lane == 0) {
+        w.red_s[2 * wave] = obj;
+        w.red_s[2 * wave + 1] = ssq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, q = 0.0;
+        for (int k = 0; k < kFusedWaves; ++k) {
+            o += w.red_s[2 * k];
+            q += w.red_s[2 * k + 1];
+        }
+        g.partial_scal[2 * (int64_t)wg] = o;
+        g.partial_scal[2 * (int64_t)wg + 1] = q;
+    }
+    if constexpr (GRAD_LDS) {
+        long long* slab = g.partial + (int64_t)wg * g.mpad;
+        for (int64_t i = tid; i < g.m; i += kFusedThreads) slab[i] = w.grad_s[i];
+    }
+}
+
+template <class T>
+__device__ __forceinline__ ProjT<T> lookup_proj(const FusedArgs<T>& g, const ProjT<T>* proj_s, uint32_t pid) {
+    ProjT<T> p = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+    if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj && pid != 0xFFFFFFFFu) p = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
+    return p;
+}
+
+}  // namespace dl

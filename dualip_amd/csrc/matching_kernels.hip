@@ -24,140 +24,9 @@
 //     per Newton pass);
 //   * every workgroup writes its private integer gradient to its own slab; a second small kernel sums the slabs
 //     (exactly) and converts to double.
-#include "common.h"
-#include "simplex.h"
-#include "wave.h"
+#include "fused_common.h"
 
 namespace dl {
-
-template <class T>
-struct FusedArgs {
-    const uint32_t* __restrict__ tiles32;  // TileDesc as 4 dwords each
-    const uint32_t* __restrict__ wg_tile_begin;
-    const void* __restrict__ rowidx;
-    const T* __restrict__ a;
-    const T* __restrict__ c;
-    const T* __restrict__ lambda;
-    T* __restrict__ x_out;
-    const ProjDev* __restrict__ projs;
-    long long* __restrict__ partial;     // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
-    double* __restrict__ partial_scal;   // [n_wg][2]
-    int* __restrict__ shift_out;         // fixed-point exponent chosen for this launch
-    double gamma;
-    double amax, cmax;                   // max |a|, max |c|
-    double xmax_bounded;                 // max |x| any bounded projection present can return (box bounds, simplex z)
-    double pmax_unbounded;               // max |bound| of one-sided projections present
-    double row_count_max;                // largest number of non-zeros in one row (of this shard)
-    int has_unbounded;                   // some column's projection does not bound |x| (cone / none): use the |v| bound
-    int64_t m;
-    int64_t mpad;
-    int32_t n_proj;
-    int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
-};
-
-// a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
-// float : 1.5 * 2^52 trick -- for |ax * 2^shift| < 2^51 the integer sits in the mantissa of the fma result (3 VALU);
-// double: full 62-bit conversion (the 2^-50 grid of the trick would be coarser than the values themselves).
-template <class T>
-struct FixedBits {
-    static constexpr int value = 50;
-};
-template <>
-struct FixedBits<double> {
-    static constexpr int value = 61;
-};
-__device__ __forceinline__ long long to_fixed(float ax, double scale) {
-    const double magic = 6755399441055744.0;
-    const double d = fma((double)ax, scale, magic);
-    return __double_as_longlong(d) - __double_as_longlong(magic);
-}
-__device__ __forceinline__ long long to_fixed(double ax, double scale) { return __double2ll_rn(ax * scale); }
-
-template <class T>
-__device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax, double scale) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
-}
-
-template <class P>
-__device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
-    return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
-}
-
-// Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
-template <class T, class RowT, bool LAM_LDS>
-__device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
-                                              double scale, int lane, double& obj, double& ssq) {
-    const bool is_simplex = is_simplex_kind(pj.kind);
-    auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
-        av = g.a[k];
-        cv = g.c[k];
-        rv = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
-        const T lam = LAM_LDS ? lam_s[rv] : (T)(s * g.lambda[rv]);
-        T v = (T)(av * lam);
-        return (T)(v + (T)(s * cv));
-    };
-    T th = (T)0;
-    bool projected = false, onehot = false;
-    if (is_simplex) {
-        T S = (T)0, v1 = (T)(-INFINITY);
-        for (uint64_t o = lane; o < len; o += 64) {
-            T av, cv;
-            uint32_t rv;
-            const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
-            S = (T)(S + u);
-            v1 = tmax(v1, u);
-        }
-        S = wave_allreduce(S, OpAdd());
-        v1 = wave_allreduce(v1, OpMax());
-        projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
-        if (projected) {
-            const T z = pj.z;
-            th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
-            long long cnt_prev = 0;
-            for (int it = 0; it < 4096; ++it) {
-                T sumA = (T)0;
-                long long cntl = 0;
-                for (uint64_t o = lane; o < len; o += 64) {
-                    T av, cv;
-                    uint32_t rv;
-                    const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
-                    if (u > th) {
-                        sumA = (T)(sumA + u);
-                        cntl += 1;
-                    }
-                }
-                sumA = wave_allreduce(sumA, OpAdd());
-                const long long cntw = (long long)wave_allreduce((double)cntl, OpAdd());
-                if (it == 0 && cntw == 1) {
-                    onehot = true;
-                    break;
-                }
-                if (cntw == cnt_prev || cntw == 0) break;
-                th = (T)((T)(sumA - z) / (T)cntw);
-                cnt_prev = cntw;
-            }
-        }
-    }
-    for (uint64_t o = lane; o < len; o += 64) {
-        T av, cv;
-        uint32_t rv;
-        const T v = value_at(k0 + o, av, cv, rv);
-        T x;
-        if (is_simplex) {
-            const T u = tmax(v, (T)0);
-            if (!projected) x = u;
-            else if (onehot) x = (u > th) ? pj.z : (T)0;
-            else x = tmax((T)(u - th), (T)0);
-        } else {
-            x = project_pointwise(v, pj);
-        }
-        const T ax = (T)(av * x);
-        if (ax != (T)0) scatter_fixed(gacc, rv, ax, scale);
-        obj += (double)(T)(cv * x);
-        ssq += (double)(T)(x * x);
-        if (g.x_out) g.x_out[k0 + o] = x;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // fused kernel
@@ -493,6 +362,11 @@ static int launch_fused_rt(const dl_matching* h, const FusedArgs<T>& args, hipSt
     return D ? launch_fused_inst<T, RowT, false, false, true>(h, args, st) : launch_fused_inst<T, RowT, false, false, false>(h, args, st);
 }
 
+int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4.hip
+int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
+static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) { return launch_fused4_f32(h, args, st); }
+static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) { return launch_fused4_f64(h, args, st); }
+
 template <class T>
 static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
     if (h->n_tiles == 0 || h->n_wg == 0) {  // no non-zeros at all: A x = 0
@@ -520,6 +394,7 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     args.has_unbounded = h->has_unbounded ? 1 : 0;
     args.m = h->m;
     args.mpad = h->mpad;
+    args.nnz = h->nnz;
     args.n_proj = h->n_proj;
     args.ablate = h->ablate;
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
@@ -538,7 +413,9 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
             h->prof_used += 1;
         }
     }
-    int rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
+    int rc;
+    if (h->layout == 4) rc = launch_fused4(h, args, st);
+    else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     const int n_slabs = h->grad_lds ? h->n_wg : 1;

@@ -1,0 +1,213 @@
+// simplex4.h -- segment machinery of the 256-wide tile: FOUR consecutive non-zeros per lane.
+//
+// Element e of a tile lives in lane e / 4, slot e % 4 (what a 16-byte load per lane delivers).  Column boundaries are
+// four wave-uniform 64-bit masks H[j] (bit L <=> element 4L+j starts a column); every per-lane predicate the segmented
+// reductions need is derived from them on the SCALAR unit (64-bit mask arithmetic) and consumed as a v_cndmask condition
+// through __builtin_amdgcn_inverse_ballot_w64 -- no per-lane integer work at all.
+//
+// Segmented all-reduce (every element receives the reduction over its own column):
+//   1. in-lane forward pass over the 4 slots                                   (3 ops + 3 selects)
+//   2. cross-lane segmented scan of the lane's open tail (DPP, as in wave.h)   (6 DPP ops + 6 selects)
+//   3. carry from the previous lane (DPP wave_shr:1), applied to the slots before the lane's first head
+//   4. in-lane backward pass; columns that end in a later lane fetch their total with ONE ds_bpermute
+// = ~38 VALU + 1 LDS op per 256 elements (the one-element-per-lane tile spends 4 x 16).
+#pragma once
+#include "common.h"
+#include "simplex.h"
+#include "wave.h"
+
+namespace dl {
+
+constexpr int kSlots = 4;
+constexpr int kTile4 = 64 * kSlots;
+
+__device__ __forceinline__ bool lane_bit(uint64_t uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
+
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// lanes whose position inside their 16-lane DPP row is >= o
+constexpr uint64_t rows_ge(int o) {
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l)
+        if ((l & 15) >= o) m |= 1ull << l;
+    return m;
+}
+constexpr uint64_t kR1 = rows_ge(1), kR2 = rows_ge(2), kR4 = rows_ge(4), kR8 = rows_ge(8);
+constexpr uint64_t kRows13 = 0xFFFF0000FFFF0000ull;  // lanes 16-31 and 48-63
+constexpr uint64_t kUpper = 0xFFFFFFFF00000000ull;   // lanes 32-63
+
+// Wave-uniform masks of one tile.
+struct Seg4 {
+    uint64_t H[kSlots];  // element 4L+j starts a column
+    uint64_t N[kSlots];  // no head in slots 0..j of the lane: the previous lane's carry applies to slot j
+    uint64_t O[kSlots];  // the column of slot j runs past the end of the lane: its total comes from a later lane
+    uint64_t P1, P2, P4, P8, PA, PB;  // predicates of the cross-lane scan over lanes (segments start at lanes with a head)
+    uint64_t G;          // lanes in which a column that entered from the previous lane ends
+};
+
+__device__ __forceinline__ Seg4 make_seg4(const uint64_t (&H)[kSlots]) {
+    Seg4 s;
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) s.H[j] = H[j];
+    s.N[0] = ~H[0];
+    s.N[1] = s.N[0] & ~H[1];
+    s.N[2] = s.N[1] & ~H[2];
+    s.N[3] = s.N[2] & ~H[3];
+    const uint64_t open = ~(H[0] >> 1) & ~(1ull << 63);  // lane L+1 exists and does not start with a head
+    s.O[3] = open;
+    s.O[2] = s.O[3] & ~H[3];
+    s.O[1] = s.O[2] & ~H[2];
+    s.O[0] = s.O[1] & ~H[1];
+    const uint64_t F = H[0] | H[1] | H[2] | H[3] | 1ull;  // lanes containing a head
+    // "a head among lanes l-o+1 .. l"
+    const uint64_t S2 = F | (F << 1);
+    const uint64_t S4 = S2 | (S2 << 2);
+    const uint64_t S8 = S4 | (S4 << 4);
+    s.P1 = ~F & kR1;
+    s.P2 = ~S2 & kR2;
+    s.P4 = ~S4 & kR4;
+    s.P8 = ~S8 & kR8;
+    // "a head among the lanes of my 16-row up to me" / "... of my 32-half up to me"
+    uint64_t T = F;
+    T |= (T << 1) & kR1;
+    T |= (T << 2) & kR2;
+    T |= (T << 4) & kR4;
+    T |= (T << 8) & kR8;
+    s.PA = ~T & kRows13;
+    // rows 1 and 3 additionally see every head of the row before them: smear bit 15 / 47 of T over the next 16 lanes
+    uint64_t Y = (T & 0x0000800000008000ull) << 1;
+    Y |= Y << 1;
+    Y |= Y << 2;
+    Y |= Y << 4;
+    Y |= Y << 8;
+    const uint64_t U = T | Y;
+    s.PB = ~U & kUpper;
+    s.G = (H[1] | H[2] | H[3]) | (H[0] >> 1) | (1ull << 63);
+    return s;
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov_i(float ident, float x) { return dpp_mov<CTRL, ROWMASK>(ident, x); }
+
+// cross-lane segmented inclusive scan with wave-uniform predicate masks
+template <class T, class Op>
+__device__ __forceinline__ T lane_scan4(T x, const Seg4& s, T ident, Op op) {
+    T t;
+    t = dpp_mov<DPP_ROW_SHR1, 0xf>(ident, x);
+    x = lane_bit(s.P1) ? op(x, t) : x;
+    t = dpp_mov<DPP_ROW_SHR2, 0xf>(ident, x);
+    x = lane_bit(s.P2) ? op(x, t) : x;
+    t = dpp_mov<DPP_ROW_SHR4, 0xf>(ident, x);
+    x = lane_bit(s.P4) ? op(x, t) : x;
+    t = dpp_mov<DPP_ROW_SHR8, 0xf>(ident, x);
+    x = lane_bit(s.P8) ? op(x, t) : x;
+    t = dpp_mov<DPP_ROW_BCAST15, 0xa>(ident, x);
+    x = lane_bit(s.PA) ? op(x, t) : x;
+    t = dpp_mov<DPP_ROW_BCAST31, 0xc>(ident, x);
+    x = lane_bit(s.PB) ? op(x, t) : x;
+    return x;
+}
+
+// Every element receives the reduction over its column.  end_lane: lane holding the end of the column that is open
+// at this lane's end (from end_lane4()).
+template <class T, class Op>
+__device__ __forceinline__ void seg_allreduce4(const T (&u)[kSlots], const Seg4& s, int end_lane, T ident, Op op, T (&tot)[kSlots]) {
+    T f[kSlots];
+    f[0] = u[0];
+#pragma unroll
+    for (int j = 1; j < kSlots; ++j) f[j] = lane_bit(s.H[j]) ? u[j] : op(f[j - 1], u[j]);
+    const T c = lane_scan4(f[kSlots - 1], s, ident, op);
+    const T carry = dpp_mov<DPP_WAVE_SHR1, 0xf>(ident, c);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) f[j] = lane_bit(s.N[j]) ? op(carry, f[j]) : f[j];
+    // backward: value at the last element of the slot's column inside this lane
+    T b[kSlots];
+    b[kSlots - 1] = f[kSlots - 1];
+#pragma unroll
+    for (int j = kSlots - 2; j >= 0; --j) b[j] = lane_bit(s.H[j + 1]) ? f[j] : b[j + 1];
+    const T r = bperm(end_lane, b[0]);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) tot[j] = lane_bit(s.O[j]) ? r : b[j];
+}
+
+// first lane above `lane` in which an entering column ends (bit 63 of G is always set)
+__device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
+    const uint32_t glo = (uint32_t)s.G & c.gt_lo, ghi = (uint32_t)(s.G >> 32) & c.gt_hi;
+    const int lo = __ffs((int)glo) - 1;
+    const int hi = 32 + __ffs((int)ghi) - 1;
+    const int e = glo ? lo : hi;
+    return ghi | glo ? e : 63;
+}
+
+// Simplex projection of every column of a 256-element tile (see simplex.h for the algorithm and the reference lines).
+//   live[j]: the element exists and belongs to a simplex column;  x is only written where live.
+// Decisions without a support COUNT where possible: feasible <=> sum over {u > max - z} <= z + 1e-6; vertex <=> that sum
+// equals the maximum exactly (the maximum is the only member); only the remaining columns pay for counting.
+template <class T>
+__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const bool (&live)[kSlots], const Seg4& s, const ProjT<T>& pj,
+                                              const LaneConst& lc, T (&x)[kSlots]) {
+    const int el = end_lane4(s, lc);
+    T u[kSlots], v1[kSlots], th[kSlots], sumA[kSlots], inu[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) u[j] = live[j] ? tmax(v[j], (T)0) : (T)0;
+    seg_allreduce4(u, s, el, (T)(-INFINITY), OpMax(), v1);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        th[j] = (T)(v1[j] - pj.z);
+        inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
+    }
+    seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
+    bool act[kSlots], proj[kSlots], onehot[kSlots];
+    bool any_act = false;
+    const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const bool feas = ineq && !(sumA[j] > pj.ztol);           // simplex.py:153-158
+        onehot[j] = live[j] && !feas && sumA[j] == v1[j];          // the maximum alone exceeds max - z (simplex.py:177-193)
+        act[j] = live[j] && !feas && !onehot[j];
+        proj[j] = act[j];
+        any_act = any_act || act[j];
+    }
+    if (__any(any_act)) {
+        T cnt_prev[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) cnt_prev[j] = (T)0;
+        for (int it = 0; it < kTile4 + 2; ++it) {
+            T ind[kSlots], cnt[kSlots];
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) ind[j] = (u[j] > th[j] && live[j]) ? (T)1 : (T)0;
+            seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt);
+            any_act = false;
+            bool need_sum = false;
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                const bool conv = cnt[j] == cnt_prev[j] || cnt[j] == (T)0;  // support unchanged: th is the fixed point
+                act[j] = act[j] && !conv;
+                need_sum = need_sum || (act[j] && it > 0);
+            }
+            if (__any(need_sum)) {
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
+                seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
+            }
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
+                th[j] = act[j] ? th_new : th[j];
+                cnt_prev[j] = act[j] ? cnt[j] : cnt_prev[j];
+                any_act = any_act || act[j];
+            }
+            if (!__any(any_act)) break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const T xg = tmax((T)(u[j] - th[j]), (T)0);
+        const T xv = (u[j] > th[j]) ? pj.z : (T)0;
+        T r = proj[j] ? xg : u[j];
+        r = onehot[j] ? xv : r;
+        x[j] = live[j] ? r : x[j];
+    }
+}
+
+}  // namespace dl
