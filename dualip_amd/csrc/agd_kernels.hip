@@ -80,119 +80,220 @@ __global__ __launch_bounds__(kAgdThreads) void dual_epilogue_kernel(int64_t m, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// one AGD iteration (agd.py:163-187; agd_utils.py:12-89)
+// one AGD iteration (agd.py:163-187; agd_utils.py:12-89) as three small multi-workgroup launches:
+//   stats    rows in parallel: [sum the integer gradient slabs ->] g = A x - b, per-workgroup partial reductions
+//   finalize one workgroup: sums the partials in a fixed order, runs the scalar step-size logic, logs
+//   update   rows in parallel: projected ascent step + momentum
+// (a single-workgroup kernel doing all three took 37 us at m = 10^4: it is latency bound on one CU)
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kStatRows = 64;      // rows per stats workgroup
+constexpr int kStatSlices = 16;    // slab slices per stats workgroup (1024 threads)
+constexpr int kStatCols = 6;       // dvtg, gmax, spos, g2, dg2, dy2
+
 template <class T>
-struct AgdArgs {
+struct StatsArgs {
     int64_t m;
-    const double* __restrict__ packed;  // [m+2]: A x, c.x, sum x^2
+    // source of A x: either the integer slabs of the fused pass ...
+    const long long* __restrict__ partial;
+    const double* __restrict__ partial_scal;
+    const int* __restrict__ shift_in;
+    int n_slabs, n_scal;
+    int64_t mpad;
+    // ... or an already reduced (and, when sharded, all-reduced) packed buffer
+    const double* __restrict__ packed_in;
+    double* __restrict__ packed_out;  // [m+2]: written when reducing slabs (kept for logging / callers)
     const T* __restrict__ b;
-    T* __restrict__ x;        // in: point of evaluation; out: next point
-    const T* __restrict__ y;  // y_{i-1}
-    T* __restrict__ y_new;    // in: y_{i-2} (the dual stored with the previous history entry); out: y_i
-    T* __restrict__ g_new;    // in: previous gradient; out: this gradient  (same buffer when in_place_g)
+    const T* __restrict__ x;
+    const T* __restrict__ y;
+    const T* __restrict__ y_prev;  // dual stored with the previous history entry
     const T* __restrict__ g_old;
-    const uint8_t* __restrict__ eq_mask;
-    const float* __restrict__ beta;
+    T* __restrict__ g_new;
+    const AgdDevState* st;
+    double* __restrict__ partial_stats;  // [gridDim.x][kStatCols]
+};
+
+template <class T, bool FROM_SLABS>
+__global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(StatsArgs<T> p) {
+    __shared__ long long shi[kStatRows * kStatSlices];
+    const int tid = threadIdx.x;
+    const int rl = tid & (kStatRows - 1);
+    const int ws = tid / kStatRows;
+    const int64_t row = (int64_t)blockIdx.x * kStatRows + rl;
+    double ax = 0.0;
+    if constexpr (FROM_SLABS) {
+        long long acc = 0;
+        if (row < p.m)
+            for (int w = ws; w < p.n_slabs; w += kStatSlices) acc += p.partial[(int64_t)w * p.mpad + row];
+        shi[tid] = acc;
+        __syncthreads();
+        if (ws == 0 && row < p.m) {
+            long long t = shi[rl];
+            for (int q = 1; q < kStatSlices; ++q) t += shi[q * kStatRows + rl];
+            ax = ldexp((double)t, -(*p.shift_in));
+            p.packed_out[row] = ax;
+        }
+    } else {
+        if (ws == 0 && row < p.m) ax = p.packed_in[row];
+    }
+    const bool has_prev = p.st->steps_done > 0;
+    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
+    if (ws == 0 && row < p.m) {
+        const T gj = (T)((T)ax - p.b[row]);
+        dvtg = (double)(T)(p.x[row] * gj);
+        gmax = (double)gj;
+        spos = gj > (T)0 ? (double)gj : 0.0;
+        g2 = (double)gj * (double)gj;
+        if (has_prev) {
+            const T dg = (T)(p.g_old[row] - gj);
+            const T dy = (T)(p.y_prev[row] - p.y[row]);
+            dg2 = (double)dg * (double)dg;
+            dy2 = (double)dy * (double)dy;
+        }
+        p.g_new[row] = gj;
+    }
+    // wave 0 holds all 64 rows of the block (ws == 0 <=> tid < 64)
+    if (tid < 64) {
+        dvtg = wave_allreduce(dvtg, OpAdd());
+        gmax = wave_allreduce(gmax, OpMax());
+        spos = wave_allreduce(spos, OpAdd());
+        g2 = wave_allreduce(g2, OpAdd());
+        dg2 = wave_allreduce(dg2, OpAdd());
+        dy2 = wave_allreduce(dy2, OpAdd());
+        if (tid == 0) {
+            double* o = p.partial_stats + (int64_t)blockIdx.x * kStatCols;
+            o[0] = dvtg;
+            o[1] = gmax;
+            o[2] = spos;
+            o[3] = g2;
+            o[4] = dg2;
+            o[5] = dy2;
+        }
+    }
+    if (FROM_SLABS && blockIdx.x == 0) {  // scalar partial sums of the fused pass: c.x and sum x^2
+        __syncthreads();
+        double o = 0.0, q = 0.0;
+        for (int w = tid; w < p.n_scal; w += kStatRows * kStatSlices) {
+            o += p.partial_scal[2 * w];
+            q += p.partial_scal[2 * w + 1];
+        }
+        o = wave_allreduce(o, OpAdd());
+        q = wave_allreduce(q, OpAdd());
+        __shared__ double so[kStatRows * kStatSlices / 64], sq[kStatRows * kStatSlices / 64];
+        if ((tid & 63) == 0) {
+            so[tid >> 6] = o;
+            sq[tid >> 6] = q;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double oo = 0.0, qq = 0.0;
+            for (int w = 0; w < kStatRows * kStatSlices / 64; ++w) {
+                oo += so[w];
+                qq += sq[w];
+            }
+            p.packed_out[p.m] = oo;
+            p.packed_out[p.m + 1] = qq;
+        }
+    }
+}
+
+template <class T>
+struct FinalizeArgs {
+    int64_t m;
+    const double* __restrict__ scal;           // &packed[m]: c.x, sum x^2
+    const double* __restrict__ partial_stats;  // [n_blocks][kStatCols]
+    int n_blocks;
     AgdDevState* st;
-    double* __restrict__ log_row;  // kLogCols doubles for this iteration (may be null)
+    double* __restrict__ log_row;
     double gamma;
-    int64_t iter;  // 1-based
     int decay_now;
     double decay_factor;
 };
 
 template <class T>
-__global__ __launch_bounds__(kAgdThreads) void agd_step_kernel(AgdArgs<T> p) {
-    __shared__ double sh[kAgdThreads / 64];
-    __shared__ double step_sh;
-    const bool has_prev = p.st->steps_done > 0;
-    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, dg2 = 0.0, dy2 = 0.0, g2 = 0.0;
-    for (int64_t j = threadIdx.x; j < p.m; j += kAgdThreads) {
-        const T gj = (T)((T)p.packed[j] - p.b[j]);
-        dvtg += (double)(T)(p.x[j] * gj);
-        gmax = (double)gj > gmax ? (double)gj : gmax;
-        spos += gj > (T)0 ? (double)gj : 0.0;
-        g2 += (double)gj * (double)gj;
-        if (has_prev) {
-            const T dg = (T)(p.g_old[j] - gj);
-            const T dy = (T)(p.y_new[j] - p.y[j]);  // y_new still holds the previous history dual
-            dg2 += (double)dg * (double)dg;
-            dy2 += (double)dy * (double)dy;
-        }
-        p.g_new[j] = gj;
+__global__ __launch_bounds__(64) void agd_finalize_kernel(FinalizeArgs<T> p) {
+    const int lane = threadIdx.x;
+    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
+    for (int k = lane; k < p.n_blocks; k += 64) {  // fixed order: bit-reproducible
+        const double* o = p.partial_stats + (int64_t)k * kStatCols;
+        dvtg += o[0];
+        gmax = o[1] > gmax ? o[1] : gmax;
+        spos += o[2];
+        g2 += o[3];
+        dg2 += o[4];
+        dy2 += o[5];
     }
-    dvtg = block_sum<kAgdThreads>(dvtg, sh);
-    gmax = block_max<kAgdThreads>(gmax, sh);
-    spos = block_sum<kAgdThreads>(spos, sh);
-    g2 = block_sum<kAgdThreads>(g2, sh);
-    dg2 = block_sum<kAgdThreads>(dg2, sh);
-    dy2 = block_sum<kAgdThreads>(dy2, sh);
-
-    if (threadIdx.x == 0) {
-        AgdDevState& st = *p.st;
-        const T nrm = (T)sqrt(p.packed[p.m + 1]);
-        const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));
-        const T obj0 = (T)p.packed[p.m];
-        const T dv = (T)dvtg;
-        const T obj = (T)((T)(obj0 + reg) + dv);
-        // ---- calculate_step_size (agd_utils.py:65-89) ----
-        if (has_prev) {
-            const T num = (T)sqrt(dg2), den = (T)sqrt(dy2);
-            const T L = (T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
-            if (st.n_lips == kLipsMax) {
-                st.lips[st.head] = (double)L;  // overwrite the oldest
-                st.head = (st.head + 1) % kLipsMax;
-            } else {
-                st.lips[(st.head + st.n_lips) % kLipsMax] = (double)L;
-                st.n_lips += 1;
-            }
-        }
-        double step;
-        if (st.n_lips < kLipsMax) {
-            step = st.initial_step;  // incomplete history (agd_utils.py:57-58)
+    dvtg = wave_allreduce(dvtg, OpAdd());
+    gmax = wave_allreduce(gmax, OpMax());
+    spos = wave_allreduce(spos, OpAdd());
+    g2 = wave_allreduce(g2, OpAdd());
+    dg2 = wave_allreduce(dg2, OpAdd());
+    dy2 = wave_allreduce(dy2, OpAdd());
+    if (lane != 0) return;
+    AgdDevState& st = *p.st;
+    const bool has_prev = st.steps_done > 0;
+    const T nrm = (T)sqrt(p.scal[1]);
+    const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));  // (gamma/2) * norm(x)**2, matching.py:157
+    const T obj0 = (T)p.scal[0];
+    const T dv = (T)dvtg;
+    const T obj = (T)((T)(obj0 + reg) + dv);                 // matching.py:33
+    // ---- calculate_step_size (agd_utils.py:65-89) ----
+    if (has_prev) {
+        const T num = (T)sqrt(dg2), den = (T)sqrt(dy2);
+        const T L = (T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
+        if (st.n_lips == kLipsMax) {
+            st.lips[st.head] = (double)L;  // overwrite the oldest
+            st.head = (st.head + 1) % kLipsMax;
         } else {
-            // builtins.max over the list, oldest first: a NaN is only kept when it comes first
-            double lmax = st.lips[st.head];
-            for (int q = 1; q < kLipsMax; ++q) {
-                const double v = st.lips[(st.head + q) % kLipsMax];
-                if (v > lmax) lmax = v;
-            }
-            if (isnan(lmax) || isinf(lmax)) step = st.initial_step;
-            else {
-                const double cand = lmax != 0.0 ? 1.0 / lmax : st.max_step;
-                step = cand < st.max_step ? cand : st.max_step;
-            }
-        }
-        st.last_step = step;
-        if (p.decay_now) st.max_step = step * p.decay_factor;  // agd.py:106-107
-        st.steps_done += 1;
-        step_sh = step;
-        if (p.log_row) {
-            p.log_row[0] = (double)obj;
-            p.log_row[1] = step;
-            p.log_row[2] = (double)reg;
-            p.log_row[3] = (double)dv;
-            p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;
-            p.log_row[5] = (double)(T)spos;
-            p.log_row[6] = (double)(T)sqrt(g2);
-            p.log_row[7] = (double)obj0;
+            st.lips[(st.head + st.n_lips) % kLipsMax] = (double)L;
+            st.n_lips += 1;
         }
     }
-    __syncthreads();
-    const T stp = (T)step_sh;
-    const float bt = p.beta[p.iter - 1];
-    const T beta = (T)bt;
+    double step;
+    if (st.n_lips < kLipsMax) {
+        step = st.initial_step;  // incomplete history (agd_utils.py:57-58)
+    } else {
+        // builtins.max over the list, oldest first: a NaN is only kept when it comes first
+        double lmax = st.lips[st.head];
+        for (int q = 1; q < kLipsMax; ++q) {
+            const double v = st.lips[(st.head + q) % kLipsMax];
+            if (v > lmax) lmax = v;
+        }
+        if (isnan(lmax) || isinf(lmax)) step = st.initial_step;
+        else {
+            const double cand = lmax != 0.0 ? 1.0 / lmax : st.max_step;
+            step = cand < st.max_step ? cand : st.max_step;
+        }
+    }
+    st.last_step = step;
+    if (p.decay_now) st.max_step = step * p.decay_factor;  // agd.py:106-107
+    st.steps_done += 1;
+    if (p.log_row) {
+        p.log_row[0] = (double)obj;
+        p.log_row[1] = step;
+        p.log_row[2] = (double)reg;
+        p.log_row[3] = (double)dv;
+        p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;  // builtins.max(max(grad), 0), matching.py:168
+        p.log_row[5] = (double)(T)spos;
+        p.log_row[6] = (double)(T)sqrt(g2);
+        p.log_row[7] = (double)obj0;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void agd_update_kernel(int64_t m, T* __restrict__ x, const T* __restrict__ y, T* __restrict__ y_new, const T* __restrict__ g,
+                                                         const uint8_t* __restrict__ eq_mask, const float* __restrict__ beta, const AgdDevState* st,
+                                                         int64_t iter) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const T stp = (T)st->last_step;
+    const float bt = beta[iter - 1];
+    const T b = (T)bt;
     const T omb = (T)(float)(1.0f - bt);  // 1.0 - fp32 0-dim tensor stays fp32 (agd.py:184)
-    for (int64_t j = threadIdx.x; j < p.m; j += kAgdThreads) {
-        const T gj = p.g_new[j];
-        T yn = (T)(p.x[j] + (T)(gj * stp));                         // agd.py:181
-        const bool eq = p.eq_mask && p.eq_mask[j];
-        if (!eq) yn = yn > (T)0 ? yn : (T)0;                        // project_on_nn_cone, agd.py:13-21
-        const T yo = p.y[j];
-        p.x[j] = (T)((T)(yn * omb) + (T)(yo * beta));               // agd.py:184
-        p.y_new[j] = yn;
-    }
+    T yn = (T)(x[j] + (T)(g[j] * stp));                         // agd.py:181
+    const bool eq = eq_mask && eq_mask[j];
+    if (!eq) yn = yn > (T)0 ? yn : (T)0;                        // project_on_nn_cone, agd.py:13-21
+    x[j] = (T)((T)(yn * omb) + (T)(y[j] * b));                  // agd.py:184
+    y_new[j] = yn;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -326,18 +427,46 @@ int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st) {
     return 0;
 }
 
-int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
-                    hipStream_t st) {
-    double* log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
-    if (s->val_dtype == DL_F32) {
-        AgdArgs<float> p{s->m,   packed, (const float*)b, (float*)s->x, (const float*)s->y, (float*)s->y_old, (float*)s->g_old, (const float*)s->g,
-                         s->eq_mask, s->beta, (AgdDevState*)s->state, log_row, gamma, iter, decay_now, decay_factor};
-        hipLaunchKernelGGL(agd_step_kernel<float>, dim3(1), dim3(kAgdThreads), 0, st, p);
-    } else {
-        AgdArgs<double> p{s->m,   packed, (const double*)b, (double*)s->x, (const double*)s->y, (double*)s->y_old, (double*)s->g_old, (const double*)s->g,
-                          s->eq_mask, s->beta, (AgdDevState*)s->state, log_row, gamma, iter, decay_now, decay_factor};
-        hipLaunchKernelGGL(agd_step_kernel<double>, dim3(1), dim3(kAgdThreads), 0, st, p);
+template <class T>
+static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
+                          double decay_factor, hipStream_t st) {
+    const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
+    StatsArgs<T> sa;
+    sa.m = s->m;
+    sa.partial = f ? static_cast<const long long*>(f->partial) : nullptr;
+    sa.partial_scal = f ? f->partial_scal : nullptr;
+    sa.shift_in = f ? f->shift_dev : nullptr;
+    sa.n_slabs = f ? (f->grad_lds ? f->n_wg : 1) : 0;
+    sa.n_scal = f ? f->n_wg : 0;
+    sa.mpad = f ? f->mpad : 0;
+    sa.packed_in = packed;
+    sa.packed_out = s->packed;
+    sa.b = (const T*)b;
+    sa.x = (const T*)s->x;
+    sa.y = (const T*)s->y;
+    sa.y_prev = (const T*)s->y_old;
+    sa.g_old = (const T*)s->g;
+    sa.g_new = (T*)s->g_old;
+    sa.st = (const AgdDevState*)s->state;
+    sa.partial_stats = s->partial_stats;
+    if (n_blocks > 0) {
+        if (f) hipLaunchKernelGGL((agd_stats_kernel<T, true>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
+        else hipLaunchKernelGGL((agd_stats_kernel<T, false>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
     }
+    FinalizeArgs<T> fa;
+    fa.m = s->m;
+    fa.scal = (f ? s->packed : packed) + s->m;
+    fa.partial_stats = s->partial_stats;
+    fa.n_blocks = n_blocks;
+    fa.st = (AgdDevState*)s->state;
+    fa.log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
+    fa.gamma = gamma;
+    fa.decay_now = decay_now;
+    fa.decay_factor = decay_factor;
+    hipLaunchKernelGGL(agd_finalize_kernel<T>, dim3(1), dim3(64), 0, st, fa);
+    if (s->m > 0)
+        hipLaunchKernelGGL(agd_update_kernel<T>, dim3((unsigned)((s->m + 255) / 256)), dim3(256), 0, st, s->m, (T*)s->x, (const T*)s->y, (T*)s->y_old,
+                           (const T*)s->g_old, s->eq_mask, s->beta, (const AgdDevState*)s->state, iter);
     DL_HIP(hipGetLastError());
     // rotate: the buffer that received y_i becomes y; the old y becomes the "previous history dual"
     void* t = s->y;
@@ -348,6 +477,16 @@ int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma
     s->g_old = t;
     return 0;
 }
+
+// f != nullptr: A x is taken from the matching handle's integer slabs (single-device loop, no separate slab reduction);
+// f == nullptr: A x is read from `packed` (already reduced, and all-reduced when sharded).
+int launch_agd_step(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
+                    hipStream_t st) {
+    if (s->val_dtype == DL_F32) return agd_step_typed<float>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);
+    return agd_step_typed<double>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);
+}
+
+size_t agd_partial_stats_bytes(int64_t m) { return sizeof(double) * kStatCols * (size_t)((m + kStatRows - 1) / kStatRows + 1); }
 
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st) {
     if (K <= 0 || L <= 0) return 0;

@@ -40,8 +40,10 @@ int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* 
 size_t agd_state_bytes();
 int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st);
 int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st);
-int launch_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
-                    hipStream_t st);
+int launch_agd_step(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
+                    double decay_factor, hipStream_t st);
+size_t agd_partial_stats_bytes(int64_t m);
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st);
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
@@ -542,7 +544,7 @@ int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void*
 // ---------------------------------------------------------------------------------------------------------
 static void agd_free(dl_agd* s) {
     if (!s) return;
-    void* ptrs[] = {s->x, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed};
+    void* ptrs[] = {s->x, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -571,6 +573,7 @@ int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, cons
     if (e == hipSuccess) e = hipMalloc((void**)&s->log, sizeof(double) * kLogCols * (size_t)(max_iter > 0 ? max_iter : 1));
     if (e == hipSuccess) e = hipMalloc(&s->state, agd_state_bytes());
     if (e == hipSuccess) e = hipMalloc((void**)&s->packed, sizeof(double) * (size_t)(m + 2));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->partial_stats, agd_partial_stats_bytes(m));
     if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->x, lambda0, vb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->y, lambda0, vb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(s->y_old, 0, vb, st);
@@ -612,7 +615,7 @@ int dl_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, in
                 dl_stream_t stream) {
     if (!s || !packed || (s->m > 0 && !b)) return fail(DL_E_ARG, "null argument");
     if (iter < 1 || iter > s->max_iter) return fail(DL_E_STATE, "iteration %lld outside 1..max_iter=%lld", (long long)iter, (long long)s->max_iter);
-    return launch_agd_step(s, packed, b, gamma, iter, decay_now, decay_factor, (hipStream_t)stream);
+    return launch_agd_step(s, nullptr, packed, b, gamma, iter, decay_now, decay_factor, (hipStream_t)stream);
 }
 
 int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_iter, int64_t n_iters, double* gamma_io_host,
@@ -624,10 +627,11 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
     double gamma = *gamma_io_host;
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
-        int rc = matching_calculate(f, s->x, gamma, s->packed, xo, st);
+        const bool empty = f->n_tiles == 0 || f->n_wg == 0;
+        int rc = empty ? matching_calculate(f, s->x, gamma, s->packed, xo, st) : matching_launch_fused(f, s->x, gamma, xo, st);
         if (rc) return rc;
         const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
-        rc = launch_agd_step(s, s->packed, b, gamma, it, decay_now, decay_factor, st);
+        rc = launch_agd_step(s, empty ? nullptr : f, s->packed, b, gamma, it, decay_now, decay_factor, st);
         if (rc) return rc;
         if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
     }

@@ -111,4 +111,5 @@ struct dl_agd {
     double* log = nullptr;   // owned, [max_iter][kLogCols]
     void* state = nullptr;   // owned, dl::AgdDevState
     double* packed = nullptr;  // owned scratch double[m+2] for dl_agd_run_matching
+    double* partial_stats = nullptr;  // owned: per-workgroup partial reductions of the step kernel
 };

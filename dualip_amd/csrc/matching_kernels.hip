@@ -367,12 +367,9 @@ int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipSt
 static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) { return launch_fused4_f32(h, args, st); }
 static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) { return launch_fused4_f64(h, args, st); }
 
+// the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
 template <class T>
-static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
-    if (h->n_tiles == 0 || h->n_wg == 0) {  // no non-zeros at all: A x = 0
-        DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
-        return 0;
-    }
+static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
     FusedArgs<T> args;
     args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
     args.wg_tile_begin = h->wg_tile_begin;
@@ -418,6 +415,22 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
+    return 0;
+}
+
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
+    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st);
+    return fused_typed<double>(h, lambda, gamma, x_out, st);
+}
+
+template <class T>
+static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
+    if (h->n_tiles == 0 || h->n_wg == 0) {  // no non-zeros at all: A x = 0
+        DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
+        return 0;
+    }
+    int rc = fused_typed<T>(h, lambda, gamma, x_out, st);
+    if (rc) return rc;
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks > 0 ? blocks : 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),

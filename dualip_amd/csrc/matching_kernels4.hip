@@ -26,6 +26,17 @@ struct alignas(sizeof(RowT) * 4) RowQuad {
     RowT v[4];
 };
 
+// The cold single-column path re-reads the kernel arguments from the kernarg segment (they sit at offset 0) instead of
+// keeping a dozen pointers alive in SGPRs across the hot loop.
+template <class T>
+__device__ __forceinline__ const FusedArgs<T>& kernarg_args(const FusedArgs<T>& fallback) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const FusedArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return fallback;
+#endif
+}
+
 template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS>
 __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,20 +77,17 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         return v & (0u - (uint32_t)ok);
     };
     struct Tile {
+        uint32_t dv;  // descriptor words, one per lane; the head masks and the projection id are only unpacked when used
         uint32_t w0lo, w0hi;
-        uint64_t H[kSlots];
-        uint32_t pid;
         uint32_t q0;  // quad offset of lane 0 relative to k_base
         Quad<T> a, c;
         RowQuad<RowT> r;
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     auto unpack_and_issue = [&](uint32_t dv, Tile& t) {
+        t.dv = dv;
         t.w0lo = rl(dv, 0);
         t.w0hi = rl(dv, 1);
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) t.H[j] = ((uint64_t)rl(dv, 3 + 2 * j) << 32) | rl(dv, 2 + 2 * j);
-        t.pid = rl(dv, 10);
         const uint32_t hi = (t.w0hi >> 8) & 0x1FF;
         const bool is_long = (t.w0hi & (1u << 19)) != 0;
         t.q0 = (hi == 0 || is_long) ? 0u : (t.w0lo - kb_lo) >> 2;  // exact: a workgroup spans < 2^32 non-zeros
@@ -106,8 +114,9 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 
         const uint32_t hi = (cur.w0hi >> 8) & 0x1FF, lo = (cur.w0hi >> 17) & 3;
         const bool is_long = (cur.w0hi & (1u << 19)) != 0;
+        const uint32_t pid = rl(cur.dv, 10);
         if (!is_long) {
-            const ProjT<T> pj = w.proj_s[cur.pid < (uint32_t)(kProjLds - 1) ? cur.pid : (uint32_t)(kProjLds - 1)];
+            const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
             const int kind = __builtin_amdgcn_readfirstlane(pj.kind);
             T v[kSlots], x[kSlots];
             bool valid[kSlots];
@@ -120,10 +129,18 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
                 if (!(g.ablate & 2)) lam = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
                 const T t1 = (T)(cur.a.v[j] * lam);        // sparse_utils.py:79
                 v[j] = (T)(t1 + (T)(s * cur.c.v[j]));      // matching.py:66,142
-                x[j] = (g.ablate & 4) ? v[j] : project_pointwise(v[j], pj);
+                x[j] = v[j];
             }
-            if (is_simplex_kind(kind) && !(g.ablate & 4)) {
-                const Seg4 sg = make_seg4(cur.H);
+            const bool simplex_tile = is_simplex_kind(kind);
+            if (!simplex_tile && !(g.ablate & 4)) {
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
+            }
+            if (simplex_tile && !(g.ablate & 4)) {
+                uint64_t H[kSlots];
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
+                const Seg4 sg = make_seg4(H);
                 simplex_tile4(v, valid, sg, pj, lc, x);
             }
             T o32 = (T)0, q32 = (T)0;
@@ -144,9 +161,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
                     if (valid[j]) x_wg[4 * (cur.q0 + (uint32_t)lane) + j] = x[j];  // neighbours own the rest of the quad
             }
         } else {
-            const ProjT<T> pl = lookup_proj(g, w.proj_s, cur.pid);
+            const FusedArgs<T>& gk = kernarg_args(g);
+            const ProjT<T> pl = lookup_proj(gk, w.proj_s, pid);
             const uint64_t k0 = (((uint64_t)cur.w0hi << 32) | cur.w0lo) & ((1ull << 40) - 1);
-            process_long_tile<T, RowT, LAM_LDS>(g, pl, k0, cur.H[0], w.lam_s, w.gacc, s, w.scale, lane, obj, ssq);
+            const uint64_t len = ((uint64_t)rl(cur.dv, 3) << 32) | rl(cur.dv, 2);
+            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq);
         }
         ti = ti_next;
         cur = nxt;

@@ -53,14 +53,13 @@ __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
 template <class T>
 __device__ __forceinline__ T project_pointwise(T v, const ProjT<T>& p) { return tmin(tmax(v, p.lo), p.hi); }
 
-// theta = num / den.  double: IEEE division (parity mode).  float: reciprocal + one Newton step + residual correction
+// theta = num / den.  double: IEEE division (parity mode).  float: reciprocal, multiply, one residual correction
 // (<= 1 ulp from the correctly rounded quotient, a third of the instructions of the IEEE expansion).
 __device__ __forceinline__ double div_exactish(double num, double den) { return num / den; }
 __device__ __forceinline__ float div_exactish(float num, float den) {
-    float r = __builtin_amdgcn_rcpf(den);
-    r = fmaf(fmaf(-den, r, 1.0f), r, r);
+    const float r = __builtin_amdgcn_rcpf(den);  // den is a small integer count: r is within 1 ulp of 1/den
     const float q = num * r;
-    return fmaf(fmaf(-den, q, num), r, q);
+    return fmaf(fmaf(-den, q, num), r, q);        // one residual correction
 }
 
 __device__ __forceinline__ bool is_simplex_kind(int k) { return k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ; }

@@ -169,35 +169,41 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const bool (
         any_act = any_act || act[j];
     }
     if (__any(any_act)) {
-        T cnt_prev[kSlots];
+        // general columns: theta_1 = (sum - z) / |{u > max - z}|.  A support of two is already final: the runner-up
+        // stays above theta_1 exactly when it is above max - z.  Larger supports iterate until the size stops changing.
+        T ind[kSlots], cnt[kSlots];
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) cnt_prev[j] = (T)0;
-        for (int it = 0; it < kTile4 + 2; ++it) {
-            T ind[kSlots], cnt[kSlots];
+        for (int j = 0; j < kSlots; ++j) ind[j] = (u[j] > th[j] && live[j]) ? (T)1 : (T)0;
+        seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt);
+        any_act = false;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
+            th[j] = act[j] ? th_new : th[j];
+            act[j] = act[j] && cnt[j] > (T)2;
+            any_act = any_act || act[j];
+        }
+        for (int it = 0; it < kTile4 && __any(any_act); ++it) {
+            T cnt2[kSlots];
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) ind[j] = (u[j] > th[j] && live[j]) ? (T)1 : (T)0;
-            seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt);
+            seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt2);
             any_act = false;
-            bool need_sum = false;
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
-                const bool conv = cnt[j] == cnt_prev[j] || cnt[j] == (T)0;  // support unchanged: th is the fixed point
-                act[j] = act[j] && !conv;
-                need_sum = need_sum || (act[j] && it > 0);
-            }
-            if (__any(need_sum)) {
-#pragma unroll
-                for (int j = 0; j < kSlots; ++j) inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
-                seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
-            }
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
-                th[j] = act[j] ? th_new : th[j];
-                cnt_prev[j] = act[j] ? cnt[j] : cnt_prev[j];
+                act[j] = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;  // support unchanged: th is the fixed point
                 any_act = any_act || act[j];
             }
             if (!__any(any_act)) break;
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
+            seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt2[j]);
+                th[j] = act[j] ? th_new : th[j];
+                cnt[j] = act[j] ? cnt2[j] : cnt[j];
+            }
         }
     }
 #pragma unroll
