@@ -107,6 +107,16 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         unpack_and_issue(dv0, cur);
     }
     while (ti < t_end) {
+        // the current tile's lambda gathers go out first: their LDS latency overlaps the descriptor unpack and the
+        // issue of the next tile's loads
+        uint32_t row[kSlots];
+        T lam[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            row[j] = (uint32_t)cur.r.v[j];
+            lam[j] = (T)1;
+            if (!(g.ablate & 2)) lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+        }
         Tile nxt;
         const uint32_t ti_next = ti + kFusedWaves;
         unpack_and_issue(dv_next, nxt);
@@ -119,16 +129,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
             const int kind = __builtin_amdgcn_readfirstlane(pj.kind);
             T v[kSlots], x[kSlots];
-            bool valid[kSlots];
-            uint32_t row[kSlots];
+            const uint32_t e0 = 4u * (uint32_t)lane - lo, span = hi - lo;  // element j of the lane is in the tile iff e0 + j < span
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
-                row[j] = (uint32_t)cur.r.v[j];
-                valid[j] = (uint32_t)(4 * lane + j) - lo < hi - lo;
-                T lam = (T)1;
-                if (!(g.ablate & 2)) lam = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
-                const T t1 = (T)(cur.a.v[j] * lam);        // sparse_utils.py:79
-                v[j] = (T)(t1 + (T)(s * cur.c.v[j]));      // matching.py:66,142
+                const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
+                const T vj = (T)(t1 + (T)(s * cur.c.v[j]));  // matching.py:66,142
+                v[j] = (e0 + (uint32_t)j < span) ? vj : (T)0;
                 x[j] = v[j];
             }
             const bool simplex_tile = is_simplex_kind(kind);
@@ -141,12 +147,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
                 const Seg4 sg = make_seg4(H);
-                simplex_tile4(v, valid, sg, pj, lc, x);
+                simplex_tile4(v, sg, pj, lc, x, g.ablate);
             }
             T o32 = (T)0, q32 = (T)0;
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
-                const T xq = valid[j] ? x[j] : (T)0;
+                const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
                 const T ax = (T)(cur.a.v[j] * xq);
                 if (ax != (T)0 && !(g.ablate & 1)) scatter_fixed(w.gacc, row[j], ax, w.scale);
                 o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             if (x_wg) {
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j)
-                    if (valid[j]) x_wg[4 * (cur.q0 + (uint32_t)lane) + j] = x[j];  // neighbours own the rest of the quad
+                    if (e0 + (uint32_t)j < span) x_wg[4 * (cur.q0 + (uint32_t)lane) + j] = x[j];  // neighbours own the rest of the quad
             }
         } else {
             const FusedArgs<T>& gk = kernarg_args(g);

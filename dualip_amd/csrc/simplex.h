@@ -45,10 +45,12 @@ __device__ __forceinline__ ProjT<T> make_proj(int kind, double p0, double p1) {
     return p;
 }
 
-template <class T>
-__device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
-template <class T>
-__device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+// One-instruction min / max.  fmaxf() would cost three: with the IEEE mode bit set the compiler canonicalises both
+// operands (v_max x,x,x) first.  The raw instruction drops a NaN operand, where torch.clamp would propagate it.
+__device__ __forceinline__ float tmax(float a, float b) { return hw_max(a, b); }
+__device__ __forceinline__ double tmax(double a, double b) { return hw_max(a, b); }
+__device__ __forceinline__ float tmin(float a, float b) { return hw_min(a, b); }
+__device__ __forceinline__ double tmin(double a, double b) { return hw_min(a, b); }
 
 template <class T>
 __device__ __forceinline__ T project_pointwise(T v, const ProjT<T>& p) { return tmin(tmax(v, p.lo), p.hi); }

@@ -86,38 +86,37 @@ __device__ __forceinline__ Seg4 make_seg4(const uint64_t (&H)[kSlots]) {
     return s;
 }
 
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_mov_i(float ident, float x) { return dpp_mov<CTRL, ROWMASK>(ident, x); }
-
-// cross-lane segmented inclusive scan with wave-uniform predicate masks
+// cross-lane segmented inclusive scan with wave-uniform predicate masks.  All reduced quantities here are >= 0
+// (clamped values, indicator counts), so 0 is the identity of both OpAdd and OpMax and the zero-fill DPP form applies.
 template <class T, class Op>
-__device__ __forceinline__ T lane_scan4(T x, const Seg4& s, T ident, Op op) {
+__device__ __forceinline__ T lane_scan4(T x, const Seg4& s, Op op) {
     T t;
-    t = dpp_mov<DPP_ROW_SHR1, 0xf>(ident, x);
+    t = dpp_mov0<DPP_ROW_SHR1, 0xf>(x);
     x = lane_bit(s.P1) ? op(x, t) : x;
-    t = dpp_mov<DPP_ROW_SHR2, 0xf>(ident, x);
+    t = dpp_mov0<DPP_ROW_SHR2, 0xf>(x);
     x = lane_bit(s.P2) ? op(x, t) : x;
-    t = dpp_mov<DPP_ROW_SHR4, 0xf>(ident, x);
+    t = dpp_mov0<DPP_ROW_SHR4, 0xf>(x);
     x = lane_bit(s.P4) ? op(x, t) : x;
-    t = dpp_mov<DPP_ROW_SHR8, 0xf>(ident, x);
+    t = dpp_mov0<DPP_ROW_SHR8, 0xf>(x);
     x = lane_bit(s.P8) ? op(x, t) : x;
-    t = dpp_mov<DPP_ROW_BCAST15, 0xa>(ident, x);
+    t = dpp_mov0<DPP_ROW_BCAST15, 0xa>(x);
     x = lane_bit(s.PA) ? op(x, t) : x;
-    t = dpp_mov<DPP_ROW_BCAST31, 0xc>(ident, x);
+    t = dpp_mov0<DPP_ROW_BCAST31, 0xc>(x);
     x = lane_bit(s.PB) ? op(x, t) : x;
     return x;
 }
 
 // Every element receives the reduction over its column.  end_lane: lane holding the end of the column that is open
 // at this lane's end (from end_lane4()).
+// (values must be >= 0, see lane_scan4)
 template <class T, class Op>
-__device__ __forceinline__ void seg_allreduce4(const T (&u)[kSlots], const Seg4& s, int end_lane, T ident, Op op, T (&tot)[kSlots]) {
+__device__ __forceinline__ void seg_allreduce4(const T (&u)[kSlots], const Seg4& s, int end_lane, Op op, T (&tot)[kSlots]) {
     T f[kSlots];
     f[0] = u[0];
 #pragma unroll
     for (int j = 1; j < kSlots; ++j) f[j] = lane_bit(s.H[j]) ? u[j] : op(f[j - 1], u[j]);
-    const T c = lane_scan4(f[kSlots - 1], s, ident, op);
-    const T carry = dpp_mov<DPP_WAVE_SHR1, 0xf>(ident, c);
+    const T c = lane_scan4(f[kSlots - 1], s, op);
+    const T carry = dpp_mov0<DPP_WAVE_SHR1, 0xf>(c);
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) f[j] = lane_bit(s.N[j]) ? op(carry, f[j]) : f[j];
     // backward: value at the last element of the slot's column inside this lane
@@ -140,79 +139,83 @@ __device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
 }
 
 // Simplex projection of every column of a 256-element tile (see simplex.h for the algorithm and the reference lines).
-//   live[j]: the element exists and belongs to a simplex column;  x is only written where live.
+//   v must already be 0 in slots that hold no element of the tile (they form dummy segments of zeros);
+//   every slot of x is written.
 // Decisions without a support COUNT where possible: feasible <=> sum over {u > max - z} <= z + 1e-6; vertex <=> that sum
 // equals the maximum exactly (the maximum is the only member); only the remaining columns pay for counting.
+// Few boolean masks are kept alive on purpose: every per-slot flag is an SGPR pair and the kernel is SGPR-starved.
 template <class T>
-__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const bool (&live)[kSlots], const Seg4& s, const ProjT<T>& pj,
-                                              const LaneConst& lc, T (&x)[kSlots]) {
+__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots],
+                                              int ablate = 0) {
     const int el = end_lane4(s, lc);
-    T u[kSlots], v1[kSlots], th[kSlots], sumA[kSlots], inu[kSlots];
+    T u[kSlots], th[kSlots], sumA[kSlots], inu[kSlots];
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) u[j] = live[j] ? tmax(v[j], (T)0) : (T)0;
-    seg_allreduce4(u, s, el, (T)(-INFINITY), OpMax(), v1);
+    for (int j = 0; j < kSlots; ++j) u[j] = tmax(v[j], (T)0);
+    {
+        T v1[kSlots];
+        seg_allreduce4(u, s, el, OpMax(), v1);
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) {
-        th[j] = (T)(v1[j] - pj.z);
-        inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
+        for (int j = 0; j < kSlots; ++j) {
+            th[j] = (T)(v1[j] - pj.z);
+            inu[j] = u[j] > th[j] ? u[j] : (T)0;
+        }
+        seg_allreduce4(inu, s, el, OpAdd(), sumA);
+        // vertex <=> sumA == max: the maximum is the only member (the comparison is exact: a one-term sum)
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) inu[j] = v1[j];  // keep the maximum in inu until the classification below
     }
-    seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
-    bool act[kSlots], proj[kSlots], onehot[kSlots];
-    bool any_act = false;
+    bool gen[kSlots];
+    bool any_gen = false;
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
-        const bool feas = ineq && !(sumA[j] > pj.ztol);           // simplex.py:153-158
-        onehot[j] = live[j] && !feas && sumA[j] == v1[j];          // the maximum alone exceeds max - z (simplex.py:177-193)
-        act[j] = live[j] && !feas && !onehot[j];
-        proj[j] = act[j];
-        any_act = any_act || act[j];
+        const bool feas = ineq && !(sumA[j] > pj.ztol);      // simplex.py:153-158: keep the clamped values
+        const bool onehot = !feas && sumA[j] == inu[j];      // simplex.py:177-193: z at the maximum, 0 elsewhere
+        const T xv = (u[j] > th[j]) ? pj.z : (T)0;
+        x[j] = onehot ? xv : u[j];
+        gen[j] = !feas && !onehot;
+        any_gen = any_gen || gen[j];
     }
-    if (__any(any_act)) {
+    if (__any(any_gen) && !(ablate & 8)) {
         // general columns: theta_1 = (sum - z) / |{u > max - z}|.  A support of two is already final: the runner-up
-        // stays above theta_1 exactly when it is above max - z.  Larger supports iterate until the size stops changing.
+        // stays above theta_1 exactly when it is above max - z.
         T ind[kSlots], cnt[kSlots];
+        bool act[kSlots];
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) ind[j] = (u[j] > th[j] && live[j]) ? (T)1 : (T)0;
-        seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt);
-        any_act = false;
+        for (int j = 0; j < kSlots; ++j) ind[j] = u[j] > th[j] ? (T)1 : (T)0;
+        seg_allreduce4(ind, s, el, OpAdd(), cnt);
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
-            th[j] = act[j] ? th_new : th[j];
-            act[j] = act[j] && cnt[j] > (T)2;
-            any_act = any_act || act[j];
+            th[j] = (gen[j] && cnt[j] > (T)0) ? th_new : th[j];
+            act[j] = gen[j] && cnt[j] > (T)2;
         }
-        for (int it = 0; it < kTile4 && __any(any_act); ++it) {
+        // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
+        // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.
+        for (int it = 0; it < kTile4 && !(ablate & 16); ++it) {
+            bool dropped = false;
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) dropped = dropped || (act[j] && ind[j] != (T)0 && !(u[j] > th[j]));
+            if (!__any(dropped)) break;
             T cnt2[kSlots];
 #pragma unroll
-            for (int j = 0; j < kSlots; ++j) ind[j] = (u[j] > th[j] && live[j]) ? (T)1 : (T)0;
-            seg_allreduce4(ind, s, el, (T)0, OpAdd(), cnt2);
-            any_act = false;
-#pragma unroll
             for (int j = 0; j < kSlots; ++j) {
-                act[j] = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;  // support unchanged: th is the fixed point
-                any_act = any_act || act[j];
+                ind[j] = u[j] > th[j] ? (T)1 : (T)0;
+                inu[j] = u[j] > th[j] ? u[j] : (T)0;
             }
-            if (!__any(any_act)) break;
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) inu[j] = (u[j] > th[j] && live[j]) ? u[j] : (T)0;
-            seg_allreduce4(inu, s, el, (T)0, OpAdd(), sumA);
+            seg_allreduce4(ind, s, el, OpAdd(), cnt2);
+            seg_allreduce4(inu, s, el, OpAdd(), sumA);
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
+                const bool changed = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;
                 const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt2[j]);
-                th[j] = act[j] ? th_new : th[j];
-                cnt[j] = act[j] ? cnt2[j] : cnt[j];
+                th[j] = changed ? th_new : th[j];
+                cnt[j] = changed ? cnt2[j] : cnt[j];
+                act[j] = changed;
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) {
-        const T xg = tmax((T)(u[j] - th[j]), (T)0);
-        const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-        T r = proj[j] ? xg : u[j];
-        r = onehot[j] ? xv : r;
-        x[j] = live[j] ? r : x[j];
+        for (int j = 0; j < kSlots; ++j) x[j] = gen[j] ? tmax((T)(u[j] - th[j]), (T)0) : x[j];
     }
 }
 

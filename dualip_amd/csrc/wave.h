@@ -6,6 +6,44 @@
 
 namespace dl {
 
+// raw v_max / v_min (no NaN canonicalisation pre-ops; host pass sees plain C)
+__device__ __forceinline__ float hw_max(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a > b ? a : b;
+#endif
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
+}
+__device__ __forceinline__ double hw_max(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a > b ? a : b;
+#endif
+}
+__device__ __forceinline__ double hw_min(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // ---- raw DPP moves: lanes whose source is outside the DPP pattern (or masked by ROWMASK) receive `ident` ----
@@ -19,6 +57,19 @@ __device__ __forceinline__ double dpp_mov(double ident, double x) {
     int xlo = __double2loint(x), xhi = __double2hiint(x);
     int rlo = __builtin_amdgcn_update_dpp(ilo, xlo, CTRL, ROWMASK, 0xf, false);
     int rhi = __builtin_amdgcn_update_dpp(ihi, xhi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(rhi, rlo);
+}
+
+// zero-fill form (bound_ctrl:1, old = 0): no identity pre-load, fuses into v_add_f32_dpp / v_max_f32_dpp.
+// Valid whenever 0 is the identity of the reduction -- sums, and maxima of non-negative values.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov0(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, true));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_mov0(double x) {
+    const int rlo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, true);
+    const int rhi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, true);
     return __hiloint2double(rhi, rlo);
 }
 
@@ -72,9 +123,10 @@ struct OpAdd {
     template <class T>
     __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
 };
-struct OpMax {
-    template <class T>
-    __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; }
+struct OpMax {  // v_max_f32 / v_max_f64 (one instruction; a NaN operand is dropped, unlike torch.clamp)
+    __device__ __forceinline__ float operator()(float a, float b) const { return hw_max(a, b); }
+    __device__ __forceinline__ double operator()(double a, double b) const { return hw_max(a, b); }
+    __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; }
 };
 
 // Segmented inclusive scan.  DPP form: 4 in-row shifts + 2 row broadcasts (no LDS traffic);

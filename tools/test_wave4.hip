@@ -30,15 +30,15 @@ __global__ void k(const float* v, const uint64_t* heads, const int* range, float
     for (int j = 0; j < 4; ++j) {
         vv[j] = v[t * 256 + 4 * lane + j];
         xx[j] = -7.f;
-        uu[j] = lane_bit(live[j]) ? vv[j] : 0.f;
+        uu[j] = lane_bit(live[j]) ? fabsf(vv[j]) : 0.f;
     }
     const int el = end_lane4(s, lc);
-    seg_allreduce4(uu, s, el, 0.f, OpAdd(), tot);
-    seg_allreduce4(uu, s, el, -INFINITY, OpMax(), mx);
+    seg_allreduce4(uu, s, el, OpAdd(), tot);
+    seg_allreduce4(uu, s, el, OpMax(), mx);
     const ProjT<float> pj = make_proj<float>(DL_PROJ_SIMPLEX, z, 0.0);
-    bool lv[4];
-    for (int j = 0; j < 4; ++j) lv[j] = lane_bit(live[j]);
-    simplex_tile4(vv, lv, s, pj, lc, xx);
+    float vz[4];
+    for (int j = 0; j < 4; ++j) vz[j] = lane_bit(live[j]) ? vv[j] : 0.f;
+    simplex_tile4(vz, s, pj, lc, xx);
     for (int j = 0; j < 4; ++j) {
         x[t * 256 + 4 * lane + j] = xx[j];
         sums[t * 256 + 4 * lane + j] = tot[j];
@@ -83,7 +83,7 @@ int main() {
                 float r = (float)(rng() % 100000) / 100000.f;
                 e = regime == 0 ? r * 30.f - 2.f : (regime == 1 ? r * 0.5f - 0.1f : r * 1.5f - 0.3f);
             }
-            for (int i = 0; i < len; ++i) { v[t * 256 + pos + i] = col[i]; sm += col[i]; mx = std::max(mx, col[i]); }
+            for (int i = 0; i < len; ++i) { v[t * 256 + pos + i] = col[i]; sm += std::fabs(col[i]); mx = std::max(mx, std::fabs(col[i])); }
             for (int i = 0; i < len; ++i) { wsum[t * 256 + pos + i] = sm; wmax[t * 256 + pos + i] = mx; }
             ref_proj(col, 1.0f);
             for (int i = 0; i < len; ++i) want[t * 256 + pos + i] = col[i];
