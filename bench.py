@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-sample-cols", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="take the N>1 code path (distributed objective + all-reduce) even with one rank")
     return ap.parse_args()
 
 
@@ -124,9 +125,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
@@ -142,7 +146,7 @@ def main():
     hi = min(n, lo + per[rank] * CHUNK_COLS)
 
     def reduce_loads(v):
-        if world > 1:
+        if sharded:
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
         return v
 
@@ -155,13 +159,13 @@ def main():
     inp.projection_map = pm_local
     nnz_local = prob["nnz"]
     nnz_t = torch.tensor([nnz_local], dtype=torch.float64, device=device)
-    if world > 1:
+    if sharded:
         dist.all_reduce(nnz_t)
     total_nnz = int(nnz_t.item())
 
     t_setup = time.perf_counter()
     b_vec = inp.b_vec
-    if world > 1:
+    if sharded:
         inp.b_vec = None
         f = MatchingSolverDualObjectiveFunctionDistributed(inp, b_vec, args.gamma, host_device=device)
         local = f.local_objective
@@ -180,7 +184,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -193,7 +197,7 @@ def main():
     launches, kernel_ms = local.profile_read()
     local.profile(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if sharded:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     result = run.finish()
@@ -255,11 +259,12 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
+            inp.b_vec = b_vec
             out["cpu_baseline"] = cpu_baseline(args, inp, pm_local, total_nnz)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

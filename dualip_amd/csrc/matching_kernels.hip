@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
 // ---------------------------------------------------------------------------------------------------------
 // slab reduction: packed[0..m) = 2^-shift * sum_w partial[w][i] (exact integer sum), packed[m], packed[m+1] = scalars
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kRedThreads = 256;
-constexpr int kRedRows = 64;  // rows per block; 4 slab-slices per block
+constexpr int kRedThreads = 1024;
+constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
 
 __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,

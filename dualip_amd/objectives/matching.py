@@ -173,12 +173,16 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
 
     def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Local pass only: returns the internal float64 buffer [A x (m) | c.x | sum x^2] (overwritten by the next call)."""
+        lam = self._check_dual(dual_val)
+        return self.calculate_packed_ptr(_hip.ptr(lam), gamma, x_out)
+
+    def calculate_packed_ptr(self, lambda_ptr: int, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same, with the dual vector given as a raw device address (the optimiser state lives inside the C library)."""
         if gamma is not None and gamma != self.gamma:
             self.gamma = gamma
-        lam = self._check_dual(dual_val)
         with torch.cuda.device(self.device):
             rc = self._lib.dl_matching_calculate(
-                self._handle, _hip.ptr(lam), float(self.gamma), _hip.ptr(self._packed), _hip.ptr(x_out), _hip.stream_ptr(self.device)
+                self._handle, lambda_ptr, float(self.gamma), _hip.ptr(self._packed), _hip.ptr(x_out), _hip.stream_ptr(self.device)
             )
         _hip.check(rc)
         return self._packed
@@ -263,13 +267,20 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
         # every rank finishes the objective on its own device (the reference moves b to host_device = cuda:0)
         self.b_vec = b_vec.to(device=self.device, dtype=self.dtype)
 
+    def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)  # the ONE collective of an iteration
+        return packed
+
     def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out=None) -> torch.Tensor:
         if gamma is not None and gamma != self.gamma:
             self.gamma = gamma
-        packed = self.local_objective.calculate_packed(dual_val, self.gamma, x_out)
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)
-        return packed
+        return self._exchange(self.local_objective.calculate_packed(dual_val, self.gamma, x_out))
+
+    def calculate_packed_ptr(self, lambda_ptr: int, gamma: float = None) -> torch.Tensor:
+        if gamma is not None and gamma != self.gamma:
+            self.gamma = gamma
+        return self._exchange(self.local_objective.calculate_packed_ptr(lambda_ptr, self.gamma))
 
     def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, rank: int = 0, **kwargs) -> ObjectiveResult:
         if save_primal:

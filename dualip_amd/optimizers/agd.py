@@ -261,8 +261,11 @@ class DeviceRun:
                 )
             else:
                 for it in range(self.done + 1, self.done + n + 1):
-                    self._x_dev = self._fetch(0, out=self._x_dev)
-                    packed = self.f.calculate_packed(self._x_dev, self.gamma.value)  # local pass + ONE sum-all-reduce
+                    if hasattr(self.f, "calculate_packed_ptr"):
+                        packed = self.f.calculate_packed_ptr(int(lib.dl_agd_x(self.state)), self.gamma.value)  # local pass + ONE sum-all-reduce
+                    else:
+                        self._x_dev = self._fetch(0, out=self._x_dev)
+                        packed = self.f.calculate_packed(self._x_dev, self.gamma.value)
                     decay_now = int(self.decay_steps > 0 and it % self.decay_steps == 0)
                     _hip.check(lib.dl_agd_step(self.state, _hip.ptr(packed), _hip.ptr(self.b_vec), self.gamma.value, it, decay_now, self.decay_factor, stream))
                     if decay_now:
