@@ -45,15 +45,17 @@ __device__ __forceinline__ ProjT<T> make_proj(int kind, double p0, double p1) {
     return p;
 }
 
-// One-instruction min / max.  fmaxf() would cost three: with the IEEE mode bit set the compiler canonicalises both
-// operands (v_max x,x,x) first.  The raw instruction drops a NaN operand, where torch.clamp would propagate it.
-__device__ __forceinline__ float tmax(float a, float b) { return hw_max(a, b); }
-__device__ __forceinline__ double tmax(double a, double b) { return hw_max(a, b); }
-__device__ __forceinline__ float tmin(float a, float b) { return hw_min(a, b); }
-__device__ __forceinline__ double tmin(double a, double b) { return hw_min(a, b); }
+template <class T>
+__device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+template <class T>
+__device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+
+// clamp(v, lo, hi), lo <= hi (box.py:15-16, cone.py:21-28 with infinite bounds where absent): v_med3_f32 for float
+__device__ __forceinline__ float clamp3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+__device__ __forceinline__ double clamp3(double v, double lo, double hi) { return tmin(tmax(v, lo), hi); }
 
 template <class T>
-__device__ __forceinline__ T project_pointwise(T v, const ProjT<T>& p) { return tmin(tmax(v, p.lo), p.hi); }
+__device__ __forceinline__ T project_pointwise(T v, const ProjT<T>& p) { return clamp3(v, p.lo, p.hi); }
 
 // theta = num / den.  double: IEEE division (parity mode).  float: reciprocal, multiply, one residual correction
 // (<= 1 ulp from the correctly rounded quotient, a third of the instructions of the IEEE expansion).
@@ -136,7 +138,7 @@ __device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (
     for (int q = 0; q < kBatch; ++q) {
         sg[q] = make_seginfo_fast(head[q] | 1ull, lc);
         live[q] = valid[q] && smp[q];
-        u[q] = live[q] ? tmax(v[q], (T)0) : (T)0;
+        u[q] = live[q] ? relu(v[q]) : (T)0;
     }
 #pragma unroll
     for (int q = 0; q < kBatch; ++q) v1[q] = seg_allreduce<USE_DPP>(u[q], sg[q], (T)(-INFINITY), OpMax());
@@ -183,7 +185,7 @@ __device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (
     }
 #pragma unroll
     for (int q = 0; q < kBatch; ++q) {
-        const T xg = tmax((T)(u[q] - th[q]), (T)0);      // general: threshold
+        const T xg = relu((T)(u[q] - th[q]));             // general: threshold
         const T xv = (u[q] > th[q]) ? pj[q].z : (T)0;    // vertex
         T r = proj[q] ? xg : u[q];
         r = onehot[q] ? xv : r;

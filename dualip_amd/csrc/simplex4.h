@@ -150,10 +150,10 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
     const int el = end_lane4(s, lc);
     T u[kSlots], th[kSlots], sumA[kSlots], inu[kSlots];
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) u[j] = tmax(v[j], (T)0);
+    for (int j = 0; j < kSlots; ++j) u[j] = relu(v[j]);
     {
         T v1[kSlots];
-        seg_allreduce4(u, s, el, OpMax(), v1);
+        seg_allreduce4(u, s, el, OpMaxNonNeg(), v1);
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             th[j] = (T)(v1[j] - pj.z);
@@ -215,7 +215,7 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
             }
         }
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) x[j] = gen[j] ? tmax((T)(u[j] - th[j]), (T)0) : x[j];
+        for (int j = 0; j < kSlots; ++j) x[j] = gen[j] ? relu((T)(u[j] - th[j])) : x[j];
     }
 }
 

@@ -6,43 +6,13 @@
 
 namespace dl {
 
-// raw v_max / v_min (no NaN canonicalisation pre-ops; host pass sees plain C)
-__device__ __forceinline__ float hw_max(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a > b ? a : b;
-#endif
-}
-__device__ __forceinline__ float hw_min(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a < b ? a : b;
-#endif
-}
-__device__ __forceinline__ double hw_max(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a > b ? a : b;
-#endif
-}
-__device__ __forceinline__ double hw_min(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a < b ? a : b;
-#endif
-}
+// Maxima without the NaN-canonicalisation pre-ops the compiler adds to fmaxf() under the IEEE mode bit (three
+// instructions instead of one), and without inline asm (which it refuses to speculate, turning selects into branches):
+// non-negative floats order like their bit patterns, and max(v, 0) is a signed-integer max against 0.
+__device__ __forceinline__ float relu(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+__device__ __forceinline__ double relu(double v) { return v > 0.0 ? v : 0.0; }
+__device__ __forceinline__ float max_nonneg(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ double max_nonneg(double a, double b) { return a > b ? a : b; }
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -123,10 +93,13 @@ struct OpAdd {
     template <class T>
     __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
 };
-struct OpMax {  // v_max_f32 / v_max_f64 (one instruction; a NaN operand is dropped, unlike torch.clamp)
-    __device__ __forceinline__ float operator()(float a, float b) const { return hw_max(a, b); }
-    __device__ __forceinline__ double operator()(double a, double b) const { return hw_max(a, b); }
-    __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; }
+struct OpMax {  // any sign (compare + select)
+    template <class T>
+    __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; }
+};
+struct OpMaxNonNeg {  // operands >= 0: one integer max on the bit patterns (float)
+    template <class T>
+    __device__ __forceinline__ T operator()(T a, T b) const { return max_nonneg(a, b); }
 };
 
 // Segmented inclusive scan.  DPP form: 4 in-row shifts + 2 row broadcasts (no LDS traffic);

@@ -34,7 +34,7 @@ __global__ void k(const float* v, const uint64_t* heads, const int* range, float
     }
     const int el = end_lane4(s, lc);
     seg_allreduce4(uu, s, el, OpAdd(), tot);
-    seg_allreduce4(uu, s, el, OpMax(), mx);
+    seg_allreduce4(uu, s, el, OpMaxNonNeg(), mx);
     const ProjT<float> pj = make_proj<float>(DL_PROJ_SIMPLEX, z, 0.0);
     float vz[4];
     for (int j = 0; j < 4; ++j) vz[j] = lane_bit(live[j]) ? vv[j] : 0.f;
