@@ -95,6 +95,7 @@ static void matching_free(dl_matching* h) {
     if (h->partial) (void)hipFree(h->partial);
     if (h->partial_scal) (void)hipFree(h->partial_scal);
     if (h->shift_dev) (void)hipFree(h->shift_dev);
+    if (h->timeline) (void)hipFree(h->timeline);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
     delete h;
@@ -163,6 +164,50 @@ static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj,
     return 0;
 }
 
+
+// Layout 4 schedule.  The fused kernel deals descriptor q to wavefront q mod S (S = 16 * workgroups) as its (q / S)-th
+// tile, so the ORDER of the descriptor array is the schedule (a descriptor is self-contained: window start, masks,
+// projection).  Simplex tiles are instruction bound, point-wise tiles memory bound: when a problem has both, the two lists
+// (each kept in memory order -- two sweep fronts) are merged so that (a) every wavefront alternates between the kinds in
+// proportion to their counts and (b) the four wavefronts that share a SIMD are at different phases of that alternation,
+// i.e. the SIMD's vector unit works on a simplex tile while its other wavefronts wait on point-wise loads.
+// Phase = Kronecker sequence frac((4 k + rho) * golden), k = tile number of the wavefront, rho = its SIMD-mate class.
+static void schedule_tiles4(std::vector<uint32_t>& words, std::vector<uint32_t>& tile_pid, const dl_proj_desc* projs, int32_t n_proj, int n_wg) {
+    const size_t n = tile_pid.size();
+    if (n == 0 || n_wg <= 0) return;
+    std::vector<uint32_t> heavy, light;
+    for (size_t t = 0; t < n; ++t) {
+        const uint32_t pid = tile_pid[t];
+        const bool long_tile = (words[t * 12 + 1] & (1u << 19)) != 0;
+        const int kind = (pid == kNoProj || (int32_t)pid >= n_proj) ? DL_PROJ_NONE : projs[pid].kind;
+        const bool hv = !long_tile && (kind == DL_PROJ_SIMPLEX || kind == DL_PROJ_SIMPLEX_EQ);
+        (hv ? heavy : light).push_back((uint32_t)t);
+    }
+    if (heavy.empty() || light.empty()) return;  // one kind: memory order is the schedule
+    const size_t S = (size_t)n_wg * kFusedWaves;
+    std::vector<uint32_t> out_words(words.size(), 0u), out_pid(n);
+    std::vector<uint32_t> order(n);
+    {
+        const double r = (double)heavy.size() / (double)n;
+        size_t ih = 0, il = 0;
+        for (size_t q = 0; q < n; ++q) {
+            const size_t k = q / S, wave = (q % S) % kFusedWaves;
+            const size_t rho = ((wave >> 2) + wave) & 3;
+            double v = (double)(4 * k + rho) * 0.6180339887498949;
+            v -= (double)(uint64_t)v;
+            const bool want_heavy = v < r;
+            const bool take_heavy = (want_heavy && ih < heavy.size()) || il == light.size();
+            order[q] = take_heavy ? heavy[ih++] : light[il++];
+        }
+    }
+    for (size_t q = 0; q < n; ++q) {
+        const uint32_t t = order[q];
+        memcpy(&out_words[q * 12], &words[(size_t)t * 12], 12 * sizeof(uint32_t));
+        out_pid[q] = tile_pid[t];
+    }
+    words.swap(out_words);  // (the trailing all-zero descriptor stays all-zero)
+    tile_pid.swap(out_pid);
+}
 
 // Layout 4: 16-byte-aligned 256-element windows of whole columns; 12 dwords per tile (see matching_kernels4.hip).
 static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs,
@@ -331,11 +376,12 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     if (h->layout == 4) {
         CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long));
         h->n_tiles = (int64_t)(words4.size() / 12);
+        words4.resize(words4.size() + 12, 0u);  // one all-zero descriptor: what schedule slots past the end read
     } else {
         CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
         h->n_tiles = (int64_t)tiles.size();
     }
-    if (h->n_tiles >= (1ll << 32)) {
+    if (h->n_tiles >= (1ll << 31)) {
         matching_free(h);
         return fail(DL_E_ARG, "too many tiles");
     }
@@ -349,6 +395,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int64_t want = (h->n_tiles + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
     h->n_wg = (int)(want < n_cu ? want : n_cu);
     if (h->n_wg < 1) h->n_wg = h->n_tiles > 0 ? 1 : 0;
+    if (h->layout == 4 && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(words4, tile_pid4, projs_host, n_proj, h->n_wg);
     std::vector<uint32_t> wg_begin((size_t)h->n_wg + 1, 0);
     {
         const uint64_t total = prefix.back();
@@ -396,6 +443,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * sizeof(long long)));
     CK(owned_malloc(h, (void**)&h->shift_dev, 2 * sizeof(unsigned long long) + sizeof(int)));
     CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    if (getenv("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
@@ -517,6 +565,16 @@ int dl_matching_profile(dl_matching* h, int enable) {
     if (!h) return fail(DL_E_ARG, "null handle");
     h->prof_on = enable != 0;
     h->prof_used = 0;
+    return 0;
+}
+
+int dl_matching_timeline_read(dl_matching* h, uint64_t* out_host, int64_t capacity) {
+    if (!h || !out_host) return fail(DL_E_ARG, "null argument");
+    if (!h->timeline) return fail(DL_E_ARG, "timeline not enabled (DUALIP_HIP_TIMELINE=1 at create)");
+    const int64_t n = (int64_t)h->n_wg * 4;
+    if (capacity < n) return fail(DL_E_ARG, "timeline buffer too small");
+    DL_HIP(hipDeviceSynchronize());
+    DL_HIP(hipMemcpy(out_host, h->timeline, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -31,7 +31,9 @@ struct FusedArgs {
     int64_t mpad;
     int64_t nnz;
     int32_t n_proj;
+    uint32_t n_tiles;   // layout 4: tiles of the launch (cyclic schedule)
     int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
+    unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
 };
 
 // a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.

@@ -393,7 +393,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.mpad = h->mpad;
     args.nnz = h->nnz;
     args.n_proj = h->n_proj;
+    args.n_tiles = (uint32_t)h->n_tiles;
     args.ablate = h->ablate;
+    args.timeline = h->timeline;
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
     hipEvent_t ev_stop = nullptr;
     if (h->prof_on) {

@@ -37,6 +37,12 @@ __device__ __forceinline__ const FusedArgs<T>& kernarg_args(const FusedArgs<T>& 
 #endif
 }
 
+template <class T>
+__device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, int k) {
+    unsigned long long* tl = kernarg_args(g).timeline;
+    if (tl && tid == 0) tl[4 * (size_t)wg + k] = wall_clock64();
+}
+
 template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS>
 __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -44,69 +50,69 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
+    stamp(g, wg, tid, 0);
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
+    stamp(g, wg, tid, 1);
     const T s = w.s;
     const LaneConst lc = make_lane_const(lane);
     double obj = 0.0, ssq = 0.0;
 
-    const uint32_t t_begin = g.wg_tile_begin[wg];
-    const uint32_t t_end = g.wg_tile_begin[wg + 1];
-    uint64_t k_base = 0;  // window start of the workgroup's first tile (multiple of 4)
-    if (t_begin < t_end) {
-        const uint32_t lo = g.tiles32[(size_t)t_begin * kDesc4Words], hi = g.tiles32[(size_t)t_begin * kDesc4Words + 1];
-        k_base = (((uint64_t)hi << 32) | lo) & ((1ull << 40) - 1) & ~3ull;  // a long first tile starts anywhere
-    }
-    const uint64_t nnz_al4 = (uint64_t)g.nnz & ~3ull;                          // host guarantees nnz_al4 >= 4 for this layout
-    if (k_base + 4 > nnz_al4) k_base = nnz_al4 - 4;
-    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)k_base);
-    k_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(k_base >> 32)) << 32) | kb_lo;
-    const T* __restrict__ a_wg = g.a + k_base;
-    const T* __restrict__ c_wg = g.c + k_base;
-    const RowT* __restrict__ r_wg = reinterpret_cast<const RowT*>(g.rowidx) + k_base;
-    T* __restrict__ x_wg = g.x_out ? g.x_out + k_base : nullptr;
-    // last quad that may be read with a vector load (the array's final partial quad is never part of a window)
-    const uint32_t max_quad = (uint32_t)((nnz_al4 - k_base) / 4) - 1u;
+    // ---- tile schedule ----
+    // Descriptors are stored in SCHEDULE order (api.hip: schedule_tiles4) and dealt cyclically to the S = 16 * workgroups
+    // wavefronts of the launch: wavefront W takes slots W, W + S, W + 2S, ...  Every wavefront therefore sees the same
+    // proportion of every projection block (no cost model, no tail), the launch sweeps the arrays front to back, and
+    // the host interleaves instruction-bound (simplex) and memory-bound (point-wise) tiles so that the wavefronts
+    // sharing a SIMD are in different kinds at any moment.
+    const uint32_t n_tiles = g.n_tiles;
+    const uint32_t S = (uint32_t)gridDim.x * (uint32_t)kFusedWaves;
+    // last quad of the arrays that may be read with a vector load (the final partial quad is never part of a window)
+    const uint64_t last_quad = ((uint64_t)g.nnz >> 2) - 1;  // host guarantees nnz >= 1024 for this layout
 
-    const size_t last_word = (size_t)t_end * kDesc4Words - 1;
-    auto load_desc = [&](uint32_t t) -> uint32_t {  // unconditional, clamped (see matching_kernels.hip)
-        const uint32_t l = (uint32_t)lane < (uint32_t)kDesc4Words ? (uint32_t)lane : (uint32_t)kDesc4Words - 1u;
-        size_t idx = (size_t)t * kDesc4Words + l;
-        idx = idx < last_word ? idx : last_word;
-        const uint32_t v = g.tiles32[idx];
-        const bool ok = (uint32_t)lane < (uint32_t)kDesc4Words && t < t_end;
-        return v & (0u - (uint32_t)ok);
+    // descriptor word `lane` of schedule slot q (lanes >= 12 re-read word 11; slots past the end read the all-zero
+    // descriptor the host appends).  A plain load: nothing consumes it before the next iteration.
+    const uint32_t dlane = (uint32_t)lane < (uint32_t)kDesc4Words ? (uint32_t)lane : (uint32_t)kDesc4Words - 1u;
+    auto load_desc = [&](uint32_t q) -> uint32_t {
+        const uint32_t t = q < n_tiles ? q : n_tiles;
+        return byte_offset(g.tiles32 + (size_t)t * kDesc4Words, dlane * 4u)[0];
     };
     struct Tile {
         uint32_t dv;  // descriptor words, one per lane; the head masks and the projection id are only unpacked when used
         uint32_t w0lo, w0hi;
-        uint32_t q0;  // quad offset of lane 0 relative to k_base
         Quad<T> a, c;
         RowQuad<RowT> r;
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
+    auto window_of = [&](uint32_t w0lo, uint32_t w0hi) -> uint64_t {  // element index of the window start (0 for padding / long tiles)
+        const uint32_t hi = (w0hi >> 8) & 0x1FF;
+        const bool is_long = (w0hi & (1u << 19)) != 0;
+        const uint64_t W = ((uint64_t)(w0hi & 0xFFu) << 32) | w0lo;
+        return (hi == 0 || is_long) ? 0ull : W;
+    };
     auto unpack_and_issue = [&](uint32_t dv, Tile& t) {
         t.dv = dv;
         t.w0lo = rl(dv, 0);
         t.w0hi = rl(dv, 1);
-        const uint32_t hi = (t.w0hi >> 8) & 0x1FF;
-        const bool is_long = (t.w0hi & (1u << 19)) != 0;
-        t.q0 = (hi == 0 || is_long) ? 0u : (t.w0lo - kb_lo) >> 2;  // exact: a workgroup spans < 2^32 non-zeros
-        uint32_t q = t.q0 + (uint32_t)lane;
-        q = q < max_quad ? q : max_quad;
-        t.a = *byte_offset(reinterpret_cast<const Quad<T>*>(a_wg), q * (uint32_t)sizeof(Quad<T>));
-        t.c = *byte_offset(reinterpret_cast<const Quad<T>*>(c_wg), q * (uint32_t)sizeof(Quad<T>));
-        t.r = *byte_offset(reinterpret_cast<const RowQuad<RowT>*>(r_wg), q * (uint32_t)sizeof(RowQuad<RowT>));
+        const uint64_t W = window_of(t.w0lo, t.w0hi);
+        const uint64_t room = last_quad - (W >> 2);                  // quads available after the window start
+        const uint32_t lim = room < 63 ? (uint32_t)room : 63u;
+        const uint32_t q = (uint32_t)lane < lim ? (uint32_t)lane : lim;  // lanes past the arrays' end re-read the last quad (masked later)
+        t.a = *byte_offset(reinterpret_cast<const Quad<T>*>(g.a + W), q * (uint32_t)sizeof(Quad<T>));
+        t.c = *byte_offset(reinterpret_cast<const Quad<T>*>(g.c + W), q * (uint32_t)sizeof(Quad<T>));
+        t.r = *byte_offset(reinterpret_cast<const RowQuad<RowT>*>(reinterpret_cast<const RowT*>(g.rowidx) + W), q * (uint32_t)sizeof(RowQuad<RowT>));
     };
 
-    uint32_t ti = t_begin + (uint32_t)wave;
-    Tile cur;
+    uint32_t ti = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;  // schedule slot
     uint32_t dv_next = 0;
-    if (ti < t_end) {
+    Tile tA, tB;
+    if (ti < n_tiles) {
         const uint32_t dv0 = load_desc(ti);
-        dv_next = load_desc(ti + kFusedWaves);
-        unpack_and_issue(dv0, cur);
+        dv_next = load_desc(ti + S);
+        unpack_and_issue(dv0, tA);
     }
-    while (ti < t_end) {
+    // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
+    // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
+    // force a full memory wait at the end of every step.
+    auto step = [&](Tile& cur, Tile& nxt) __attribute__((always_inline)) {
         // the current tile's lambda gathers go out first: their LDS latency overlaps the descriptor unpack and the
         // issue of the next tile's loads
         uint32_t row[kSlots];
@@ -114,13 +120,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             row[j] = (uint32_t)cur.r.v[j];
-            lam[j] = (T)1;
-            if (!(g.ablate & 2)) lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+            lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
         }
-        Tile nxt;
-        const uint32_t ti_next = ti + kFusedWaves;
-        unpack_and_issue(dv_next, nxt);
-        dv_next = load_desc(ti_next + kFusedWaves);
+        const uint32_t dv_cur_next = dv_next;
+        dv_next = load_desc(ti + 2u * S);
+        unpack_and_issue(dv_cur_next, nxt);
 
         const uint32_t hi = (cur.w0hi >> 8) & 0x1FF, lo = (cur.w0hi >> 17) & 3;
         const bool is_long = (cur.w0hi & (1u << 19)) != 0;
@@ -135,36 +139,34 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
                 const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
                 const T vj = (T)(t1 + (T)(s * cur.c.v[j]));  // matching.py:66,142
                 v[j] = (e0 + (uint32_t)j < span) ? vj : (T)0;
-                x[j] = v[j];
             }
-            const bool simplex_tile = is_simplex_kind(kind);
-            if (!simplex_tile && !(g.ablate & 4)) {
-#pragma unroll
-                for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
-            }
-            if (simplex_tile && !(g.ablate & 4)) {
+            if (is_simplex_kind(kind)) {
                 uint64_t H[kSlots];
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
                 const Seg4 sg = make_seg4(H);
-                simplex_tile4(v, sg, pj, lc, x, g.ablate);
+                simplex_tile4(v, sg, pj, lc, x);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
             }
             T o32 = (T)0, q32 = (T)0;
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
                 const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
                 const T ax = (T)(cur.a.v[j] * xq);
-                if (ax != (T)0 && !(g.ablate & 1)) scatter_fixed(w.gacc, row[j], ax, w.scale);
+                if (ax != (T)0) scatter_fixed(w.gacc, row[j], ax, w.scale);
                 o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
                 q32 = (T)(q32 + (T)(xq * xq));
                 x[j] = xq;
             }
             obj += (double)o32;
             ssq += (double)q32;
-            if (x_wg) {
+            if (g.x_out) {
+                T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j)
-                    if (e0 + (uint32_t)j < span) x_wg[4 * (cur.q0 + (uint32_t)lane) + j] = x[j];  // neighbours own the rest of the quad
+                    if (e0 + (uint32_t)j < span) xw[4 * (uint32_t)lane + j] = x[j];  // neighbours own the rest of the quad
             }
         } else {
             const FusedArgs<T>& gk = kernarg_args(g);
@@ -173,10 +175,22 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const uint64_t len = ((uint64_t)rl(cur.dv, 3) << 32) | rl(cur.dv, 2);
             process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq);
         }
-        ti = ti_next;
-        cur = nxt;
+        ti += S;
+    };
+    while (ti < n_tiles) {
+        step(tA, tB);
+        if (ti >= n_tiles) break;
+        step(tB, tA);
+    }
+    if (kernarg_args(g).timeline) {
+        __syncthreads();
+        stamp(g, wg, tid, 2);
     }
     fused_epilogue<T, GRAD_LDS>(g, w, obj, ssq, tid, lane, wave, wg);
+    if (kernarg_args(g).timeline) {
+        __syncthreads();
+        stamp(g, wg, tid, 3);
+    }
 }
 
 template <class T, class RowT, bool LAM, bool GRAD>

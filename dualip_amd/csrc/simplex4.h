@@ -141,14 +141,15 @@ __device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
 // Simplex projection of every column of a 256-element tile (see simplex.h for the algorithm and the reference lines).
 //   v must already be 0 in slots that hold no element of the tile (they form dummy segments of zeros);
 //   every slot of x is written.
-// Decisions without a support COUNT where possible: feasible <=> sum over {u > max - z} <= z + 1e-6; vertex <=> that sum
-// equals the maximum exactly (the maximum is the only member); only the remaining columns pay for counting.
+// Two reduction rounds serve almost every tile: MAX (theta_0 = max - z), then SUM and COUNT over {u > theta_0} issued
+// together (two independent dependency chains, one LDS wait).  feasible <=> sum <= z + 1e-6 (simplex.py:153-158);
+// vertex <=> count == 1 (simplex.py:177-193); count == 2 => theta_1 = (sum - z)/2 is final (the runner-up stays above
+// theta_1 exactly when it is above max - z); larger supports run monotone Newton passes that end on a ballot.
 // Few boolean masks are kept alive on purpose: every per-slot flag is an SGPR pair and the kernel is SGPR-starved.
 template <class T>
-__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots],
-                                              int ablate = 0) {
+__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots]) {
     const int el = end_lane4(s, lc);
-    T u[kSlots], th[kSlots], sumA[kSlots], inu[kSlots];
+    T u[kSlots], th[kSlots], sumA[kSlots], cnt[kSlots], inu[kSlots], ind[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) u[j] = relu(v[j]);
     {
@@ -157,65 +158,53 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             th[j] = (T)(v1[j] - pj.z);
-            inu[j] = u[j] > th[j] ? u[j] : (T)0;
+            const bool in = u[j] > th[j];
+            inu[j] = in ? u[j] : (T)0;
+            ind[j] = in ? (T)1 : (T)0;
         }
-        seg_allreduce4(inu, s, el, OpAdd(), sumA);
-        // vertex <=> sumA == max: the maximum is the only member (the comparison is exact: a one-term sum)
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) inu[j] = v1[j];  // keep the maximum in inu until the classification below
     }
-    bool gen[kSlots];
-    bool any_gen = false;
+    seg_allreduce4(inu, s, el, OpAdd(), sumA);
+    seg_allreduce4(ind, s, el, OpAdd(), cnt);
+    bool act[kSlots];
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
-        const bool feas = ineq && !(sumA[j] > pj.ztol);      // simplex.py:153-158: keep the clamped values
-        const bool onehot = !feas && sumA[j] == inu[j];      // simplex.py:177-193: z at the maximum, 0 elsewhere
+        const bool feas = ineq && !(sumA[j] > pj.ztol);   // keep the clamped values
+        const bool onehot = cnt[j] == (T)1;               // z at the maximum, 0 elsewhere (exact z, as the reference)
         const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-        x[j] = onehot ? xv : u[j];
-        gen[j] = !feas && !onehot;
-        any_gen = any_gen || gen[j];
+        const T th1 = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
+        const bool gen = !feas && cnt[j] > (T)1;
+        th[j] = gen ? th1 : th[j];
+        const T xg = relu((T)(u[j] - th[j]));
+        T r = (!feas && onehot) ? xv : u[j];
+        x[j] = gen ? xg : r;
+        act[j] = gen && cnt[j] > (T)2;
     }
-    if (__any(any_gen) && !(ablate & 8)) {
-        // general columns: theta_1 = (sum - z) / |{u > max - z}|.  A support of two is already final: the runner-up
-        // stays above theta_1 exactly when it is above max - z.
-        T ind[kSlots], cnt[kSlots];
-        bool act[kSlots];
+    // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
+    // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.
+    for (int it = 0; it < kTile4; ++it) {
+        bool dropped = false;
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) ind[j] = u[j] > th[j] ? (T)1 : (T)0;
-        seg_allreduce4(ind, s, el, OpAdd(), cnt);
+        for (int j = 0; j < kSlots; ++j) dropped = dropped || (act[j] && ind[j] != (T)0 && !(u[j] > th[j]));
+        if (!__any(dropped)) break;
+        T cnt2[kSlots];
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
-            th[j] = (gen[j] && cnt[j] > (T)0) ? th_new : th[j];
-            act[j] = gen[j] && cnt[j] > (T)2;
+            const bool in = u[j] > th[j];
+            ind[j] = in ? (T)1 : (T)0;
+            inu[j] = in ? u[j] : (T)0;
         }
-        // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
-        // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.
-        for (int it = 0; it < kTile4 && !(ablate & 16); ++it) {
-            bool dropped = false;
+        seg_allreduce4(ind, s, el, OpAdd(), cnt2);
+        seg_allreduce4(inu, s, el, OpAdd(), sumA);
 #pragma unroll
-            for (int j = 0; j < kSlots; ++j) dropped = dropped || (act[j] && ind[j] != (T)0 && !(u[j] > th[j]));
-            if (!__any(dropped)) break;
-            T cnt2[kSlots];
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                ind[j] = u[j] > th[j] ? (T)1 : (T)0;
-                inu[j] = u[j] > th[j] ? u[j] : (T)0;
-            }
-            seg_allreduce4(ind, s, el, OpAdd(), cnt2);
-            seg_allreduce4(inu, s, el, OpAdd(), sumA);
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                const bool changed = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;
-                const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt2[j]);
-                th[j] = changed ? th_new : th[j];
-                cnt[j] = changed ? cnt2[j] : cnt[j];
-                act[j] = changed;
-            }
+        for (int j = 0; j < kSlots; ++j) {
+            const bool changed = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;
+            const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt2[j]);
+            th[j] = changed ? th_new : th[j];
+            cnt[j] = changed ? cnt2[j] : cnt[j];
+            x[j] = changed ? relu((T)(u[j] - th[j])) : x[j];
+            act[j] = changed;
         }
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) x[j] = gen[j] ? relu((T)(u[j] - th[j])) : x[j];
     }
 }
 

@@ -160,6 +160,15 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         _hip.check(self._lib.dl_matching_profile_read(self._handle, ctypes.byref(ms), ctypes.byref(cnt)))
         return int(cnt.value), float(ms.value)
 
+    def timeline(self):
+        """Developer aid (DUALIP_HIP_TIMELINE=1 at construction): uint64[n_wg, 4] 100 MHz stamps of the last fused launch."""
+        import numpy as np
+
+        n_wg = self.info()["workgroups"]
+        out = np.zeros((n_wg, 4), dtype=np.uint64)
+        _hip.check(self._lib.dl_matching_timeline_read(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size))
+        return out
+
     def _primal_buffer(self) -> torch.Tensor:
         if self._primal is None:
             self._primal = torch.empty(self.nnz, dtype=self.dtype, device=self.device)

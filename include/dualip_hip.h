@@ -101,6 +101,10 @@ int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, doub
  * returns the number of launches and their summed duration in milliseconds since the hook was (re-)enabled. */
 int dl_matching_profile(dl_matching* h, int enable);
 int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host);
+/* Developer aid (handles created with DUALIP_HIP_TIMELINE=1 in the environment): per-workgroup 100 MHz wall-clock
+ * stamps of the LAST fused launch, out_host[4*wg + {0,1,2,3}] = start, prologue done, tile loop done, end.
+ * Synchronises the device. */
+int dl_matching_timeline_read(dl_matching* h, uint64_t* out_host, int64_t capacity);
 
 /* The rest of calculate() for the non-distributed objective and for rank 0 of the distributed one
  * (calc_grad matching.py:25-34, slacks :164-178, distributed :280-299):
