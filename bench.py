@@ -50,25 +50,35 @@ def parse():
     ap.add_argument("--cpu-sample-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="take the N>1 code path (distributed objective + all-reduce) even with one rank")
+    ap.add_argument("--emulate-world", type=int, default=0, help="developer aid: with --force-sharded and one rank, hold rank 0's shard of a W-rank run and "
+                    "scale its partial sums by W in place of the all-reduce (per-rank cost of a W-GPU run; the printed value is NOT a result)")
     return ap.parse_args()
 
 
-def projection_map(kind, n_global, lo, hi):
-    """Global map restricted to the local columns [lo, hi): first half box[0,1], second half simplex z=1 (config 4)."""
-    from dualip_amd.projections import create_projection_map
-    from dualip_amd.utils.dist_utils import global_to_local_projection_map
-
+def projection_blocks(kind, n_global, align):
+    """Blocks of the global projection map as (proj_type, params, lo, hi): config 4's "mixed" map is box[0,1] on the
+    first half of the entities and simplex z=1 on the second (the cut sits on a generator-chunk boundary)."""
     if kind == "box":
-        gm = create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n_global, indices=range(n_global))
-    elif kind == "simplex":
-        gm = create_projection_map("simplex", {"z": 1.0}, n_global, indices=range(n_global))
-    else:
-        half = n_global // 2
-        gm = {
-            **create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n_global, indices=range(half)),
-            **create_projection_map("simplex", {"z": 1.0}, n_global, indices=range(half, n_global)),
-        }
-    return global_to_local_projection_map(gm, range(lo, hi))
+        return [("box", {"lower": 0.0, "upper": 1.0}, 0, n_global)]
+    if kind == "simplex":
+        return [("simplex", {"z": 1.0}, 0, n_global)]
+    half = (n_global // 2) // align * align if n_global >= 2 * align else n_global // 2
+    return [("box", {"lower": 0.0, "upper": 1.0}, 0, half), ("simplex", {"z": 1.0}, half, n_global)]
+
+
+def shard_plan(kind, n_global, world, rank, align):
+    """(column ranges of this rank, local projection map): every rank takes its share of EVERY projection block
+    (dualip_amd.utils.dist_utils.balanced_block_ranges), so all ranks carry the same operator mix."""
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.utils.dist_utils import balanced_block_ranges
+
+    ranges, pm, pos = [], {}, 0
+    for ptype, params, lo, hi in projection_blocks(kind, n_global, align):
+        for a, b in balanced_block_ranges([(lo, hi)], world, rank, align):
+            ranges.append((a, b))
+            pm.update(create_projection_map(ptype, params, None, indices=range(pos, pos + (b - a))))
+            pos += b - a
+    return ranges, pm
 
 
 def cpu_baseline(args, inp, pm_local, total_nnz):
@@ -139,23 +149,20 @@ def main():
 
     n, m = args.entities, args.destinations
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    # contiguous, chunk-aligned column ranges (every rank builds its own shard of the SAME global problem)
-    chunks = (n + CHUNK_COLS - 1) // CHUNK_COLS
-    per = [chunks // world + (1 if r < chunks % world else 0) for r in range(world)]
-    lo = min(n, sum(per[:rank]) * CHUNK_COLS)
-    hi = min(n, lo + per[rank] * CHUNK_COLS)
+    # chunk-aligned column ranges: this rank's share of every projection block of the SAME global problem
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1 and sharded) else 0
+    ranges, pm_local = shard_plan(args.proj, n, emu or world, rank, CHUNK_COLS)
 
     def reduce_loads(v):
         if sharded:
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        return v
+        return v * float(emu) if emu else v
 
     t_gen = time.perf_counter()
-    prob = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_range=(lo, hi), reduce_loads=reduce_loads)
+    prob = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_ranges=ranges, reduce_loads=reduce_loads)
     inp = prob["input_args"]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    pm_local = projection_map(args.proj, n, lo, hi)
     inp.projection_map = pm_local
     nnz_local = prob["nnz"]
     nnz_t = torch.tensor([nnz_local], dtype=torch.float64, device=device)
@@ -169,6 +176,9 @@ def main():
         inp.b_vec = None
         f = MatchingSolverDualObjectiveFunctionDistributed(inp, b_vec, args.gamma, host_device=device)
         local = f.local_objective
+        if emu:
+            real_exchange = f._exchange
+            f._exchange = lambda packed: real_exchange(packed).mul_(float(emu))
     else:
         f = MatchingSolverDualObjectiveFunction(inp, args.gamma)
         local = f
@@ -204,7 +214,7 @@ def main():
     run.close()
 
     vs = 4 if args.dtype == "f32" else 8
-    alg_bytes = nnz_local * (2 * vs + 4) + (hi - lo) * 4 + 4 * m * vs  # a, c, 32-bit row per nnz; colptr; lambda/grad/b/y
+    alg_bytes = nnz_local * (2 * vs + 4) + prob["n_local"] * 4 + 4 * m * vs  # a, c, 32-bit row per nnz; colptr; lambda/grad/b/y
     avg_kernel_s = (kernel_ms / max(launches, 1)) * 1e-3
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     traffic = None

@@ -15,7 +15,7 @@ range of the SAME global problem; only the m-sized greedy loads need one all-red
 import numpy as np
 import torch
 
-CHUNK_COLS = 500_000
+CHUNK_COLS = 250_000
 
 
 def _dest_params(num_destinations, target_sparsity, seed):
@@ -52,17 +52,23 @@ def _chunk(c0, c1, m, p_cdf, p_total, s_t, v_t, seed, device):
     return counts, dest.to(torch.int32), a, -c, loads
 
 
-def generate_matching_problem(num_sources, num_destinations, target_sparsity, seed=42, device="cuda:0", dtype=torch.float32, col_range=None, reduce_loads=None):
+def generate_matching_problem(num_sources, num_destinations, target_sparsity, seed=42, device="cuda:0", dtype=torch.float32, col_range=None, reduce_loads=None,
+                              col_ranges=None):
     """Build the (shard of the) synthetic problem on ``device``.
 
     col_range=(lo, hi): generate only these global columns (both multiples of CHUNK_COLS or the ends).
+    col_ranges=[(lo, hi), ...]: several such ranges, concatenated in the given order (a shard that takes its share of
+    every projection block).
     reduce_loads: callable applied to the float64[m] greedy-load vector before b is formed (pass an all-reduce when
     sharded).  Returns dict(input_args=MatchingInputArgs(projection_map=None -- set by the caller), nnz, m, n_local).
     """
     from dualip_amd.objectives.matching import MatchingInputArgs
 
     m = int(num_destinations)
-    lo, hi = (0, int(num_sources)) if col_range is None else (int(col_range[0]), int(col_range[1]))
+    if col_ranges is None:
+        col_ranges = [(0, int(num_sources)) if col_range is None else (int(col_range[0]), int(col_range[1]))]
+    col_ranges = [(int(a), int(b)) for a, b in col_ranges if int(b) > int(a)]
+    n_local = sum(b - a for a, b in col_ranges)
     p, s, v, rho = _dest_params(m, target_sparsity, seed)
     p_t = torch.from_numpy(p).to(device)
     p_cdf = torch.cumsum(p_t / p_t.sum(), 0)
@@ -70,20 +76,21 @@ def generate_matching_problem(num_sources, num_destinations, target_sparsity, se
     v_t = torch.from_numpy(v).to(device=device, dtype=torch.float32)
     counts, rows, a_parts, c_parts = [], [], [], []
     loads = torch.zeros(m, device=device, dtype=torch.float64)
-    c0 = lo
-    while c0 < hi:
-        c1 = min(hi, (c0 // CHUNK_COLS + 1) * CHUNK_COLS)
-        cnt, r, a, c, ld = _chunk(c0, c1, m, p_cdf, float(p.sum()), s_t, v_t, seed, device)
-        counts.append(cnt)
-        rows.append(r)
-        a_parts.append(a)
-        c_parts.append(c)
-        loads += ld
-        c0 = c1
+    for lo, hi in col_ranges:
+        c0 = lo
+        while c0 < hi:
+            c1 = min(hi, (c0 // CHUNK_COLS + 1) * CHUNK_COLS)
+            cnt, r, a, c, ld = _chunk(c0, c1, m, p_cdf, float(p.sum()), s_t, v_t, seed, device)
+            counts.append(cnt)
+            rows.append(r)
+            a_parts.append(a)
+            c_parts.append(c)
+            loads += ld
+            c0 = c1
     counts = torch.cat(counts) if counts else torch.zeros(0, dtype=torch.int64, device=device)
     nnz = int(counts.sum())
     idx_dtype = torch.int32 if nnz < 2**31 - 1 else torch.int64
-    colptr = torch.zeros(hi - lo + 1, dtype=idx_dtype, device=device)
+    colptr = torch.zeros(n_local + 1, dtype=idx_dtype, device=device)
     colptr[1:] = torch.cumsum(counts, 0).to(idx_dtype)
     del counts
     rowidx = torch.cat(rows).to(idx_dtype) if rows else torch.zeros(0, dtype=idx_dtype, device=device)
@@ -95,7 +102,7 @@ def generate_matching_problem(num_sources, num_destinations, target_sparsity, se
     if reduce_loads is not None:
         loads = reduce_loads(loads)
     b = (torch.from_numpy(rho).to(device) * (loads + 1e-8)).to(dtype)
-    A = torch.sparse_csc_tensor(colptr, rowidx, a_vals, size=(m, hi - lo), check_invariants=False)
-    C = torch.sparse_csc_tensor(colptr, rowidx, c_vals, size=(m, hi - lo), check_invariants=False)
+    A = torch.sparse_csc_tensor(colptr, rowidx, a_vals, size=(m, n_local), check_invariants=False)
+    C = torch.sparse_csc_tensor(colptr, rowidx, c_vals, size=(m, n_local), check_invariants=False)
     args = MatchingInputArgs(A=A, c=C, projection_map=None, b_vec=b, equality_mask=None)
-    return dict(input_args=args, nnz=nnz, m=m, n_local=hi - lo)
+    return dict(input_args=args, nnz=nnz, m=m, n_local=n_local)

@@ -2,6 +2,7 @@
 // Lipschitz-history step size (device resident, no host round trip), dense-block projection operator and
 // Jacobi row scaling.
 #include "common.h"
+#include <algorithm>
 #include <cstring>
 #include "wave.h"
 
@@ -122,8 +123,20 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     double ax = 0.0;
     if constexpr (FROM_SLABS) {
         long long acc = 0;
-        if (row < p.m)
-            for (int w = ws; w < p.n_slabs; w += kStatSlices) acc += p.partial[(int64_t)w * p.mpad + row];
+        {   // latency bound: eight slabs in flight before the first is added (slabs past the end re-read the last one)
+            const int64_t rc = row < p.m ? row : p.m - 1;
+            constexpr int kU = 8;
+            for (int w0 = ws; w0 < p.n_slabs; w0 += kStatSlices * kU) {
+                long long v[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int w = w0 + kStatSlices * u;
+                    v[u] = p.partial[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) acc += (w0 + kStatSlices * u < p.n_slabs) ? v[u] : 0ll;
+            }
+        }
         shi[tid] = acc;
         __syncthreads();
         if (ws == 0 && row < p.m) {
@@ -169,8 +182,7 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
             o[5] = dy2;
         }
     }
-    if (FROM_SLABS && blockIdx.x == 0) {  // scalar partial sums of the fused pass: c.x and sum x^2
-        __syncthreads();
+    if (FROM_SLABS && blockIdx.x + 1 == gridDim.x) {  // the extra last block: scalar partial sums of the fused pass (c.x, sum x^2)
         double o = 0.0, q = 0.0;
         for (int w = tid; w < p.n_scal; w += kStatRows * kStatSlices) {
             o += p.partial_scal[2 * w];
@@ -196,104 +208,148 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     }
 }
 
+// ---- finalize + update in one launch ----
+// Every workgroup derives the SAME scalars (objective pieces, Lipschitz estimate, step) from the stats partials, in the
+// same order, then updates its own 1024 rows.  (Letting every workgroup recompute the statistics from the reduced A x
+// instead -- no stats launch on the sharded route -- measured 22 us against 4.3 + 7.5 us for the two launches.)  The optimizer state is double buffered: all workgroups read st_in,
+// workgroup 0 writes st_out.
+constexpr int kApplyThreads = 1024;
+
 template <class T>
-struct FinalizeArgs {
+struct ApplyArgs {
     int64_t m;
-    const double* __restrict__ scal;           // &packed[m]: c.x, sum x^2
-    const double* __restrict__ partial_stats;  // [n_blocks][kStatCols]
+    const double* __restrict__ partial_stats;  // [n_blocks][kStatCols], from the stats launch
     int n_blocks;
-    AgdDevState* st;
+    const T* __restrict__ g_new;               // gradient written by the stats launch
+    const double* __restrict__ scal;           // c.x, sum x^2
+    const AgdDevState* st_in;
+    AgdDevState* st_out;
     double* __restrict__ log_row;
     double gamma;
     int decay_now;
     double decay_factor;
+    // update
+    const T* __restrict__ x;
+    T* __restrict__ x_next;
+    const T* __restrict__ y;
+    T* __restrict__ y_new;
+    const uint8_t* __restrict__ eq_mask;
+    const float* __restrict__ beta;
+    int64_t iter;
 };
 
 template <class T>
-__global__ __launch_bounds__(64) void agd_finalize_kernel(FinalizeArgs<T> p) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(kApplyThreads) void agd_apply_kernel(ApplyArgs<T> p) {
+    const int tid = threadIdx.x;
+    const AgdDevState& si = *p.st_in;
+    const bool has_prev = si.steps_done > 0;
+    const double ring = si.lips[(tid & 63) < kLipsMax ? (tid & 63) : kLipsMax - 1];  // Lipschitz history, one entry per lane
     double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
-    for (int k = lane; k < p.n_blocks; k += 64) {  // fixed order: bit-reproducible
-        const double* o = p.partial_stats + (int64_t)k * kStatCols;
-        dvtg += o[0];
-        gmax = o[1] > gmax ? o[1] : gmax;
-        spos += o[2];
-        g2 += o[3];
-        dg2 += o[4];
-        dy2 += o[5];
+    T g_mine = (T)0;  // gradient of this thread's own row
+    const int64_t mine = (int64_t)blockIdx.x * kApplyThreads + tid;
+    {
+        // every wavefront sums the partials in the same fixed order (no LDS, no barrier); four rows per lane are loaded
+        // before the first is used -- the launch is latency bound
+        constexpr int kU = 4;
+        for (int k0 = tid & 63; k0 < p.n_blocks; k0 += 64 * kU) {
+            double o[kU][kStatCols];
+            bool in[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int k = k0 + 64 * u;
+                in[u] = k < p.n_blocks;
+                const double* src = p.partial_stats + (int64_t)(in[u] ? k : p.n_blocks - 1) * kStatCols;
+#pragma unroll
+                for (int c = 0; c < kStatCols; ++c) o[u][c] = src[c];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                dvtg += in[u] ? o[u][0] : 0.0;
+                gmax = (in[u] && o[u][1] > gmax) ? o[u][1] : gmax;
+                spos += in[u] ? o[u][2] : 0.0;
+                g2 += in[u] ? o[u][3] : 0.0;
+                dg2 += in[u] ? o[u][4] : 0.0;
+                dy2 += in[u] ? o[u][5] : 0.0;
+            }
+        }
+        dvtg = wave_allreduce(dvtg, OpAdd());
+        gmax = wave_allreduce(gmax, OpMax());
+        spos = wave_allreduce(spos, OpAdd());
+        g2 = wave_allreduce(g2, OpAdd());
+        dg2 = wave_allreduce(dg2, OpAdd());
+        dy2 = wave_allreduce(dy2, OpAdd());
+        if (mine < p.m) g_mine = p.g_new[mine];  // written by the stats launch
     }
-    dvtg = wave_allreduce(dvtg, OpAdd());
-    gmax = wave_allreduce(gmax, OpMax());
-    spos = wave_allreduce(spos, OpAdd());
-    g2 = wave_allreduce(g2, OpAdd());
-    dg2 = wave_allreduce(dg2, OpAdd());
-    dy2 = wave_allreduce(dy2, OpAdd());
-    if (lane != 0) return;
-    AgdDevState& st = *p.st;
-    const bool has_prev = st.steps_done > 0;
-    const T nrm = (T)sqrt(p.scal[1]);
-    const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));  // (gamma/2) * norm(x)**2, matching.py:157
-    const T obj0 = (T)p.scal[0];
-    const T dv = (T)dvtg;
-    const T obj = (T)((T)(obj0 + reg) + dv);                 // matching.py:33
     // ---- calculate_step_size (agd_utils.py:65-89) ----
+    // The Lipschitz ring lives one entry per lane (loaded at the top of the kernel): no serial walk over global memory.
+    int n_lips = si.n_lips, head = si.head, slot = -1;
+    double L = 0.0;
     if (has_prev) {
         const T num = (T)sqrt(dg2), den = (T)sqrt(dy2);
-        const T L = (T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
-        if (st.n_lips == kLipsMax) {
-            st.lips[st.head] = (double)L;  // overwrite the oldest
-            st.head = (st.head + 1) % kLipsMax;
+        L = (double)(T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
+        if (n_lips == kLipsMax) {
+            slot = head;  // overwrite the oldest
+            head = (head + 1) % kLipsMax;
         } else {
-            st.lips[(st.head + st.n_lips) % kLipsMax] = (double)L;
-            st.n_lips += 1;
+            slot = (head + n_lips) % kLipsMax;
+            n_lips += 1;
         }
     }
+    const int lane = tid & 63;
+    const double ring_new = lane == slot ? L : ring;  // lanes >= kLipsMax carry padding
     double step;
-    if (st.n_lips < kLipsMax) {
-        step = st.initial_step;  // incomplete history (agd_utils.py:57-58)
+    if (n_lips < kLipsMax) {
+        step = si.initial_step;  // incomplete history (agd_utils.py:57-58)
     } else {
-        // builtins.max over the list, oldest first: a NaN is only kept when it comes first
-        double lmax = st.lips[st.head];
-        for (int q = 1; q < kLipsMax; ++q) {
-            const double v = st.lips[(st.head + q) % kLipsMax];
-            if (v > lmax) lmax = v;
-        }
-        if (isnan(lmax) || isinf(lmax)) step = st.initial_step;
+        // builtins.max over the list, oldest first: NaN if the oldest entry is NaN, else the maximum of the non-NaN entries
+        const double first = bperm(head, ring_new);
+        const double cand_l = (lane < kLipsMax && !isnan(ring_new)) ? ring_new : -INFINITY;
+        const double mx = wave_allreduce(cand_l, OpMax());
+        const double lmax = isnan(first) ? first : mx;
+        if (isnan(lmax) || isinf(lmax)) step = si.initial_step;
         else {
-            const double cand = lmax != 0.0 ? 1.0 / lmax : st.max_step;
-            step = cand < st.max_step ? cand : st.max_step;
+            const double cand = lmax != 0.0 ? 1.0 / lmax : si.max_step;
+            step = cand < si.max_step ? cand : si.max_step;
         }
     }
-    st.last_step = step;
-    if (p.decay_now) st.max_step = step * p.decay_factor;  // agd.py:106-107
-    st.steps_done += 1;
-    if (p.log_row) {
-        p.log_row[0] = (double)obj;
-        p.log_row[1] = step;
-        p.log_row[2] = (double)reg;
-        p.log_row[3] = (double)dv;
-        p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;  // builtins.max(max(grad), 0), matching.py:168
-        p.log_row[5] = (double)(T)spos;
-        p.log_row[6] = (double)(T)sqrt(g2);
-        p.log_row[7] = (double)obj0;
+    if (blockIdx.x == 0 && tid < kLipsMax) p.st_out->lips[tid] = ring_new;
+    if (blockIdx.x == 0 && tid == 0) {
+        AgdDevState& so = *p.st_out;
+        so.initial_step = si.initial_step;
+        so.max_step = p.decay_now ? step * p.decay_factor : si.max_step;  // agd.py:106-107
+        so.last_step = step;
+        so.n_lips = n_lips;
+        so.head = head;
+        so.steps_done = si.steps_done + 1;
+        if (p.log_row) {
+            const T nrm = (T)sqrt(p.scal[1]);
+            const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));  // (gamma/2) * norm(x)**2, matching.py:157
+            const T obj0 = (T)p.scal[0];
+            const T dv = (T)dvtg;
+            const T obj = (T)((T)(obj0 + reg) + dv);                 // matching.py:33
+            p.log_row[0] = (double)obj;
+            p.log_row[1] = step;
+            p.log_row[2] = (double)reg;
+            p.log_row[3] = (double)dv;
+            p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;  // builtins.max(max(grad), 0), matching.py:168
+            p.log_row[5] = (double)(T)spos;
+            p.log_row[6] = (double)(T)sqrt(g2);
+            p.log_row[7] = (double)obj0;
+        }
     }
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void agd_update_kernel(int64_t m, T* __restrict__ x, const T* __restrict__ y, T* __restrict__ y_new, const T* __restrict__ g,
-                                                         const uint8_t* __restrict__ eq_mask, const float* __restrict__ beta, const AgdDevState* st,
-                                                         int64_t iter) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const T stp = (T)st->last_step;
-    const float bt = beta[iter - 1];
-    const T b = (T)bt;
-    const T omb = (T)(float)(1.0f - bt);  // 1.0 - fp32 0-dim tensor stays fp32 (agd.py:184)
-    T yn = (T)(x[j] + (T)(g[j] * stp));                         // agd.py:181
-    const bool eq = eq_mask && eq_mask[j];
-    if (!eq) yn = yn > (T)0 ? yn : (T)0;                        // project_on_nn_cone, agd.py:13-21
-    x[j] = (T)((T)(yn * omb) + (T)(y[j] * b));                  // agd.py:184
-    y_new[j] = yn;
+    // ---- projected ascent step + momentum (agd.py:181-184) ----
+    if (mine < p.m) {
+        const T stp = (T)step;
+        const float bt = p.beta[p.iter - 1];
+        const T bb = (T)bt;
+        const T omb = (T)(float)(1.0f - bt);  // 1.0 - fp32 0-dim tensor stays fp32 (agd.py:184)
+        T yn = (T)(p.x[mine] + (T)(g_mine * stp));                  // agd.py:181
+        const bool eq = p.eq_mask && p.eq_mask[mine];
+        if (!eq) yn = yn > (T)0 ? yn : (T)0;                         // project_on_nn_cone, agd.py:13-21
+        const T xn = (T)((T)(yn * omb) + (T)(p.y[mine] * bb));       // agd.py:184
+        p.y_new[mine] = yn;
+        p.x_next[mine] = xn;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -406,7 +462,7 @@ int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* 
     return 0;
 }
 
-size_t agd_state_bytes() { return sizeof(AgdDevState); }
+size_t agd_state_bytes() { return 2 * sizeof(AgdDevState); }  // double buffered
 
 int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st) {
     AgdDevState h;
@@ -415,13 +471,14 @@ int agd_state_init(void* dev_state, double initial_step, double max_step, hipStr
     h.initial_step = initial_step;
     h.last_step = initial_step;
     DL_HIP(hipMemcpyAsync(dev_state, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    DL_HIP(hipMemcpyAsync((AgdDevState*)dev_state + 1, &h, sizeof(h), hipMemcpyHostToDevice, st));
     DL_HIP(hipStreamSynchronize(st));  // h is a stack object
     return 0;
 }
 
-int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st) {
+int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t st) {
     AgdDevState h;
-    DL_HIP(hipMemcpyAsync(&h, dev_state, sizeof(h), hipMemcpyDeviceToHost, st));
+    DL_HIP(hipMemcpyAsync(&h, (AgdDevState*)dev_state + cur, sizeof(h), hipMemcpyDeviceToHost, st));
     DL_HIP(hipStreamSynchronize(st));
     *out = h.max_step;
     return 0;
@@ -431,50 +488,58 @@ template <class T>
 static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
                           double decay_factor, hipStream_t st) {
     const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
-    StatsArgs<T> sa;
-    sa.m = s->m;
-    sa.partial = f ? static_cast<const long long*>(f->partial) : nullptr;
-    sa.partial_scal = f ? f->partial_scal : nullptr;
-    sa.shift_in = f ? f->shift_dev : nullptr;
-    sa.n_slabs = f ? (f->grad_lds ? f->n_wg : 1) : 0;
-    sa.n_scal = f ? f->n_wg : 0;
-    sa.mpad = f ? f->mpad : 0;
-    sa.packed_in = packed;
-    sa.packed_out = s->packed;
-    sa.b = (const T*)b;
-    sa.x = (const T*)s->x;
-    sa.y = (const T*)s->y;
-    sa.y_prev = (const T*)s->y_old;
-    sa.g_old = (const T*)s->g;
-    sa.g_new = (T*)s->g_old;
-    sa.st = (const AgdDevState*)s->state;
-    sa.partial_stats = s->partial_stats;
+    AgdDevState* states = (AgdDevState*)s->state;
+    const AgdDevState* st_in = states + s->state_cur;
+    AgdDevState* st_out = states + (s->state_cur ^ 1);
     if (n_blocks > 0) {
-        if (f) hipLaunchKernelGGL((agd_stats_kernel<T, true>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
+        StatsArgs<T> sa;
+        sa.m = s->m;
+        sa.partial = f ? static_cast<const long long*>(f->partial) : nullptr;
+        sa.partial_scal = f ? f->partial_scal : nullptr;
+        sa.shift_in = f ? f->shift_dev : nullptr;
+        sa.n_slabs = f ? (f->grad_lds ? f->n_wg : 1) : 0;
+        sa.n_scal = f ? f->n_wg : 0;
+        sa.mpad = f ? f->mpad : 0;
+        sa.packed_in = packed;
+        sa.packed_out = s->packed;
+        sa.b = (const T*)b;
+        sa.x = (const T*)s->x;
+        sa.y = (const T*)s->y;
+        sa.y_prev = (const T*)s->y_old;
+        sa.g_old = (const T*)s->g;
+        sa.g_new = (T*)s->g_old;
+        sa.st = st_in;
+        sa.partial_stats = s->partial_stats;
+        if (f) hipLaunchKernelGGL((agd_stats_kernel<T, true>), dim3(n_blocks + 1), dim3(kStatRows * kStatSlices), 0, st, sa);  // + the scalar-sum block
         else hipLaunchKernelGGL((agd_stats_kernel<T, false>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
     }
-    FinalizeArgs<T> fa;
-    fa.m = s->m;
-    fa.scal = (f ? s->packed : packed) + s->m;
-    fa.partial_stats = s->partial_stats;
-    fa.n_blocks = n_blocks;
-    fa.st = (AgdDevState*)s->state;
-    fa.log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
-    fa.gamma = gamma;
-    fa.decay_now = decay_now;
-    fa.decay_factor = decay_factor;
-    hipLaunchKernelGGL(agd_finalize_kernel<T>, dim3(1), dim3(64), 0, st, fa);
-    if (s->m > 0)
-        hipLaunchKernelGGL(agd_update_kernel<T>, dim3((unsigned)((s->m + 255) / 256)), dim3(256), 0, st, s->m, (T*)s->x, (const T*)s->y, (T*)s->y_old,
-                           (const T*)s->g_old, s->eq_mask, s->beta, (const AgdDevState*)s->state, iter);
+    ApplyArgs<T> aa;
+    aa.m = s->m;
+    aa.partial_stats = s->partial_stats;
+    aa.n_blocks = n_blocks;
+    aa.g_new = (const T*)s->g_old;
+    aa.scal = (f ? s->packed : packed) + s->m;
+    aa.st_in = st_in;
+    aa.st_out = st_out;
+    aa.log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
+    aa.gamma = gamma;
+    aa.decay_now = decay_now;
+    aa.decay_factor = decay_factor;
+    aa.x = (const T*)s->x;
+    aa.x_next = (T*)s->x_alt;
+    aa.y = (const T*)s->y;
+    aa.y_new = (T*)s->y_old;
+    aa.eq_mask = s->eq_mask;
+    aa.beta = s->beta;
+    aa.iter = iter;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, (s->m + kApplyThreads - 1) / kApplyThreads);
+    hipLaunchKernelGGL(agd_apply_kernel<T>, dim3(grid), dim3(kApplyThreads), 0, st, aa);
     DL_HIP(hipGetLastError());
-    // rotate: the buffer that received y_i becomes y; the old y becomes the "previous history dual"
-    void* t = s->y;
-    s->y = s->y_old;
-    s->y_old = t;
-    t = s->g;
-    s->g = s->g_old;
-    s->g_old = t;
+    // rotate: the buffer that received y_i becomes y; the old y becomes the "previous history dual"; likewise x, g, state
+    std::swap(s->y, s->y_old);
+    std::swap(s->g, s->g_old);
+    std::swap(s->x, s->x_alt);
+    s->state_cur ^= 1;
     return 0;
 }
 

@@ -39,7 +39,7 @@ int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* 
                     double* scal_out, hipStream_t st);
 size_t agd_state_bytes();
 int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st);
-int agd_state_read_max_step(void* dev_state, double* out, hipStream_t st);
+int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t st);
 int launch_agd_step(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
                     double decay_factor, hipStream_t st);
 size_t agd_partial_stats_bytes(int64_t m);
@@ -602,7 +602,7 @@ int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void*
 // ---------------------------------------------------------------------------------------------------------
 static void agd_free(dl_agd* s) {
     if (!s) return;
-    void* ptrs[] = {s->x, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats};
+    void* ptrs[] = {s->x, s->x_alt, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -624,7 +624,7 @@ int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, cons
     const size_t vs = val_dtype == DL_F32 ? 4 : 8;
     const size_t vb = (size_t)(m > 0 ? m : 1) * vs;
     hipError_t e = hipSuccess;
-    void** vecs[] = {&s->x, &s->y, &s->y_old, &s->g, &s->g_old};
+    void** vecs[] = {&s->x, &s->x_alt, &s->y, &s->y_old, &s->g, &s->g_old};
     for (void** v : vecs)
         if (e == hipSuccess) e = hipMalloc(v, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&s->beta, sizeof(float) * (size_t)(max_iter > 0 ? max_iter : 1));
@@ -707,7 +707,7 @@ int dl_agd_read_log(dl_agd* s, int64_t first, int64_t count, double* rows_host, 
 
 int dl_agd_read_max_step(dl_agd* s, double* out_host, dl_stream_t stream) {
     if (!s || !out_host) return fail(DL_E_ARG, "null argument");
-    return agd_state_read_max_step(s->state, out_host, (hipStream_t)stream);
+    return agd_state_read_max_step(s->state, s->state_cur, out_host, (hipStream_t)stream);
 }
 
 int dl_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* proj_host, dl_stream_t stream) {

@@ -110,7 +110,9 @@ struct dl_agd {
     const uint8_t* eq_mask = nullptr;  // caller-owned
     float* beta = nullptr;   // owned, float[max_iter]
     double* log = nullptr;   // owned, [max_iter][kLogCols]
-    void* state = nullptr;   // owned, dl::AgdDevState
+    void* state = nullptr;   // owned, two dl::AgdDevState (double buffered)
+    int state_cur = 0;
+    void* x_alt = nullptr;   // owned: the buffer the next iterate is written to
     double* packed = nullptr;  // owned scratch double[m+2] for dl_agd_run_matching
     double* partial_stats = nullptr;  // owned: per-workgroup partial reductions of the step kernel
 };

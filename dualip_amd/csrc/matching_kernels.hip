@@ -266,22 +266,34 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
     __shared__ long long shi[kRedThreads];
     __shared__ double sh[kRedThreads / 32];
     const int tid = threadIdx.x;
-    const int rl = tid & (kRedRows - 1);
-    const int ws = tid / kRedRows;
-    const int64_t row = (int64_t)blockIdx.x * kRedRows + rl;
-    long long acc = 0;
-    if (row < m) {
-        for (int w = ws; w < n_slabs; w += kRedThreads / kRedRows) acc += partial[(int64_t)w * mpad + row];
-    }
-    shi[tid] = acc;
-    __syncthreads();
-    if (ws == 0 && row < m) {
-        long long t = shi[rl];
-        for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
-        packed[row] = ldexp((double)t, -(*shift_in));
-    }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x + 1 < gridDim.x) {  // row blocks; the LAST block only sums the scalar partials (runs beside them)
+        const int rl = tid & (kRedRows - 1);
+        const int ws = tid / kRedRows;
+        const int64_t row = (int64_t)blockIdx.x * kRedRows + rl;
+        const int64_t rc = row < m ? row : (m > 0 ? m - 1 : 0);
+        long long acc = 0;
+        // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
+        constexpr int kU = 8, kStride = kRedThreads / kRedRows;
+        for (int w0 = ws; w0 < n_slabs; w0 += kStride * kU) {
+            long long v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int w = w0 + kStride * u;
+                v[u] = partial[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
+        }
+        shi[tid] = acc;
         __syncthreads();
+        if (ws == 0 && row < m) {
+            long long t = shi[rl];
+            for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
+            packed[row] = ldexp((double)t, -(*shift_in));
+        }
+        return;
+    }
+    {
         double o = 0.0, q = 0.0;
         for (int w = tid; w < n_scal; w += kRedThreads) {
             o += partial_scal[2 * w];
@@ -435,7 +447,7 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     if (rc) return rc;
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks > 0 ? blocks : 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
                        h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out);
     DL_HIP(hipGetLastError());
     return 0;

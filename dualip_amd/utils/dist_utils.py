@@ -17,6 +17,26 @@ def balanced_split_sizes(num_cols: int, num_parts: int) -> List[int]:
     return [base + (1 if i < extra else 0) for i in range(num_parts)]
 
 
+def balanced_block_ranges(blocks: Sequence[Tuple[int, int]], num_parts: int, part: int, align: int = 1) -> List[Tuple[int, int]]:
+    """Column ranges of shard ``part`` when every block ``(lo, hi)`` of columns is split evenly over the shards.
+
+    A projection map made of a few large blocks with different operators (say box on one half of the entities and simplex
+    on the other) is badly served by the reference's contiguous split (dist_utils.py:49-62): some ranks would hold only the
+    cheap operator, others only the expensive one, and every iteration waits for the slowest.  Giving each rank its share of
+    EVERY block equalises the work; columns are independent given the dual vector, so any partition yields the same sums.
+    ``align`` keeps the cut points on multiples of a chunk size (relative to each block's start)."""
+    out = []
+    for lo, hi in blocks:
+        units = -(-(hi - lo) // align)
+        sizes = balanced_split_sizes(units, num_parts)
+        u0 = sum(sizes[:part])
+        a = min(hi, lo + u0 * align)
+        b = min(hi, a + sizes[part] * align)
+        if b > a:
+            out.append((a, b))
+    return out
+
+
 def _as_plain(indices):
     if isinstance(indices, range) and len(indices) <= _LIST_LIMIT:
         return list(indices)

@@ -192,3 +192,26 @@ def test_run_solver_rejects_unknown_objective():
 
     with pytest.raises(ValueError, match="not supported"):
         build_objective(None, SolverArgs(), ComputeArgs(host_device="cpu"), ObjectiveArgs(objective_type="other"))
+
+
+def test_balanced_block_ranges_cover_every_block_evenly():
+    from dualip_amd.utils.dist_utils import balanced_block_ranges
+
+    blocks = [(0, 1000), (1000, 2600)]
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            rs = balanced_block_ranges(blocks, world, r, align=100)
+            for a, b in rs:
+                assert a % 100 == 0 and (b % 100 == 0 or b in (1000, 2600))
+            seen.append(rs)
+            # every rank holds a share of both blocks (10 and 16 units of 100 over <= 8 ranks)
+            assert any(a < 1000 for a, _ in rs) and any(a >= 1000 for a, _ in rs)
+        cols = sorted(c for rs in seen for a, b in rs for c in range(a, b))
+        assert cols == list(range(2600))
+        per_block = [[sum(b - a for a, b in rs if lo <= a < hi) for rs in seen] for lo, hi in blocks]
+        for sizes in per_block:
+            assert max(sizes) - min(sizes) <= 100
+    # unaligned tail and more parts than units
+    rs = [balanced_block_ranges([(0, 250)], 4, r, align=100) for r in range(4)]
+    assert sorted(c for x in rs for a, b in x for c in range(a, b)) == list(range(250))

@@ -10,15 +10,16 @@ import numpy as np
 import torch
 
 import bench
-from benchmark.synthetic import generate_matching_problem
+from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
 from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 proj = sys.argv[2] if len(sys.argv) > 2 else "mixed"
 dev = torch.device("cuda:0")
-prob = generate_matching_problem(n, 10_000, 1e-3, seed=42, device=dev, dtype=torch.float32)
+ranges, pm = bench.shard_plan(proj, n, 1, 0, CHUNK_COLS)
+prob = generate_matching_problem(n, 10_000, 1e-3, seed=42, device=dev, dtype=torch.float32, col_ranges=ranges)
 inp = prob["input_args"]
-inp.projection_map = bench.projection_map(proj, n, 0, n)
+inp.projection_map = pm
 f = MatchingSolverDualObjectiveFunction(inp, 1e-3)
 from dualip_amd.optimizers.agd import AcceleratedGradientDescent
 
