@@ -55,6 +55,11 @@ _SIGNATURES = {
     "dl_agd_read_max_step": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), _c_vp]),
     "dl_project_dense": (_c_int, [_c_i64, _c_i64, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_vp]),
     "dl_jacobi_precondition": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
+    "dl_lp_create": (_c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int]),
+    "dl_lp_destroy": (_c_int, [_c_vp]),
+    "dl_lp_calculate": (_c_int, [_c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),
+    "dl_lp_primal": (_c_int, [_c_vp, _c_vp, _c_dbl, _c_int, _c_vp, _c_vp]),
+    "dl_lp_gradient": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp]),
 }
 
 _lib = None

@@ -203,11 +203,14 @@ class DeviceRun:
         self.solver, self.f, self.rank = solver, f, rank
         self.lib = _hip.load()
         self.sharded = hasattr(f, "local_objective")
+        # objectives that hand over a packed [A x | c.x | sum x^2] buffer per iteration: the sharded matching objective
+        # (after its all-reduce) and the generic-LP objective; the single-device matching objective runs wholly inside C
+        self.packed_route = self.sharded or bool(getattr(f, "_dualip_packed", False))
         self.local = f.local_objective if self.sharded else f
         if not self.sharded and f.b_vec is None:
             raise ValueError("a matching objective built with b_vec=None only provides local partial sums; wrap it in the distributed objective")
         self.device, self.dtype, self.m = self.local.device, self.local.dtype, self.local.m
-        self.b_vec = f.b_vec
+        self.b_vec = getattr(f, "b_step", f.b_vec)  # (row-normalised b for a Jacobi-preconditioned LP objective)
         self.max_iter = solver.max_iter
         if solver.save_primal and self.sharded:
             raise NotImplementedError("save_primal=True is not yet supported in distributed mode")
@@ -252,7 +255,7 @@ class DeviceRun:
         with torch.cuda.device(self.device):
             stream = _hip.stream_ptr(self.device)
             last = self.done + n == self.max_iter
-            if not self.sharded:
+            if not self.packed_route:
                 _hip.check(
                     lib.dl_agd_run_matching(
                         self.state, self.local._handle, _hip.ptr(self.b_vec), self.done + 1, n, ctypes.byref(self.gamma), self.decay_steps,
@@ -262,7 +265,8 @@ class DeviceRun:
             else:
                 for it in range(self.done + 1, self.done + n + 1):
                     if hasattr(self.f, "calculate_packed_ptr"):
-                        packed = self.f.calculate_packed_ptr(int(lib.dl_agd_x(self.state)), self.gamma.value)  # local pass + ONE sum-all-reduce
+                        extra = {"x_out": self.primal} if (self.primal is not None and it == self.max_iter and not self.sharded) else {}
+                        packed = self.f.calculate_packed_ptr(int(lib.dl_agd_x(self.state)), self.gamma.value, **extra)  # local pass [+ ONE sum-all-reduce]
                     else:
                         self._x_dev = self._fetch(0, out=self._x_dev)
                         packed = self.f.calculate_packed(self._x_dev, self.gamma.value)

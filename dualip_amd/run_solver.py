@@ -13,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 from dualip_amd.objectives.base import BaseInputArgs
+from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunction
 from dualip_amd.objectives.matching import (
     MatchingInputArgs,
     MatchingSolverDualObjectiveFunction,
@@ -59,7 +60,10 @@ def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_
             local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device
         )
     if kind == "miplib2017":
-        raise NotImplementedError("the miplib2017 objective is not part of the MI355X matching hot path (SURVEY.md 8f3)")
+        kwargs = dict(objective_args.objective_kwargs or {})
+        if objective_args.use_jacobi_precondition:
+            kwargs.setdefault("use_jacobi_precondition", True)
+        return MIPLIB2017ObjectiveFunction(miplib_input_args=input_args, **kwargs)
     raise ValueError(f"Objective type {kind} not supported")
 
 
@@ -93,4 +97,9 @@ def run_solver(
     device = objective.device if hasattr(objective, "device") else host_device
     initial_dual = initial_dual.to(device)
     rank = dist.get_rank() if (sharded and dist.is_initialized()) else 0
-    return solver.maximize(objective, initial_dual, rank=rank)
+    result = solver.maximize(objective, initial_dual, rank=rank)
+    if getattr(objective, "use_jacobi_precondition", None):  # report duals / gradient of the original rows (run_solver.py:136-144)
+        dual_val, dual_grad = objective.invert_jacobi_precondition(result.dual_val, result.objective_result.dual_gradient)
+        result.dual_val = dual_val
+        result.objective_result.dual_gradient = dual_grad
+    return result

@@ -177,6 +177,26 @@ int dl_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* 
 int dl_jacobi_precondition(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b,
                            void* row_norms_out, int val_dtype, dl_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Generic LP ("miplib2017") dual objective -- MIPLIB2017ObjectiveFunction (src/dualip/objectives/miplib.py:28-109).
+ * x has one entry per variable:  z = (-1/gamma)(A^T lambda' + c),  x = clamp(z, lower, upper),  lambda' = lambda * inv_row_norm.
+ * The handle BORROWS every array (device pointers, caller keeps them alive): A in both CSC (for A^T lambda) and CSR
+ * (for A x) with int64 pointer arrays and int32 index arrays; c, lower, upper val[n] (-inf / +inf where a bound is
+ * absent); inv_row_norm val[m] = 1/||A_i|| for the Jacobi-preconditioned variant (miplib.py:48-56,74-75,94-95) or NULL.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct dl_lp dl_lp;
+int dl_lp_create(dl_lp** out, int64_t m, int64_t n, int64_t nnz, const int64_t* colptr, const int32_t* rowidx, const void* vals_csc,
+                 const int64_t* rowptr, const int32_t* colidx, const void* vals_csr, const void* c, const void* lower, const void* upper,
+                 const void* inv_row_norm, int val_dtype);
+int dl_lp_destroy(dl_lp* h);
+/* miplib.py:77-99 in one call: packed_out[0..m) = (A x)_i [* inv_row_norm_i], packed_out[m] = c.x, packed_out[m+1] = sum x^2
+ * (the layout dl_dual_epilogue / dl_agd_step consume; pass b [* inv_row_norm] there).  x_out val[n] or NULL. */
+int dl_lp_calculate(dl_lp* h, const void* lambda, double gamma, double* packed_out, void* x_out, dl_stream_t stream);
+/* The two halves, for projection maps that are not point-wise bounds (miplib.py:80-92 applies arbitrary registered
+ * operators to index sets): dl_lp_primal with apply_bounds = 0 returns z, the caller projects, dl_lp_gradient finishes. */
+int dl_lp_primal(dl_lp* h, const void* lambda, double gamma, int apply_bounds, void* x_out, dl_stream_t stream);
+int dl_lp_gradient(dl_lp* h, const void* x, double* packed_out, dl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,3 +121,14 @@ class OracleLocalObjective:
             dual_gradient=torch.from_numpy(np.asarray(grad, dtype=self.np_dtype)), dual_objective=t(obj), reg_penalty=t(reg),
             dual_val_times_grad=t(dvtg), max_pos_slack=t(mx), sum_pos_slack=t(sm),
         )
+
+
+def lp_small_entries(z):
+    """The projection map of tests/golden/make_golden_lp.py:small_map as (proj_type, params, indices) triples."""
+    return [
+        ("box", {"lower": -0.5, "upper": 1.5}, z["idx_two"]),
+        ("box", {}, z["idx_unit"]),
+        ("cone", {"lower": 0.0}, z["idx_lo"]),
+        ("cone", {"upper": 0.75}, z["idx_up"]),
+        ("box", {"lower": 0.25, "upper": 2.0}, z["idx_lu_names"]),
+    ]
