@@ -1,0 +1,152 @@
+"""GPU edge cases of the fused matching pass against the CPU oracle (``-m gpu``): shapes the golden fixtures do not reach.
+
+  * more than 65 536 dual rows  -> 32-bit row indices, the dual vector and the gradient no longer fit the LDS (global-atomic plan)
+  * more than 255 projection entries -> entries beyond the LDS table are served by the single-column path
+  * value arrays that are not 16-byte aligned, and tiny problems -> the 64-wide tile layout
+  * columns longer than a 256-element window, empty columns, an all-empty problem, a column range of one operator inside another
+Tolerance: RTOL of tests/helpers.py (2e-4 fp32 / 1e-9 fp64, relative to the largest magnitude).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import agd_oracle
+from tests.helpers import NP_DT, RTOL, relerr, torch_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _random_problem(m, n, mean_deg, seed, long_cols=(), empty_every=0):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(mean_deg, n).astype(np.int64)
+    deg = np.minimum(deg, m)
+    for j, d in long_cols:
+        deg[j] = d
+    if empty_every:
+        deg[::empty_every] = 0
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    colptr[1:] = np.cumsum(deg)
+    rows = np.concatenate([np.sort(rng.choice(m, size=int(d), replace=False)) for d in deg]) if deg.sum() else np.zeros(0, dtype=np.int64)
+    nnz = int(colptr[-1])
+    a = rng.uniform(0.05, 1.0, nnz)
+    c = -rng.uniform(0.01, 0.5, nnz)
+    b = rng.uniform(0.5, 2.0, m)
+    return dict(m=m, n=n, colptr=colptr, rowidx=rows.astype(np.int64), a=a, c=c, b=b)
+
+
+def _compare(p, pm, entries, col_proj, gamma, dn, lam, scale=1.0):
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, pm, DEV), gamma=gamma)
+    td = torch.float32 if dn == "f32" else torch.float64
+    res = f.calculate(torch.from_numpy(lam).to(td).to(DEV), gamma=gamma, save_primal=True)
+    ax, obj0, ssq, x = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], p["a"], p["c"], lam, gamma, entries, col_proj=col_proj, dtype=NP_DT[dn])
+    grad, obj, reg, dvtg, mx, sm = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], gamma, NP_DT[dn])
+    assert relerr(res.dual_gradient.cpu().numpy(), grad) < RTOL[dn] * scale
+    assert relerr(res.primal_var.cpu().numpy(), x) < RTOL[dn] * scale
+    assert relerr([float(res.dual_objective), float(res.reg_penalty)], [obj, reg]) < RTOL[dn] * 10 * scale
+    return f
+
+
+def test_more_than_65536_rows():
+    from dualip_amd.projections import create_projection_map
+
+    m, n = 70_000, 6_000
+    p = _random_problem(m, n, 9, seed=5)
+    lam = np.random.default_rng(1).uniform(0, 0.01, m)
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0})):
+            f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
+            info = f.info()
+            assert info["row_index_bytes"] == 4 and info["lambda_in_lds"] == 0 and info["grad_in_lds"] == 0, info
+
+
+def test_more_projection_entries_than_the_lds_table():
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 300, 6_000
+    p = _random_problem(m, n, 8, seed=9)
+    lam = np.random.default_rng(2).uniform(0, 0.02, m)
+    pm, entries, col_proj = {}, [], np.full(n, -1, dtype=np.int32)
+    per = 15  # 400 entries of 15 columns: box bounds / simplex radii that differ per entry
+    for e in range(n // per):
+        idx = list(range(e * per, (e + 1) * per))
+        if e % 3 == 0:
+            kind, params = "simplex", {"z": 0.5 + 0.01 * e}
+        elif e % 3 == 1:
+            kind, params = "box", {"lower": 0.0, "upper": 0.2 + 0.002 * e}
+        else:
+            kind, params = "cone", {"lower": 0.001 * e}
+        pm[f"e{e}"] = ProjectionEntry(kind, params, indices=idx)
+        entries.append((kind, params))
+        col_proj[idx] = e
+    for dn in ("f32", "f64"):
+        _compare(p, pm, entries, col_proj, 0.02, dn, lam)
+
+
+def test_unaligned_values_and_tiny_problems_take_the_narrow_layout():
+    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = _random_problem(120, 900, 7, seed=3, long_cols=((5, 100), (400, 90)), empty_every=37)
+    lam = np.random.default_rng(4).uniform(0, 0.05, p["m"])
+    pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
+    ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.05)
+    assert ref.info()["layout"] == 4
+    want = ref.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
+    want_grad, want_x = want.dual_gradient.clone(), want.primal_var.clone()
+    # the same values one element into a larger buffer: 4-byte aligned, not 16-byte aligned
+    nnz = int(p["colptr"][-1])
+    a_buf = torch.zeros(nnz + 8, dtype=torch.float32, device=DEV)
+    c_buf = torch.zeros(nnz + 8, dtype=torch.float32, device=DEV)
+    a_buf[1 : nnz + 1] = torch.from_numpy(p["a"]).float().to(DEV)
+    c_buf[1 : nnz + 1] = torch.from_numpy(p["c"]).float().to(DEV)
+    colptr, rowidx = torch.from_numpy(p["colptr"]).to(DEV), torch.from_numpy(p["rowidx"]).to(DEV)
+    A = torch.sparse_csc_tensor(colptr, rowidx, a_buf[1 : nnz + 1], size=(p["m"], p["n"]), check_invariants=False)
+    C = torch.sparse_csc_tensor(colptr, rowidx, c_buf[1 : nnz + 1], size=(p["m"], p["n"]), check_invariants=False)
+    if A.values().data_ptr() % 16 != 0:  # (torch may copy the slice into a fresh, aligned allocation: then there is nothing to test)
+        f = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.from_numpy(p["b"]).float().to(DEV), equality_mask=None), gamma=0.05)
+        assert f.info()["layout"] == 1
+        got = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
+        assert relerr(got.dual_gradient.cpu().numpy(), want_grad.cpu().numpy()) < 1e-6
+        assert relerr(got.primal_var.cpu().numpy(), want_x.cpu().numpy()) < 1e-6
+    # fewer than 1024 non-zeros: narrow layout, same numbers as the oracle
+    q = _random_problem(40, 60, 6, seed=8, empty_every=7)
+    f = _compare(q, create_projection_map("simplex", {"z": 1.0}, q["n"]), [("simplex", {"z": 1.0})], None, 0.05, "f64",
+                 np.random.default_rng(6).uniform(0, 0.05, q["m"]))
+    assert f.info()["layout"] == 1
+
+
+def test_long_columns_empty_columns_and_nested_ranges():
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 2_000, 4_000
+    # columns longer than one 256-element window, next to ordinary and empty ones
+    p = _random_problem(m, n, 10, seed=21, long_cols=((1, 300), (17, 1500), (1999, 257), (3999, 700)), empty_every=11)
+    lam = np.random.default_rng(7).uniform(0, 0.01, m)
+    pm = {
+        "simplex_a": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(0, 1000))),
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 0.7}, indices=list(range(1000, 1800))),
+        "simplex_b": ProjectionEntry("simplex_eq", {"z": 2.0}, indices=list(range(2500, 4000))),
+        # 1800..2499: in no entry
+    }
+    entries = [("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.7}), ("simplex_eq", {"z": 2.0})]
+    col_proj = np.full(n, -1, dtype=np.int32)
+    col_proj[0:1000], col_proj[1000:1800], col_proj[2500:4000] = 0, 1, 2
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.03, dn, lam)
+        assert f.info()["long_columns"] >= 4
+
+
+def test_all_columns_empty():
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = dict(m=50, n=30, colptr=np.zeros(31, dtype=np.int64), rowidx=np.zeros(0, dtype=np.int64), a=np.zeros(0), c=np.zeros(0), b=np.linspace(0.1, 1, 50))
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, 30), DEV), gamma=0.1)
+    lam = torch.rand(50, dtype=torch.float64, device=DEV)
+    res = f.calculate(lam, save_primal=True)
+    assert torch.allclose(res.dual_gradient, -torch.from_numpy(p["b"]).to(DEV))
+    assert abs(float(res.dual_objective) + float((lam.cpu() * torch.from_numpy(p["b"])).sum())) < 1e-12 and res.primal_var.numel() == 0

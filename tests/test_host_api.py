@@ -215,3 +215,45 @@ def test_balanced_block_ranges_cover_every_block_evenly():
     # unaligned tail and more parts than units
     rs = [balanced_block_ranges([(0, 250)], 4, r, align=100) for r in range(4)]
     assert sorted(c for x in rs for a, b in x for c in range(a, b)) == list(range(250))
+
+
+def test_memmap_cache_format_reads_and_rewrites_the_reference_cache(tmp_path):
+    """tests/golden/g5_cache/ was written by the reference's generator (tests/golden/make_golden_cache.py)."""
+    import filecmp
+    import json
+    import os
+
+    import numpy as np
+    import torch
+
+    from benchmark import cache_format as cf
+    from tests.helpers import GOLDEN
+
+    src = os.path.join(GOLDEN, "g5_cache")
+    key = (1000, 20, 0.2, torch.float32, 42)
+    assert cf.cache_prefix(*key) == "s1000_d20_sp0.2_float32_seed42"
+    arrays = cf.load_matching_cache_numpy(src, *key)
+    assert arrays is not None
+    ccol, row, a_vals, c_vals, b = arrays
+    assert ccol.shape == (1001,) and ccol[0] == 0 and ccol[-1] == row.shape[0] == a_vals.shape[0] == c_vals.shape[0] == 3993
+    assert np.all(np.diff(ccol) >= 0) and row.min() >= 0 and row.max() < 20 and b.shape == (20,)
+    assert np.all(c_vals >= 0) and np.all(a_vals >= 0)  # the cache holds positive costs; the input bundle negates them (:447-448)
+    # a different key is a miss, as in the reference (generate_synthetic_data.py:235-246)
+    assert cf.load_matching_cache_numpy(src, 1000, 20, 0.2, torch.float32, 43) is None
+    assert cf.load_matching_cache_numpy(src, 1000, 20, 0.2, torch.float64, 42) is None
+    # writing the same arrays gives byte-identical files and the same metadata record
+    dst = str(tmp_path / "cache")
+    prefix = cf.save_matching_cache(dst, *key, ccol, row, a_vals, c_vals, b)
+    for k in cf.ARRAYS:
+        assert filecmp.cmp(os.path.join(src, f"{prefix}_{k}.dat"), os.path.join(dst, f"{prefix}_{k}.dat"), shallow=False), k
+    assert json.load(open(os.path.join(src, f"{prefix}_meta.json"))) == json.load(open(os.path.join(dst, f"{prefix}_meta.json")))
+    # and loads into the operator API's input bundle (CPU tensors here; the GPU tests load to the device)
+    args = cf.load_matching_cache(src, *key, device="cpu")
+    assert args.A.layout == torch.sparse_csc and tuple(args.A.shape) == (20, 1000) and args.A.values().dtype == torch.float32
+    assert torch.equal(args.A.ccol_indices(), args.c.ccol_indices()) and args.b_vec.shape == (20,)
+    assert torch.equal(args.c.values(), -torch.from_numpy(np.asarray(c_vals)).to(torch.float32)) and "simplex_z_1.0" in args.projection_map
+    # bundle -> cache -> bundle round trip
+    dst2 = str(tmp_path / "cache2")
+    cf.save_matching_args(dst2, args, 0.2, 7)
+    back = cf.load_matching_cache(dst2, 1000, 20, 0.2, torch.float32, 7, device="cpu")
+    assert torch.equal(back.A.values(), args.A.values()) and torch.equal(back.c.values(), args.c.values()) and torch.equal(back.b_vec, args.b_vec)
