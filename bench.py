@@ -81,6 +81,22 @@ def shard_plan(kind, n_global, world, rank, align):
     return ranges, pm
 
 
+def copy_ceiling_gbps(device, nbytes=1 << 30, reps=10):
+    """Measured device-to-device copy rate (bytes read + bytes written per second) on this box: the practical HBM ceiling
+    next to the 8 TB/s vendor peak (SURVEY.md 8d asks for both)."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(args, inp, pm_local, total_nnz):
     """Oracle (kind 'port') on the first --cpu-sample-cols local columns, all host cores."""
     import oracle
@@ -266,6 +282,7 @@ def main():
                 "final_dual_objective": result.dual_objective,
                 "layout": local.info(),
                 "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
+                "copy_ceiling_GBps": copy_ceiling_gbps(device),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

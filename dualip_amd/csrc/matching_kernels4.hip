@@ -51,9 +51,6 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg = blockIdx.x;
     stamp(g, wg, tid, 0);
-    const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
-    stamp(g, wg, tid, 1);
-    const T s = w.s;
     const LaneConst lc = make_lane_const(lane);
     double obj = 0.0, ssq = 0.0;
 
@@ -109,6 +106,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         dv_next = load_desc(ti + S);
         unpack_and_issue(dv0, tA);
     }
+    // the first tile's loads are in flight while the workgroup stages lambda and zeroes its gradient
+    const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
+    stamp(g, wg, tid, 1);
+    const T s = w.s;
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
     // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
     // force a full memory wait at the end of every step.
