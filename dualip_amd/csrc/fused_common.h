@@ -169,11 +169,25 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     w.red_s = reinterpret_cast<double*>(smem + off);
     w.s = (T)(-1.0 / g.gamma);
     double lmax = 0.0;
-    for (int64_t i = tid; i < g.m; i += kFusedThreads) {
-        const T l = g.lambda[i];
-        if constexpr (LAM_LDS) w.lam_s[i] = (T)(w.s * l);
-        const double al = fabs((double)l);
-        lmax = al > lmax ? al : lmax;
+    {   // latency bound (every workgroup pulls the whole dual vector from L2): four loads in flight per thread
+        constexpr int kU = 4;
+        for (int64_t i0 = tid; i0 < g.m; i0 += (int64_t)kU * kFusedThreads) {
+            T l[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                l[u] = g.lambda[i < g.m ? i : g.m - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                if (i < g.m) {
+                    if constexpr (LAM_LDS) w.lam_s[i] = (T)(w.s * l[u]);
+                    const double al = fabs((double)l[u]);
+                    lmax = al > lmax ? al : lmax;
+                }
+            }
+        }
     }
     if constexpr (GRAD_LDS) {
         for (int64_t i = tid; i < g.m; i += kFusedThreads) w.grad_s[i] = 0;

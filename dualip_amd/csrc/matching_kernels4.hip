@@ -101,15 +101,14 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     uint32_t ti = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;  // schedule slot
     uint32_t dv_next = 0;
     Tile tA, tB;
-    if (ti < n_tiles) {
-        const uint32_t dv0 = load_desc(ti);
-        dv_next = load_desc(ti + S);
-        unpack_and_issue(dv0, tA);
-    }
-    // the first tile's loads are in flight while the workgroup stages lambda and zeroes its gradient
+    // the first two descriptors are in flight while the workgroup stages lambda and zeroes its gradient (their loads
+    // are older than the prologue's, so waiting for lambda does not wait for tile data)
+    const uint32_t dv0 = load_desc(ti);
+    dv_next = load_desc(ti + S);
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
     stamp(g, wg, tid, 1);
     const T s = w.s;
+    if (ti < n_tiles) unpack_and_issue(dv0, tA);
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
     // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
     // force a full memory wait at the end of every step.
