@@ -129,6 +129,108 @@ __device__ __forceinline__ void seg_allreduce4(const T (&u)[kSlots], const Seg4&
     for (int j = 0; j < kSlots; ++j) tot[j] = lane_bit(s.O[j]) ? r : b[j];
 }
 
+// ---- SUM reductions without selects ----
+// For sums, "take the neighbour's value if the predicate holds" is x + p * t with p in {0, 1}: ONE fused multiply-add
+// (exactly round(x + t) or x) instead of an add and a v_cndmask, and the DPP move folds into it (v_fmac_f32_dpp).  The 0/1
+// masks are built once per tile (13 selects) and reused by every sum / count reduction of the tile (>= 2).  Values must be
+// finite (an infinity times 0 would leak a NaN into the neighbouring column): simplex_tile4 clamps at FLT_MAX.
+template <class T>
+struct SegMul4 {
+    T nh[kSlots];  // slot j does not start a column (j >= 1)
+    T nN[kSlots];  // the previous lane's carry applies to slot j
+    T p1, p2, p4, p8, pa, pb;
+};
+template <class T>
+__device__ __forceinline__ SegMul4<T> make_segmul4(const Seg4& s) {
+    SegMul4<T> m;
+    m.nh[0] = (T)0;
+#pragma unroll
+    for (int j = 1; j < kSlots; ++j) m.nh[j] = lane_bit(s.H[j]) ? (T)0 : (T)1;
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) m.nN[j] = lane_bit(s.N[j]) ? (T)1 : (T)0;
+    m.p1 = lane_bit(s.P1) ? (T)1 : (T)0;
+    m.p2 = lane_bit(s.P2) ? (T)1 : (T)0;
+    m.p4 = lane_bit(s.P4) ? (T)1 : (T)0;
+    m.p8 = lane_bit(s.P8) ? (T)1 : (T)0;
+    m.pa = lane_bit(s.PA) ? (T)1 : (T)0;
+    m.pb = lane_bit(s.PB) ? (T)1 : (T)0;
+    return m;
+}
+__device__ __forceinline__ float fma_exact(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_exact(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <class T>
+__device__ __forceinline__ T lane_scan4_sum(T x, const SegMul4<T>& m) {
+    x = fma_exact(dpp_mov0<DPP_ROW_SHR1, 0xf>(x), m.p1, x);
+    x = fma_exact(dpp_mov0<DPP_ROW_SHR2, 0xf>(x), m.p2, x);
+    x = fma_exact(dpp_mov0<DPP_ROW_SHR4, 0xf>(x), m.p4, x);
+    x = fma_exact(dpp_mov0<DPP_ROW_SHR8, 0xf>(x), m.p8, x);
+    x = fma_exact(dpp_mov0<DPP_ROW_BCAST15, 0xa>(x), m.pa, x);
+    x = fma_exact(dpp_mov0<DPP_ROW_BCAST31, 0xc>(x), m.pb, x);
+    return x;
+}
+// the same scan over two independent values.  float: the compiler does not fold the DPP move into v_fmac_f32, so the
+// six steps are written out -- x += dpp(x) * p is ONE instruction per value (lanes without a source add 0 * p).  The
+// s_nop supplies, together with the other chain's instruction, the two wait states a DPP read needs after a VALU write.
+template <class T>
+__device__ __forceinline__ void lane_scan4_sum2(T& xa, T& xb, const SegMul4<T>& m) {
+    xa = lane_scan4_sum(xa, m);
+    xb = lane_scan4_sum(xb, m);
+}
+#define DL_FMAC_DPP2(ctrl, mask)                                                                            \
+    asm("s_nop 0\n\tv_fmac_f32_dpp %0, %0, %2 " ctrl "\n\tv_fmac_f32_dpp %1, %1, %2 " ctrl : "+v"(xa), "+v"(xb) : "v"(mask))
+template <>
+__device__ __forceinline__ void lane_scan4_sum2<float>(float& xa, float& xb, const SegMul4<float>& m) {
+    asm("s_nop 1" : "+v"(xa), "+v"(xb));  // (the compiler's hazard recogniser does not look inside inline assembly)
+    DL_FMAC_DPP2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", m.p1);
+    DL_FMAC_DPP2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", m.p2);
+    DL_FMAC_DPP2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", m.p4);
+    DL_FMAC_DPP2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", m.p8);
+    DL_FMAC_DPP2("row_bcast:15 row_mask:0xa bank_mask:0xf", m.pa);
+    DL_FMAC_DPP2("row_bcast:31 row_mask:0xc bank_mask:0xf", m.pb);
+    asm("s_nop 1" : "+v"(xa), "+v"(xb));
+}
+#undef DL_FMAC_DPP2
+
+// Two sums at once (the simplex needs the sum and the size of the support): every element receives both totals of its
+// column.  The two chains are independent, so their instructions interleave and share the LDS wait.
+template <class T>
+__device__ __forceinline__ void seg_allreduce4_sum2(const T (&a)[kSlots], const T (&b)[kSlots], const Seg4& s, const SegMul4<T>& m, int end_lane,
+                                                    T (&ta)[kSlots], T (&tb)[kSlots]) {
+    T fa[kSlots], fb[kSlots];
+    fa[0] = a[0];
+    fb[0] = b[0];
+#pragma unroll
+    for (int j = 1; j < kSlots; ++j) {
+        fa[j] = fma_exact(fa[j - 1], m.nh[j], a[j]);
+        fb[j] = fma_exact(fb[j - 1], m.nh[j], b[j]);
+    }
+    T xa = fa[kSlots - 1], xb = fb[kSlots - 1];
+    lane_scan4_sum2(xa, xb, m);
+    const T ca = dpp_mov0<DPP_WAVE_SHR1, 0xf>(xa);
+    const T cb = dpp_mov0<DPP_WAVE_SHR1, 0xf>(xb);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        fa[j] = fma_exact(ca, m.nN[j], fa[j]);
+        fb[j] = fma_exact(cb, m.nN[j], fb[j]);
+    }
+    T ba[kSlots], bb[kSlots];
+    ba[kSlots - 1] = fa[kSlots - 1];
+    bb[kSlots - 1] = fb[kSlots - 1];
+#pragma unroll
+    for (int j = kSlots - 2; j >= 0; --j) {
+        ba[j] = lane_bit(s.H[j + 1]) ? fa[j] : ba[j + 1];
+        bb[j] = lane_bit(s.H[j + 1]) ? fb[j] : bb[j + 1];
+    }
+    const T ra = bperm(end_lane, ba[0]);
+    const T rb = bperm(end_lane, bb[0]);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        ta[j] = lane_bit(s.O[j]) ? ra : ba[j];
+        tb[j] = lane_bit(s.O[j]) ? rb : bb[j];
+    }
+}
+
 // first lane above `lane` in which an entering column ends (bit 63 of G is always set)
 __device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
     const uint32_t glo = (uint32_t)s.G & c.gt_lo, ghi = (uint32_t)(s.G >> 32) & c.gt_hi;
@@ -151,7 +253,7 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
     const int el = end_lane4(s, lc);
     T u[kSlots], th[kSlots], sumA[kSlots], cnt[kSlots], inu[kSlots], ind[kSlots];
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) u[j] = relu(v[j]);
+    for (int j = 0; j < kSlots; ++j) u[j] = relu_finite(v[j]);  // max(v, 0), and no infinity (see SegMul4)
     {
         T v1[kSlots];
         seg_allreduce4(u, s, el, OpMaxNonNeg(), v1);
@@ -163,8 +265,8 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
             ind[j] = in ? (T)1 : (T)0;
         }
     }
-    seg_allreduce4(inu, s, el, OpAdd(), sumA);
-    seg_allreduce4(ind, s, el, OpAdd(), cnt);
+    const SegMul4<T> sm = make_segmul4<T>(s);
+    seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt);
     bool act[kSlots];
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
 #pragma unroll
@@ -194,8 +296,7 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
             ind[j] = in ? (T)1 : (T)0;
             inu[j] = in ? u[j] : (T)0;
         }
-        seg_allreduce4(ind, s, el, OpAdd(), cnt2);
-        seg_allreduce4(inu, s, el, OpAdd(), sumA);
+        seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt2);
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             const bool changed = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;

@@ -11,6 +11,9 @@ namespace dl {
 // non-negative floats order like their bit patterns, and max(v, 0) is a signed-integer max against 0.
 __device__ __forceinline__ float relu(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 __device__ __forceinline__ double relu(double v) { return v > 0.0 ? v : 0.0; }
+// clamp to [0, largest finite]: one v_med3 (a NaN input gives 0 or the upper bound, never a NaN)
+__device__ __forceinline__ float relu_finite(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.402823466e+38f); }
+__device__ __forceinline__ double relu_finite(double v) { return v > 0.0 ? (v < 1.7976931348623157e+308 ? v : 1.7976931348623157e+308) : 0.0; }
 __device__ __forceinline__ float max_nonneg(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ double max_nonneg(double a, double b) { return a > b ? a : b; }
 

@@ -94,7 +94,10 @@ def test_unaligned_values_and_tiny_problems_take_the_narrow_layout():
     lam = np.random.default_rng(4).uniform(0, 0.05, p["m"])
     pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
     ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.05)
-    assert ref.info()["layout"] == 4
+    import os
+
+    forced_narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the whole suite is also run with the narrow layout forced)
+    assert ref.info()["layout"] == (1 if forced_narrow else 4)
     want = ref.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
     want_grad, want_x = want.dual_gradient.clone(), want.primal_var.clone()
     # the same values one element into a larger buffer: 4-byte aligned, not 16-byte aligned
