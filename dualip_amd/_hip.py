@@ -41,6 +41,7 @@ _SIGNATURES = {
     "dl_matching_calculate": (_c_int, [_c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),
     "dl_matching_profile": (_c_int, [_c_vp, _c_int]),
     "dl_matching_profile_read": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
+    "dl_matching_set_eq_padding": (_c_int, [_c_vp, _c_vp, ctypes.c_int32, _c_vp]),
     "dl_matching_timeline_read": (_c_int, [_c_vp, ctypes.POINTER(ctypes.c_uint64), _c_i64]),
     "dl_dual_epilogue": (_c_int, [_c_i64, _c_int, _c_vp, _c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),
     "dl_agd_create": (_c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_int, _c_i64, _c_vp, _c_dbl, _c_dbl, _c_vp, _c_vp, _c_vp]),

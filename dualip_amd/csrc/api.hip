@@ -96,6 +96,7 @@ static void matching_free(dl_matching* h) {
     if (h->partial_scal) (void)hipFree(h->partial_scal);
     if (h->shift_dev) (void)hipFree(h->shift_dev);
     if (h->timeline) (void)hipFree(h->timeline);
+    if (h->eq_heights) (void)hipFree(h->eq_heights);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
     delete h;
@@ -565,6 +566,26 @@ int dl_matching_profile(dl_matching* h, int enable) {
     if (!h) return fail(DL_E_ARG, "null handle");
     h->prof_on = enable != 0;
     h->prof_used = 0;
+    return 0;
+}
+
+int dl_matching_set_eq_padding(dl_matching* h, const int32_t* heights_host, int32_t n_rows, dl_stream_t stream) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    if (!heights_host) {  // back to the exact projection
+        if (h->eq_heights) {
+            DL_HIP(hipStreamSynchronize((hipStream_t)stream));
+            (void)hipFree(h->eq_heights);
+            h->eq_heights = nullptr;
+        }
+        return 0;
+    }
+    if (n_rows != h->n_proj) return fail(DL_E_ARG, "heights must have one row of 32 per projection entry (%d), got %d", (int)h->n_proj, (int)n_rows);
+    for (int64_t k = 0; k < (int64_t)n_rows * 32; ++k)
+        if (heights_host[k] < 0) return fail(DL_E_ARG, "negative block height");
+    const size_t bytes = sizeof(int32_t) * 32 * (size_t)(n_rows > 0 ? n_rows : 1);
+    if (!h->eq_heights) DL_HIP(hipMalloc((void**)&h->eq_heights, bytes));
+    DL_HIP(hipMemcpyAsync(h->eq_heights, heights_host, sizeof(int32_t) * 32 * (size_t)n_rows, hipMemcpyHostToDevice, (hipStream_t)stream));
+    DL_HIP(hipStreamSynchronize((hipStream_t)stream));  // heights_host may be a temporary
     return 0;
 }
 

@@ -92,6 +92,7 @@ struct dl_matching {
     size_t owned_bytes = 0;
     bool use_dpp = true;
     int ablate = 0;  // developer-only timing ablations, see FusedArgs
+    int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)
     unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
     bool prof_on = false;

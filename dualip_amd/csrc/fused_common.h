@@ -34,6 +34,7 @@ struct FusedArgs {
     uint32_t n_tiles;   // layout 4: tiles of the launch (cyclic schedule)
     int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
+    const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
 };
 
 // a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
@@ -59,6 +60,14 @@ __device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax
     atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
 }
 
+// ---- simplex_eq "padded block" compatibility (dl_matching_set_eq_padding) ----
+// The reference projects a column inside a zero-padded [L x K] block, L = the longest column of the column's bucket
+// (sparse_utils.py:185-209; buckets by nnz: (0,2], (2,4], (4,8], ... matching.py:87-114).  For simplex_eq the padding is
+// visible exactly when the clamped column sums to less than z: the deficit is then spread over L entries instead of the
+// column's own.  bucket(len) = bucketize(len, [0, 2, 4, ...]) = 1 for len <= 2, else ceil(log2(len)).
+constexpr int kEqBuckets = 32;
+__device__ __forceinline__ int eq_bucket(int len) { return len <= 2 ? 1 : 32 - __clz(len - 1); }
+
 template <class P>
 __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
     return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
@@ -67,7 +76,7 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 // Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
 template <class T, class RowT, bool LAM_LDS>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
-                                              double scale, int lane, double& obj, double& ssq) {
+                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr) {
     const bool is_simplex = is_simplex_kind(pj.kind);
     auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
         av = g.a[k];
@@ -91,7 +100,10 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
         S = wave_allreduce(S, OpAdd());
         v1 = wave_allreduce(v1, OpMax());
         projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
-        if (projected) {
+        const bool padded = eq_row && pj.kind == DL_PROJ_SIMPLEX_EQ && S < pj.z;
+        if (padded) {  // every entry and every padding zero is in the support: theta = (S - z) / L, final
+            th = (T)((T)(S - pj.z) / (T)eq_row[eq_bucket((int)(len < 0x7fffffff ? len : 0x7fffffff))]);
+        } else if (projected) {
             const T z = pj.z;
             th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
             long long cnt_prev = 0;

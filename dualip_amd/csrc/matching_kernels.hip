@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
         // ------------------------------ batch of short tiles: one non-zero per lane and tile ------------------------------
         ProjT<T> pj[kBatch];
         bool valid[kBatch], smp[kBatch];
+        const int32_t* eq_row[kBatch];
         bool any_simplex = false, any_long = false;
         T v[kBatch], x[kBatch];
 #pragma unroll
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
             const int kind = __builtin_amdgcn_readfirstlane(pj[q].kind);
             valid[q] = !is_long && (uint32_t)lane < cnt;
             smp[q] = !is_long && cnt > 0 && is_simplex_kind(kind);
+            eq_row[q] = (kind == DL_PROJ_SIMPLEX_EQ && g.eq_heights) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
             any_simplex = any_simplex || smp[q];
             T lam = (T)1;
             if (!(g.ablate & 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
             v[q] = (T)(t1 + (T)(s * cur.c[q]));        // matching.py:66,142
             x[q] = (g.ablate & 4) ? v[q] : project_pointwise(v[q], pj[q]);
         }
-        if (any_simplex && !(g.ablate & 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x);
+        if (any_simplex && !(g.ablate & 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x, eq_row);
         T o32 = (T)0, q32 = (T)0;
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
@@ -222,7 +224,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
                     ProjT<T> pl = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
                     if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj) pl = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
                     const uint64_t w0 = ((uint64_t)w0hi << 32) | w0lo;
-                    process_long_tile<T, RowT, LAM_LDS>(g, pl, tile_nnz_start(w0), w1, lam_s, gacc, s, scale, lane, obj, ssq);
+                    const int32_t* eq_long = (g.eq_heights && pid != kNoProj) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
+                    process_long_tile<T, RowT, LAM_LDS>(g, pl, tile_nnz_start(w0), w1, lam_s, gacc, s, scale, lane, obj, ssq, eq_long);
                 }
             }
         }
@@ -408,6 +411,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.n_tiles = (uint32_t)h->n_tiles;
     args.ablate = h->ablate;
     args.timeline = h->timeline;
+    args.eq_heights = h->eq_heights;
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
     hipEvent_t ev_stop = nullptr;
     if (h->prof_on) {

@@ -145,7 +145,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
                 const Seg4 sg = make_seg4(H);
-                simplex_tile4(v, sg, pj, lc, x);
+                const int32_t* eq_row = nullptr;
+                if (kind == DL_PROJ_SIMPLEX_EQ) {  // cold: the pointer is re-read from the kernel arguments
+                    const int32_t* eqh = kernarg_args(g).eq_heights;
+                    eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
+                }
+                simplex_tile4(v, sg, pj, lc, x, eq_row);
             } else {
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const ProjT<T> pl = lookup_proj(gk, w.proj_s, pid);
             const uint64_t k0 = (((uint64_t)cur.w0hi << 32) | cur.w0lo) & ((1ull << 40) - 1);
             const uint64_t len = ((uint64_t)rl(cur.dv, 3) << 32) | rl(cur.dv, 2);
-            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq);
+            const int32_t* eq_row = (gk.eq_heights && pid != kNoProj && pid != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pid * kEqBuckets : nullptr;
+            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row);
         }
         ti += S;
     };

@@ -129,7 +129,8 @@ __device__ __forceinline__ SegInfo make_seginfo_fast(uint64_t head, const LaneCo
 // smp[q] == false (tile absent or not a simplex tile): x[q] is left untouched.
 template <bool USE_DPP, class T>
 __device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (&valid)[kBatch], const uint64_t (&head)[kBatch],
-                                              const ProjT<T> (&pj)[kBatch], const bool (&smp)[kBatch], const LaneConst& lc, T (&x)[kBatch]) {
+                                              const ProjT<T> (&pj)[kBatch], const bool (&smp)[kBatch], const LaneConst& lc, T (&x)[kBatch],
+                                              const int32_t* const (&eq_row)[kBatch]) {
     SegInfo sg[kBatch];
     T u[kBatch], th[kBatch], v1[kBatch];
     bool act[kBatch], proj[kBatch], onehot[kBatch], live[kBatch];
@@ -169,7 +170,14 @@ __device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (
                 act[q] = act[q] && !conv;
                 if (__any(act[q])) {
                     const T sumA = seg_allreduce<USE_DPP>(in ? u[q] : (T)0, sg[q], (T)0, OpAdd());
-                    const T th_new = div_exactish((T)(sumA - pj[q].z), (T)cnt);
+                    T den = (T)cnt;
+                    if (eq_row[q]) {  // simplex_eq compatibility mode (fused_common.h: eq_bucket): sum < z on the first pass means
+                                      // theta < 0, the support is the whole column (cnt = its length) plus the padding zeros
+                        const int b = cnt <= 2 ? 1 : 32 - __clz(cnt - 1);
+                        const T L = (T)eq_row[q][b > 0 ? b : 1];
+                        den = (it == 0 && sumA < pj[q].z) ? L : den;
+                    }
+                    const T th_new = div_exactish((T)(sumA - pj[q].z), den);
                     // feasible after the clamp (simplex.py:153-158): only decided on the first pass
                     const bool feas = it == 0 && pj[q].kind == DL_PROJ_SIMPLEX && !(sumA > pj[q].ztol);
                     const bool upd = act[q] && !feas && cnt != 0;

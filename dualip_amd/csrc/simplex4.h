@@ -249,7 +249,8 @@ __device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
 // theta_1 exactly when it is above max - z); larger supports run monotone Newton passes that end on a ballot.
 // Few boolean masks are kept alive on purpose: every per-slot flag is an SGPR pair and the kernel is SGPR-starved.
 template <class T>
-__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots]) {
+__device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots],
+                                              const int32_t* eq_row = nullptr) {
     const int el = end_lane4(s, lc);
     T u[kSlots], th[kSlots], sumA[kSlots], cnt[kSlots], inu[kSlots], ind[kSlots];
 #pragma unroll
@@ -269,18 +270,31 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
     seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt);
     bool act[kSlots];
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
+    T den[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) den[j] = cnt[j];
+    if (eq_row) {  // wave-uniform, simplex_eq in the reference-compatibility mode only (see eq_bucket, fused_common.h)
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            // sum < z: theta < 0, the whole column is the support (count = its length) and so are the padding zeros
+            const int len = (int)cnt[j];
+            const T L = (T)eq_row[eq_bucket(len > 0 ? len : 1)];
+            den[j] = (sumA[j] < pj.z) ? L : cnt[j];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
+        const bool padded = den[j] != cnt[j];
         const bool feas = ineq && !(sumA[j] > pj.ztol);   // keep the clamped values
-        const bool onehot = cnt[j] == (T)1;               // z at the maximum, 0 elsewhere (exact z, as the reference)
+        const bool onehot = cnt[j] == (T)1 && !padded;    // z at the maximum, 0 elsewhere (exact z, as the reference)
         const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-        const T th1 = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
-        const bool gen = !feas && cnt[j] > (T)1;
+        const T th1 = div_exactish((T)(sumA[j] - pj.z), den[j]);
+        const bool gen = !feas && (cnt[j] > (T)1 || padded);
         th[j] = gen ? th1 : th[j];
         const T xg = relu((T)(u[j] - th[j]));
         T r = (!feas && onehot) ? xv : u[j];
         x[j] = gen ? xg : r;
-        act[j] = gen && cnt[j] > (T)2;
+        act[j] = gen && cnt[j] > (T)2 && !padded;
     }
     // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
     // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.

@@ -69,11 +69,19 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
 
     With ``b_vec=None`` it computes only the local partial sums (A x, c.x, gamma/2 ||x||^2) -- the building block of
     the distributed objective, as in the reference (matching.py:57-58, 179-184).
+
+    ``batching`` is accepted for signature compatibility; the fused pass has no buckets.  It only matters together with
+    ``simplex_eq_padding="reference"``: by default a ``simplex_eq`` entry is the exact projection onto
+    {x >= 0, sum x = z} over each column's own entries; the reference projects inside zero-padded blocks, one per
+    nnz-bucket (``batching=True``: buckets (0,2], (2,4], (4,8], ...) or one per entry (``batching=False``), so a clamped
+    column that sums to less than z has its deficit spread over the block height instead of its own length
+    (SURVEY.md 8a P4).  ``"reference"`` reproduces that, block heights computed from the column lengths as the
+    reference does (matching.py:87-114, sparse_utils.py:185-186).
     """
 
     _dualip_native = True
 
-    def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True):
+    def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True, simplex_eq_padding: str = "exact"):
         A, c = matching_input_args.A, matching_input_args.c
         if A.layout != torch.sparse_csc or c.layout != torch.sparse_csc:
             raise ValueError("Both A and c must be CSC-format sparse tensors")
@@ -134,6 +142,40 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         self._packed = torch.zeros(self.m + 2, dtype=torch.float64, device=self.device)
         self._scal = torch.zeros(6, dtype=torch.float64, device=self.device)
         self._primal = None  # allocated on the first save_primal, then reused (the reference aliases its scratch too)
+        if simplex_eq_padding not in ("exact", "reference"):
+            raise ValueError("simplex_eq_padding must be 'exact' or 'reference'")
+        self.simplex_eq_padding = simplex_eq_padding
+        if simplex_eq_padding == "reference" and any(e.proj_type == "simplex_eq" for e in self.projection_map.values()):
+            heights = self._padded_block_heights(colptr).cpu().contiguous()
+            with torch.cuda.device(self.device):
+                _hip.check(lib.dl_matching_set_eq_padding(handle, heights.data_ptr(), heights.shape[0], _hip.stream_ptr(self.device)))
+
+    def _padded_block_heights(self, colptr: torch.Tensor) -> torch.Tensor:
+        """int32 [n_entries, 32]: height of the reference's zero-padded block for every (entry, nnz-bucket)."""
+        lengths = (colptr[1:] - colptr[:-1]).to(torch.int64)
+        thresholds = [0]
+        i = 1
+        while 2**i <= self.m:                      # matching.py:93-99
+            thresholds.append(2**i)
+            i += 1
+        thresholds.append(self.m + 1)
+        th = torch.tensor(thresholds, dtype=torch.int64, device=self.device)
+        out = torch.zeros((len(self.projection_map), 32), dtype=torch.int64, device=self.device)
+        for q, entry in enumerate(self.projection_map.values()):
+            if entry.proj_type != "simplex_eq":
+                continue
+            idx = entry.indices
+            idx = torch.arange(idx.start, idx.stop, idx.step, device=self.device) if isinstance(idx, range) else torch.as_tensor(idx, dtype=torch.int64, device=self.device)
+            lens = lengths[idx]
+            lens = lens[lens > 0]
+            if lens.numel() == 0:
+                continue
+            if self.batching:
+                bucket = torch.bucketize(lens, th).clamp_(max=31)        # matching.py:104, right=False
+                out[q].scatter_reduce_(0, bucket, lens, reduce="amax")   # L = longest column of the bucket (sparse_utils.py:186)
+            else:
+                out[q, :] = lens.max()                                   # one block per entry
+        return out.to(torch.int32)
 
     # ------------------------------------------------------------------------------------------------------
     def __del__(self):

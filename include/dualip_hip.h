@@ -101,6 +101,12 @@ int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, doub
  * returns the number of launches and their summed duration in milliseconds since the hook was (re-)enabled. */
 int dl_matching_profile(dl_matching* h, int enable);
 int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host);
+/* simplex_eq reference-compatibility mode.  By default "simplex_eq" is the exact projection onto
+ * {x >= 0, sum x = z} over the column's own entries.  The reference projects inside a zero-padded [L x K] block per
+ * nnz-bucket (sparse_utils.py:185-209; matching.py:87-114), so when a clamped column sums to less than z its deficit is
+ * spread over L >= len entries.  heights_host[q*32 + j] = L of projection entry q for bucket j = bucketize(len, [0,2,4,8,..])
+ * (j = 1 for len <= 2, else ceil(log2 len)); n_rows = number of projection entries.  NULL restores the exact projection. */
+int dl_matching_set_eq_padding(dl_matching* h, const int32_t* heights_host, int32_t n_rows, dl_stream_t stream);
 /* Developer aid (handles created with DUALIP_HIP_TIMELINE=1 in the environment): per-workgroup 100 MHz wall-clock
  * stamps of the LAST fused launch, out_host[4*wg + {0,1,2,3}] = start, prologue done, tile loop done, end.
  * Synchronises the device. */

@@ -132,3 +132,24 @@ def lp_small_entries(z):
         ("cone", {"upper": 0.75}, z["idx_up"]),
         ("box", {"lower": 0.25, "upper": 2.0}, z["idx_lu_names"]),
     ]
+
+
+def padded_eq_entries(p, zz, batching):
+    """Oracle description of the reference's zero-padded ``simplex_eq`` blocks: one oracle entry per nnz-bucket
+    (``batching``) or a single one, each with ``lblock`` = the longest column it holds (matching.py:87-114,
+    sparse_utils.py:185-186).  Returns (entries, lblocks, col_proj)."""
+    lens = np.diff(p["colptr"])
+    if not batching:
+        return [("simplex_eq", {"z": zz})], [int(lens.max())], np.zeros(p["n"], dtype=np.int32)
+    th = [0]
+    i = 1
+    while 2**i <= p["m"]:
+        th.append(2**i)
+        i += 1
+    th.append(p["m"] + 1)
+    bucket = np.searchsorted(np.array(th), lens, side="left")  # torch.bucketize(right=False)
+    ids = sorted(set(int(b) for b in bucket[lens > 0]))
+    remap = {b: k for k, b in enumerate(ids)}
+    col_proj = np.array([remap.get(int(b), 0) for b in bucket], dtype=np.int32)
+    lblocks = [int(lens[bucket == b].max()) for b in ids]
+    return [("simplex_eq", {"z": zz})] * len(ids), lblocks, col_proj

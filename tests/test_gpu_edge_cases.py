@@ -153,3 +153,27 @@ def test_all_columns_empty():
     res = f.calculate(lam, save_primal=True)
     assert torch.allclose(res.dual_gradient, -torch.from_numpy(p["b"]).to(DEV))
     assert abs(float(res.dual_objective) + float((lam.cpu() * torch.from_numpy(p["b"])).sum())) < 1e-12 and res.primal_var.numel() == 0
+
+
+@pytest.mark.parametrize("batching", [True, False])
+def test_simplex_eq_reference_padding_with_long_columns(batching):
+    """The padded-block mode through the single-column path (columns of 300-1500 non-zeros) and ordinary tiles, against the
+    oracle's padded blocks (one oracle entry per nnz-bucket / one for the whole map)."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import padded_eq_entries
+
+    m, n = 2_000, 3_000
+    p = _random_problem(m, n, 10, seed=33, long_cols=((1, 300), (17, 1500), (1999, 257)), empty_every=13)
+    lam = np.random.default_rng(8).uniform(0, 0.01, m)
+    zz = 400.0  # far above most clamped column sums: the padding decides the result
+    entries, _, col_proj = padded_eq_entries(p, zz, batching)
+    for dn in ("f32", "f64"):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map("simplex_eq", {"z": zz}, n), DEV), gamma=0.03, batching=batching,
+                                                simplex_eq_padding="reference")
+        td = torch.float32 if dn == "f32" else torch.float64
+        res = f.calculate(torch.from_numpy(lam).to(td).to(DEV), save_primal=True)
+        ax, obj0, ssq, x = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.03, entries, col_proj=col_proj, dtype=NP_DT[dn])
+        grad = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], 0.03, NP_DT[dn])[0]
+        assert relerr(res.primal_var.cpu().numpy(), x) < RTOL[dn]
+        assert relerr(res.dual_gradient.cpu().numpy(), grad) < RTOL[dn]

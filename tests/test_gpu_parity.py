@@ -443,3 +443,30 @@ def test_benchmark_scale_properties(kind):
     proj = ("box", {"lower": 0.0, "upper": 1.0}) if (kind == "box" or (kind == "mixed" and hi <= half)) else ("simplex", {"z": 1.0})
     _, _, _, xo = oracle.matching_calculate(10_000, hi - lo, sub["colptr"], sub["rowidx"], sub["a"], sub["c"], lam.cpu().numpy(), gamma, [proj], dtype=np.float32)
     assert relerr(x[cp[0] : cp[-1]].cpu().numpy(), xo) < 2e-4
+
+
+@pytest.mark.parametrize("batching", [True, False])
+def test_simplex_eq_reference_padding_mode(batching, scan_mode):
+    """``simplex_eq_padding="reference"``: the deficit of a column that sums to less than z is spread over the height of
+    the reference's zero-padded block (per nnz-bucket, or per entry with batching=False) -- golden ge_simplex_eq.npz."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    z = load("g1_syn2000.npz")
+    ge = load("ge_simplex_eq.npz")
+    p = problem(z)
+    for dn in NP_DT:
+        for zz in (1.0, 40.0):
+            f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map("simplex_eq", {"z": zz}, p["n"]), DEV), gamma=0.1,
+                                                    batching=batching, simplex_eq_padding="reference")
+            for ln in ("zero", "small"):
+                res = f.calculate(torch.from_numpy(z[f"lam_{ln}"]).to(TD[dn]).to(DEV), gamma=0.1, save_primal=True)
+                key = f"{zz}|{int(batching)}|{ln}|{dn}"
+                assert relerr(res.dual_gradient.cpu().numpy(), ge[f"{key}|grad"]) < RTOL[dn], key
+                assert relerr(res.primal_var.cpu().numpy(), ge[f"{key}|x"]) < RTOL[dn], key
+                assert relerr([float(res.dual_objective), float(res.reg_penalty)], ge[f"{key}|scal"]) < RTOL[dn] * 10, key
+    # the default stays the exact projection: every non-empty column sums to z
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex_eq", {"z": 40.0}, p["n"]), DEV), gamma=0.1)
+    x = f.calculate(torch.zeros(p["m"], dtype=torch.float64, device=DEV), save_primal=True).primal_var.cpu().numpy()
+    sums = np.add.reduceat(x, p["colptr"][:-1][np.diff(p["colptr"]) > 0])
+    assert np.allclose(sums, 40.0, atol=1e-9)

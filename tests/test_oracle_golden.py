@@ -156,3 +156,25 @@ def test_movielens_like_trace_f64():
     assert relerr(r["dual_obj_log"][:60], z["f64|dual_obj_log"][:60]) < 1e-10
     assert np.allclose(r["step_log"][:60], z["f64|step_log"][:60], rtol=1e-9)
     assert relerr(r["dual_obj_log"], z["f64|dual_obj_log"]) < 1e-3
+
+
+def test_simplex_eq_padded_blocks_match_reference():
+    """``simplex_eq`` inside the reference's matching objective depends on the zero-padded block height:
+    the oracle with one entry per nnz-bucket (batching) or a single entry reproduces tests/golden/ge_simplex_eq.npz."""
+    from tests.helpers import padded_eq_entries
+
+    z = load("g1_syn2000.npz")
+    ge = load("ge_simplex_eq.npz")
+    p = problem(z)
+    for dn, dt in NP_DT.items():
+        for zz in (1.0, 40.0):
+            for batching in (1, 0):
+                entries, _, col_proj = padded_eq_entries(p, zz, bool(batching))
+                for ln in ("zero", "small"):
+                    grad, x, scal = _calc(p, entries, z[f"lam_{ln}"], 0.1, dt, col_proj=col_proj)
+                    key = f"{zz}|{batching}|{ln}|{dn}"
+                    assert relerr(grad, ge[f"{key}|grad"]) < RTOL[dn], key
+                    assert relerr(x, ge[f"{key}|x"]) < RTOL[dn], key
+                    assert relerr(scal[:2], ge[f"{key}|scal"]) < RTOL[dn] * 10, key
+    # the two modes really differ on this problem (z = 40: most columns sum to less than z)
+    assert np.abs(ge["40.0|1|zero|f64|x"] - ge["40.0|0|zero|f64|x"]).max() > 1.0

@@ -28,7 +28,8 @@ __global__ void k(const float* v, const uint64_t* heads, const int* counts, floa
         pj[q] = make_proj<float>(DL_PROJ_SIMPLEX, z, 0.0);
         xx[q] = vv[q];
     }
-    simplex_batch<DPP>(vv, valid, hd, pj, smp, lc, xx);
+    const int32_t* eq_row[kBatch] = {};
+    simplex_batch<DPP>(vv, valid, hd, pj, smp, lc, xx, eq_row);
     for (int q = 0; q < kBatch; ++q) x[(b * kBatch + q) * 64 + lane] = valid[q] ? xx[q] : 0.f;
 }
 
