@@ -270,31 +270,38 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
     seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt);
     bool act[kSlots];
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
-    T den[kSlots];
-#pragma unroll
-    for (int j = 0; j < kSlots; ++j) den[j] = cnt[j];
-    if (eq_row) {  // wave-uniform, simplex_eq in the reference-compatibility mode only (see eq_bucket, fused_common.h)
+    if (!eq_row) {
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            // sum < z: theta < 0, the whole column is the support (count = its length) and so are the padding zeros
+            const bool feas = ineq && !(sumA[j] > pj.ztol);   // keep the clamped values
+            const bool onehot = cnt[j] == (T)1;               // z at the maximum, 0 elsewhere (exact z, as the reference)
+            const T xv = (u[j] > th[j]) ? pj.z : (T)0;
+            const T th1 = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
+            const bool gen = !feas && cnt[j] > (T)1;
+            th[j] = gen ? th1 : th[j];
+            const T xg = relu((T)(u[j] - th[j]));
+            T r = (!feas && onehot) ? xv : u[j];
+            x[j] = gen ? xg : r;
+            act[j] = gen && cnt[j] > (T)2;
+        }
+    } else {
+        // simplex_eq in the reference-compatibility mode (wave-uniform, cold; see eq_bucket in fused_common.h): a column
+        // whose clamped entries sum to less than z has theta < 0 -- its whole length is the support (count = length) and
+        // so are the padding zeros of the reference's block, so the deficit is divided by the block height L
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
             const int len = (int)cnt[j];
             const T L = (T)eq_row[eq_bucket(len > 0 ? len : 1)];
-            den[j] = (sumA[j] < pj.z) ? L : cnt[j];
+            const bool padded = sumA[j] < pj.z;
+            const bool onehot = cnt[j] == (T)1 && !padded;
+            const T xv = (u[j] > th[j]) ? pj.z : (T)0;
+            const T th1 = div_exactish((T)(sumA[j] - pj.z), padded ? L : cnt[j]);
+            const bool gen = cnt[j] > (T)1 || padded;
+            th[j] = gen ? th1 : th[j];
+            const T xg = relu((T)(u[j] - th[j]));
+            x[j] = gen ? xg : (onehot ? xv : u[j]);
+            act[j] = gen && cnt[j] > (T)2 && !padded;
         }
-    }
-#pragma unroll
-    for (int j = 0; j < kSlots; ++j) {
-        const bool padded = den[j] != cnt[j];
-        const bool feas = ineq && !(sumA[j] > pj.ztol);   // keep the clamped values
-        const bool onehot = cnt[j] == (T)1 && !padded;    // z at the maximum, 0 elsewhere (exact z, as the reference)
-        const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-        const T th1 = div_exactish((T)(sumA[j] - pj.z), den[j]);
-        const bool gen = !feas && (cnt[j] > (T)1 || padded);
-        th[j] = gen ? th1 : th[j];
-        const T xg = relu((T)(u[j] - th[j]));
-        T r = (!feas && onehot) ? xv : u[j];
-        x[j] = gen ? xg : r;
-        act[j] = gen && cnt[j] > (T)2 && !padded;
     }
     // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
     // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.
