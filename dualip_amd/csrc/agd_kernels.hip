@@ -81,11 +81,11 @@ __global__ __launch_bounds__(kAgdThreads) void dual_epilogue_kernel(int64_t m, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// one AGD iteration (agd.py:163-187; agd_utils.py:12-89) as three small multi-workgroup launches:
+// one AGD iteration (agd.py:163-187; agd_utils.py:12-89) as two small multi-workgroup launches:
 //   stats    rows in parallel: [sum the integer gradient slabs ->] g = A x - b, per-workgroup partial reductions
-//   finalize one workgroup: sums the partials in a fixed order, runs the scalar step-size logic, logs
-//   update   rows in parallel: projected ascent step + momentum
-// (a single-workgroup kernel doing all three took 37 us at m = 10^4: it is latency bound on one CU)
+//   apply    every workgroup: sums the partials in a fixed order and runs the scalar step-size logic (workgroup 0 logs and
+//            writes the next state), then its rows' projected ascent step + momentum            (agd_apply_kernel below)
+// (a single-workgroup kernel doing all of it took 37 us at m = 10^4: it is latency bound on one CU)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kStatRows = 64;      // rows per stats workgroup
 constexpr int kStatSlices = 16;    // slab slices per stats workgroup (1024 threads)

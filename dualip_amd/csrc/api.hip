@@ -387,7 +387,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         return fail(DL_E_ARG, "too many tiles");
     }
 
-    // ---- workgroups: one per CU, contiguous tile ranges of equal non-zero count ----
+    // ---- workgroups: one per CU.  Layout 1: contiguous tile ranges of equal cost (wg_tile_begin); layout 4: descriptors in
+    //      schedule order, dealt cyclically to the wavefronts (schedule_tiles4) ----
     hipDeviceProp_t prop;
     CKH(hipGetDeviceProperties(&prop, h->device));
     int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -2,7 +2,7 @@
 
 Reference: src/dualip/optimizers/agd_utils.py:4-89.  The function names and signatures of the reference module are
 kept for callers and tests; the native matching path does not use this file -- its step size is computed on the
-device by ``agd_step_kernel`` (csrc/agd_kernels.hip) with the same rule.
+device by ``agd_stats_kernel`` + ``agd_apply_kernel`` (csrc/agd_kernels.hip) with the same rule.
 
 Rule: keep the last ``max_history_length`` (gradient, dual) pairs; L_j = ||g_{j+1}-g_j|| / ||y_{j+1}-y_j|| for
 consecutive pairs; fewer than ``max_history_length - 1`` estimates -> initial_step_size; otherwise
