@@ -43,3 +43,5 @@ print("earliest-finishing WGs", order[:8], us[order[:8], 2])
 print("latest-finishing WGs", order[-8:], us[order[-8:], 2])
 q = np.linspace(0, len(d) - 1, 17).astype(int)
 print("loop-done by wg (every 16th):", np.round(us[q, 2], 0))
+xcd = np.arange(len(us)) % 8
+print("loop-done mean by XCD (us):", np.round([us[xcd == k, 2].mean() for k in range(8)], 1), " overall mean %.1f max %.1f" % (us[:, 2].mean(), us[:, 2].max()))
