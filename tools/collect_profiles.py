@@ -1,4 +1,4 @@
-"""Developer tool: copy the summaries tools_profile.sh left under gpurun_out/prof_<tag>/ into profiles/ (tracked) and rebuild
+"""Developer tool: copy the summaries tools/profile.sh left under gpurun_out/prof_<tag>/ into profiles/ (tracked) and rebuild
 profiles/traffic.json.   usage: python tools/collect_profiles.py"""
 import csv
 import json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_profile.sh <tag> [bench args...]
+# usage (on the GPU box, from the repo root): bash tools/profile.sh <tag> [bench args...]
 # kernel-trace stats pass + two PMC passes of the same bench command; only summaries are kept under gpurun_out/prof_<tag>/
 set -u
 TAG=$1; shift
