@@ -177,3 +177,26 @@ def test_simplex_eq_reference_padding_with_long_columns(batching):
         grad = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], 0.03, NP_DT[dn])[0]
         assert relerr(res.primal_var.cpu().numpy(), x) < RTOL[dn]
         assert relerr(res.dual_gradient.cpu().numpy(), grad) < RTOL[dn]
+
+
+def test_results_are_bit_reproducible():
+    """The gradient is accumulated in 64-bit fixed point (integer atomics are associative): repeated launches, and two
+    independently built handles, return identical bits -- the reference's scatter_add_ on a GPU does not."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 500, 40_000
+    p = _random_problem(m, n, 10, seed=77)
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=range(0, n // 2)),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=range(n // 2, n)),
+    }
+    lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.02, m)).float().to(DEV)
+    outs = []
+    for _ in range(2):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.02)
+        for _ in range(3):
+            r = f.calculate(lam, save_primal=True)
+            outs.append((r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective)))
+    for g, x, o in outs[1:]:
+        assert torch.equal(g, outs[0][0]) and torch.equal(x, outs[0][1]) and o == outs[0][2]
