@@ -150,7 +150,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
                     const int32_t* eqh = kernarg_args(g).eq_heights;
                     eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
                 }
+                // the instruction-bound section runs at raised issue priority: measured 2-4 % on all-simplex maps, neutral on
+                // mixed ones (the inverse -- loads first -- measured slower)
+                __builtin_amdgcn_s_setprio(2);
                 simplex_tile4(v, sg, pj, lc, x, eq_row);
+                __builtin_amdgcn_s_setprio(0);
             } else {
 #pragma unroll
                 for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
