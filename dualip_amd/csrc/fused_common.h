@@ -60,14 +60,6 @@ __device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax
     atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
 }
 
-// ---- simplex_eq "padded block" compatibility (dl_matching_set_eq_padding) ----
-// The reference projects a column inside a zero-padded [L x K] block, L = the longest column of the column's bucket
-// (sparse_utils.py:185-209; buckets by nnz: (0,2], (2,4], (4,8], ... matching.py:87-114).  For simplex_eq the padding is
-// visible exactly when the clamped column sums to less than z: the deficit is then spread over L entries instead of the
-// column's own.  bucket(len) = bucketize(len, [0, 2, 4, ...]) = 1 for len <= 2, else ceil(log2(len)).
-constexpr int kEqBuckets = 32;
-__device__ __forceinline__ int eq_bucket(int len) { return len <= 2 ? 1 : 32 - __clz(len - 1); }
-
 template <class P>
 __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
     return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing

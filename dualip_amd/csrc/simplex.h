@@ -66,6 +66,14 @@ __device__ __forceinline__ float div_exactish(float num, float den) {
     return fmaf(fmaf(-den, q, num), r, q);        // one residual correction
 }
 
+// ---- simplex_eq "padded block" compatibility (dl_matching_set_eq_padding) ----
+// The reference projects a column inside a zero-padded [L x K] block, L = the longest column of the column's bucket
+// (sparse_utils.py:185-209; buckets by nnz: (0,2], (2,4], (4,8], ... matching.py:87-114).  For simplex_eq the padding is
+// visible exactly when the clamped column sums to less than z: the deficit is then spread over L entries instead of the
+// column's own.  bucket(len) = bucketize(len, [0, 2, 4, ...]) = 1 for len <= 2, else ceil(log2(len)).
+constexpr int kEqBuckets = 32;
+__device__ __forceinline__ int eq_bucket(int len) { return len <= 2 ? 1 : 32 - __clz(len - 1); }
+
 __device__ __forceinline__ bool is_simplex_kind(int k) { return k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ; }
 
 // ---- per-lane constants of the segment machinery (computed once per kernel) ----

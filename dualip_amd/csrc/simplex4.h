@@ -243,16 +243,19 @@ __device__ __forceinline__ int end_lane4(const Seg4& s, const LaneConst& c) {
 // Simplex projection of every column of a 256-element tile (see simplex.h for the algorithm and the reference lines).
 //   v must already be 0 in slots that hold no element of the tile (they form dummy segments of zeros);
 //   every slot of x is written.
-// Two reduction rounds serve almost every tile: MAX (theta_0 = max - z), then SUM and COUNT over {u > theta_0} issued
-// together (two independent dependency chains, one LDS wait).  feasible <=> sum <= z + 1e-6 (simplex.py:153-158);
-// vertex <=> count == 1 (simplex.py:177-193); count == 2 => theta_1 = (sum - z)/2 is final (the runner-up stays above
-// theta_1 exactly when it is above max - z); larger supports run monotone Newton passes that end on a ballot.
+// Two reduction rounds serve most tiles: MAX (theta_0 = max - z), then SUM and COUNT over {u > theta_0} issued together
+// (two independent dependency chains, one LDS wait).  feasible <=> sum <= z + 1e-6 (simplex.py:153-158); vertex <=>
+// count == 1 (simplex.py:177-193); count == 2 => theta = (sum - z)/2 is final (the runner-up stays above it exactly
+// when it is above max - z); larger supports run monotone Newton (Michelot) passes.  A pass is kept cheap -- late in a
+// solve almost every tile holds a column that needs two or three: the state of a column is (S, C) = (sum of its support
+// - z, size of its support), membership is tested as u * C > S (no division inside the loop), a pass is only run when a
+// ballot says some member dropped out, and theta = S / C and x are formed once, after the loop.
 // Few boolean masks are kept alive on purpose: every per-slot flag is an SGPR pair and the kernel is SGPR-starved.
 template <class T>
 __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& s, const ProjT<T>& pj, const LaneConst& lc, T (&x)[kSlots],
                                               const int32_t* eq_row = nullptr) {
     const int el = end_lane4(s, lc);
-    T u[kSlots], th[kSlots], sumA[kSlots], cnt[kSlots], inu[kSlots], ind[kSlots];
+    T u[kSlots], th0[kSlots], S[kSlots], C[kSlots], inu[kSlots], ind[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) u[j] = relu_finite(v[j]);  // max(v, 0), and no infinity (see SegMul4)
     {
@@ -260,73 +263,69 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
         seg_allreduce4(u, s, el, OpMaxNonNeg(), v1);
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            th[j] = (T)(v1[j] - pj.z);
-            const bool in = u[j] > th[j];
+            th0[j] = (T)(v1[j] - pj.z);
+            const bool in = u[j] > th0[j];
             inu[j] = in ? u[j] : (T)0;
             ind[j] = in ? (T)1 : (T)0;
         }
     }
     const SegMul4<T> sm = make_segmul4<T>(s);
+    T sumA[kSlots], cnt[kSlots];
     seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt);
+    // Column state (S, C): theta = S / C.  "Keep the clamped values" is encoded as (0, 2) -- theta = 0 returns u itself --
+    // and C == 1 marks a vertex, so no per-slot flag besides `act` has to live across the Newton loop.
     bool act[kSlots];
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
     if (!eq_row) {
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            const bool feas = ineq && !(sumA[j] > pj.ztol);   // keep the clamped values
-            const bool onehot = cnt[j] == (T)1;               // z at the maximum, 0 elsewhere (exact z, as the reference)
-            const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-            const T th1 = div_exactish((T)(sumA[j] - pj.z), cnt[j]);
-            const bool gen = !feas && cnt[j] > (T)1;
-            th[j] = gen ? th1 : th[j];
-            const T xg = relu((T)(u[j] - th[j]));
-            T r = (!feas && onehot) ? xv : u[j];
-            x[j] = gen ? xg : r;
-            act[j] = gen && cnt[j] > (T)2;
+            const bool keep = ineq && !(sumA[j] > pj.ztol);
+            act[j] = !keep && cnt[j] > (T)2;
+            S[j] = keep ? (T)0 : (T)(sumA[j] - pj.z);
+            C[j] = keep ? (T)2 : cnt[j];
         }
     } else {
-        // simplex_eq in the reference-compatibility mode (wave-uniform, cold; see eq_bucket in fused_common.h): a column
-        // whose clamped entries sum to less than z has theta < 0 -- its whole length is the support (count = length) and
-        // so are the padding zeros of the reference's block, so the deficit is divided by the block height L
+        // simplex_eq in the reference-compatibility mode (wave-uniform, cold; see eq_bucket in simplex.h): a column whose
+        // clamped entries sum to less than z has theta < 0 -- its whole length is the support (count = length) and so
+        // are the padding zeros of the reference's block, so the deficit is divided by the block height L
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             const int len = (int)cnt[j];
             const T L = (T)eq_row[eq_bucket(len > 0 ? len : 1)];
             const bool padded = sumA[j] < pj.z;
-            const bool onehot = cnt[j] == (T)1 && !padded;
-            const T xv = (u[j] > th[j]) ? pj.z : (T)0;
-            const T th1 = div_exactish((T)(sumA[j] - pj.z), padded ? L : cnt[j]);
-            const bool gen = cnt[j] > (T)1 || padded;
-            th[j] = gen ? th1 : th[j];
-            const T xg = relu((T)(u[j] - th[j]));
-            x[j] = gen ? xg : (onehot ? xv : u[j]);
-            act[j] = gen && cnt[j] > (T)2 && !padded;
+            act[j] = cnt[j] > (T)2 && !padded;
+            S[j] = (T)(sumA[j] - pj.z);
+            C[j] = padded ? L : cnt[j];
         }
     }
-    // Larger supports: a pass is only needed if some member of the support fell to or below the new threshold
-    // (the support can only shrink).  That test is a ballot -- no reduction -- and is what ends almost every tile.
     for (int it = 0; it < kTile4; ++it) {
-        bool dropped = false;
-#pragma unroll
-        for (int j = 0; j < kSlots; ++j) dropped = dropped || (act[j] && ind[j] != (T)0 && !(u[j] > th[j]));
-        if (!__any(dropped)) break;
-        T cnt2[kSlots];
+        bool in[kSlots], dropped = false;
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            const bool in = u[j] > th[j];
-            ind[j] = in ? (T)1 : (T)0;
-            inu[j] = in ? u[j] : (T)0;
+            in[j] = (T)(u[j] * C[j]) > S[j];  // u > S / C
+            dropped = dropped || (act[j] && ind[j] != (T)0 && !in[j]);
         }
-        seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt2);
+        if (!__any(dropped)) break;  // no support changed: every (S, C) is final
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            const bool changed = act[j] && cnt2[j] != cnt[j] && cnt2[j] != (T)0;
-            const T th_new = div_exactish((T)(sumA[j] - pj.z), cnt2[j]);
-            th[j] = changed ? th_new : th[j];
-            cnt[j] = changed ? cnt2[j] : cnt[j];
-            x[j] = changed ? relu((T)(u[j] - th[j])) : x[j];
+            ind[j] = in[j] ? (T)1 : (T)0;
+            inu[j] = in[j] ? u[j] : (T)0;
+        }
+        seg_allreduce4_sum2(inu, ind, s, sm, el, sumA, cnt);
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            const bool changed = act[j] && cnt[j] != C[j] && cnt[j] != (T)0;
+            S[j] = changed ? (T)(sumA[j] - pj.z) : S[j];
+            C[j] = changed ? cnt[j] : C[j];
             act[j] = changed;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const T th = div_exactish(S[j], C[j]);
+        const T xg = relu((T)(u[j] - th));
+        const T xv = (u[j] > th0[j]) ? pj.z : (T)0;  // vertex: z at the maximum, 0 elsewhere (exact z, as the reference)
+        x[j] = C[j] == (T)1 ? xv : xg;
     }
 }
 
