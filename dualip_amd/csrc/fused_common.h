@@ -32,7 +32,7 @@ struct FusedArgs {
     int64_t nnz;
     int32_t n_proj;
     uint32_t n_tiles;   // layout 4: tiles of the launch (cyclic schedule)
-    int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
+    int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
 };
