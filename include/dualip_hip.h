@@ -71,9 +71,11 @@ int dl_version(void);
 /* Replaces MatchingSolverDualObjectiveFunction.__init__/_compute_buckets (src/dualip/objectives/matching.py:43-114).
  *   A and c are CSC (m x n) with the SAME pattern: colptr[n+1], rowidx[nnz] (idx_dtype), a[nnz], c[nnz] (val_dtype);
  *   one primal variable per stored non-zero.  a and c are referenced, not copied (the reference keeps references
- *   too; Jacobi pre-conditioning applied in place before or after creation is seen).  rowidx is re-encoded once to
- *   uint16 (m <= 65536) or uint32; colptr is consumed once to build the wave-tile table (<= 64 non-zeros of whole
- *   columns per wavefront, tiles never mix projection entries) that replaces the reference's power-of-two buckets.
+ *   too) and must not change afterwards: their maxima and the row histogram, taken here, bound the fixed-point
+ *   gradient accumulators -- apply Jacobi pre-conditioning BEFORE creating the handle.  rowidx is re-encoded once to
+ *   uint16 (m <= 65536) or uint32; colptr is consumed once to build the wave-tile table (16-byte aligned windows of
+ *   <= 256 non-zeros of whole columns, four per lane; <= 64 non-zeros, one per lane, when a / c are not 16-byte aligned
+ *   or nnz < 1024; tiles never mix projection entries) that replaces the reference's power-of-two buckets.
  *   col_proj: int32[n], index into projs_host per column, -1 = no entry; NULL = every column uses projs_host[0].
  * Synchronises `stream` once (one-off host-side tile packing). */
 int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx,
