@@ -100,6 +100,10 @@ struct StatsArgs {
     const int* __restrict__ shift_in;
     int n_slabs, n_scal;
     int64_t mpad;
+    // hot-rows plan of the matching handle (inv != null): slab column p is the caller's row inv[p]; columns >= m_hot are in `cold`
+    const int32_t* __restrict__ inv;
+    int64_t m_hot;
+    const long long* __restrict__ cold;
     // ... or an already reduced (and, when sharded, all-reduced) packed buffer
     const double* __restrict__ packed_in;
     double* __restrict__ packed_out;  // [m+2]: written when reducing slabs (kept for logging / callers)
@@ -119,14 +123,21 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     const int tid = threadIdx.x;
     const int rl = tid & (kStatRows - 1);
     const int ws = tid / kStatRows;
-    const int64_t row = (int64_t)blockIdx.x * kStatRows + rl;
+    const int64_t col = (int64_t)blockIdx.x * kStatRows + rl;  // slab column
+    const bool live = col < p.m;
+    int64_t row = col;                                           // the caller's row
+    if constexpr (FROM_SLABS) {
+        if (p.inv && live) row = p.inv[col];
+    }
     double ax = 0.0;
     if constexpr (FROM_SLABS) {
         long long acc = 0;
         {   // latency bound: eight slabs in flight before the first is added (slabs past the end re-read the last one)
-            const int64_t rc = row < p.m ? row : p.m - 1;
+            const int64_t rc = live ? col : p.m - 1;
+            const bool in_slabs = !p.inv || rc < p.m_hot;
+            if (!in_slabs && ws == 0) acc = p.cold[rc];
             constexpr int kU = 8;
-            for (int w0 = ws; w0 < p.n_slabs; w0 += kStatSlices * kU) {
+            for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
                 long long v[kU];
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
@@ -139,18 +150,18 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
         }
         shi[tid] = acc;
         __syncthreads();
-        if (ws == 0 && row < p.m) {
+        if (ws == 0 && live) {
             long long t = shi[rl];
             for (int q = 1; q < kStatSlices; ++q) t += shi[q * kStatRows + rl];
             ax = ldexp((double)t, -(*p.shift_in));
             p.packed_out[row] = ax;
         }
     } else {
-        if (ws == 0 && row < p.m) ax = p.packed_in[row];
+        if (ws == 0 && live) ax = p.packed_in[row];
     }
     const bool has_prev = p.st->steps_done > 0;
     double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
-    if (ws == 0 && row < p.m) {
+    if (ws == 0 && live) {
         const T gj = (T)((T)ax - p.b[row]);
         dvtg = (double)(T)(p.x[row] * gj);
         gmax = (double)gj;
@@ -500,6 +511,9 @@ static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed,
         sa.n_slabs = f ? (f->grad_lds ? f->n_wg : 1) : 0;
         sa.n_scal = f ? f->n_wg : 0;
         sa.mpad = f ? f->mpad : 0;
+        sa.inv = (f && f->m_hot > 0) ? f->row_inv : nullptr;
+        sa.m_hot = f ? f->m_hot : 0;
+        sa.cold = f ? f->cold_grad : nullptr;
         sa.packed_in = packed;
         sa.packed_out = s->packed;
         sa.b = (const T*)b;

@@ -65,6 +65,12 @@ __global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, 
     }
 }
 
+// hot-rows plan: re-encoded row ids -> ids renumbered by frequency (in place, one-off)
+template <class DstT>
+__global__ void remap_rows_kernel(int64_t nnz, DstT* __restrict__ rows, const int32_t* __restrict__ perm) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) rows[k] = (DstT)perm[rows[k]];
+}
+
 template <class SrcT>
 static int reencode_rows(dl_matching* h, const void* rowidx, hipStream_t st, int* bad_dev, unsigned int* row_count) {
     const int threads = 256;
@@ -97,6 +103,9 @@ static void matching_free(dl_matching* h) {
     if (h->shift_dev) (void)hipFree(h->shift_dev);
     if (h->timeline) (void)hipFree(h->timeline);
     if (h->eq_heights) (void)hipFree(h->eq_heights);
+    if (h->row_inv) (void)hipFree(h->row_inv);
+    if (h->lam_perm) (void)hipFree(h->lam_perm);
+    if (h->cold_grad) (void)hipFree(h->cold_grad);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
     delete h;
@@ -427,6 +436,33 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         h->grad_lds = false;
     }
     h->lds_bytes = lds_need(h->lam_lds, h->grad_lds);
+    // hot-rows plan (256-wide layout): when the dual vector and the gradient do not both fit the LDS, renumber the rows by
+    // frequency and keep the m_hot most frequent ones in LDS; the cold tail goes through L2 gathers and global atomics.
+    // DUALIP_HIP_HOT_ROWS: "0" disables the plan, "N" forces m_hot = N (testing).
+    {
+        const char* hot_env = getenv("DUALIP_HIP_HOT_ROWS");
+        int64_t forced = hot_env ? atoll(hot_env) : -1;
+        const bool allowed = h->layout == 4 && nnz > 0 && max_mode >= 2 && forced != 0;
+        int64_t m_hot = 0;
+        if (allowed && forced > 0 && forced < m && fused_lds_bytes(forced, val_dtype, true, true) <= kLdsBudget) {
+            m_hot = forced;
+        } else if (allowed && !(h->lam_lds && h->grad_lds)) {
+            int64_t lo = 0, hi = m;  // largest row count whose dual vector + gradient fit
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) / 2;
+                if (fused_lds_bytes(mid, val_dtype, true, true) <= kLdsBudget) lo = mid;
+                else hi = mid - 1;
+            }
+            m_hot = lo / 64 * 64;
+            if (m_hot < 1024 || m_hot >= m) m_hot = 0;
+        }
+        if (m_hot > 0) {
+            h->m_hot = m_hot;
+            h->lam_lds = true;
+            h->grad_lds = true;
+            h->lds_bytes = fused_lds_bytes(m_hot, val_dtype, true, true);
+        }
+    }
     h->mpad = (m + 63) / 64 * 64;
     if (h->mpad == 0) h->mpad = 64;
 
@@ -445,6 +481,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * sizeof(long long)));
     CK(owned_malloc(h, (void**)&h->shift_dev, 2 * sizeof(unsigned long long) + sizeof(int)));
     CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    if (h->m_hot > 0) {
+        CK(owned_malloc(h, (void**)&h->row_inv, sizeof(int32_t) * (size_t)m));
+        CK(owned_malloc(h, &h->lam_perm, (size_t)m * (val_dtype == DL_F32 ? 4 : 8)));
+        CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad));
+    }
     if (getenv("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
@@ -501,6 +542,34 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     memcpy(&h->amax, &mx_host[0], sizeof(double));
     memcpy(&h->cmax, &mx_host[1], sizeof(double));
     for (unsigned int v : row_count_h) h->row_count_max = v > (unsigned int)h->row_count_max ? (int64_t)v : h->row_count_max;
+    if (h->m_hot > 0) {
+        // renumber rows by descending non-zero count (stable): new id < m_hot <=> the row lives in LDS
+        std::vector<int32_t> inv((size_t)m), perm((size_t)m);
+        for (int64_t i = 0; i < m; ++i) inv[(size_t)i] = (int32_t)i;
+        std::stable_sort(inv.begin(), inv.end(), [&](int32_t x, int32_t y) { return row_count_h[(size_t)x] > row_count_h[(size_t)y]; });
+        for (int64_t pnew = 0; pnew < m; ++pnew) perm[(size_t)inv[(size_t)pnew]] = (int32_t)pnew;
+        int32_t* perm_dev = nullptr;
+        e = hipMalloc((void**)&perm_dev, sizeof(int32_t) * (size_t)m);
+        if (e == hipSuccess) e = hipMemcpyAsync(perm_dev, perm.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->row_inv, inv.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            const int threads = 256;
+            const int64_t b64 = (nnz + threads - 1) / threads;
+            const int blocks = (int)(b64 > 8192 ? 8192 : (b64 > 0 ? b64 : 1));
+            if (h->row_bytes == 2) hipLaunchKernelGGL(remap_rows_kernel<uint16_t>, dim3(blocks), dim3(threads), 0, st, nnz, (uint16_t*)h->rowidx, perm_dev);
+            else hipLaunchKernelGGL(remap_rows_kernel<uint32_t>, dim3(blocks), dim3(threads), 0, st, nnz, (uint32_t*)h->rowidx, perm_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // perm / inv are host temporaries
+        if (perm_dev) (void)hipFree(perm_dev);
+        if (e != hipSuccess) {
+            matching_free(h);
+            return hip_fail(e, "row renumbering");
+        }
+        uint64_t hot_nnz = 0;
+        for (int64_t pnew = 0; pnew < h->m_hot; ++pnew) hot_nnz += row_count_h[(size_t)inv[(size_t)pnew]];
+        h->hot_fraction = nnz > 0 ? (double)hot_nnz / (double)nnz : 1.0;
+    }
     // |x| bounds per projection kind: box -> max(|lower|, |upper|); simplex -> z (+ slack); cone / identity -> via |v| per launch
     bool used_none = false;
     std::vector<char> used((size_t)(n_proj > 0 ? n_proj : 1), 0);
@@ -553,6 +622,8 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 6: return h->n_long;
         case 7: return h->row_bytes;
         case 8: return h->layout;
+        case 9: return h->m_hot;
+        case 10: return (int64_t)(h->hot_fraction * 1e6);
         default: return -1;
     }
 }

@@ -92,6 +92,13 @@ struct dl_matching {
     size_t owned_bytes = 0;
     bool use_dpp = true;
     int ablate = 0;  // developer-only timing ablations, see FusedArgs
+    // "hot rows" plan (dual vector / gradient too large for the LDS): rows renumbered by frequency, the m_hot most frequent
+    // ones live in LDS, the cold tail goes through L2 (gathers) and 64-bit global atomics (cold_grad)
+    int64_t m_hot = 0;                // 0 = plan not in use
+    double hot_fraction = 1.0;        // share of the non-zeros whose row is hot
+    int32_t* row_inv = nullptr;       // owned, [m]: renumbered row -> caller's row
+    void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
+    long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
     int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)
     unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches

@@ -34,6 +34,8 @@ struct FusedArgs {
     uint32_t n_tiles;   // layout 4: tiles of the launch (cyclic schedule)
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
+    int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does
+    long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed)
     const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
 };
 
@@ -68,13 +70,13 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 // Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
 template <class T, class RowT, bool LAM_LDS>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
-                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr) {
+                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0) {
     const bool is_simplex = is_simplex_kind(pj.kind);
     auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
         av = g.a[k];
         cv = g.c[k];
         rv = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
-        const T lam = LAM_LDS ? lam_s[rv] : (T)(s * g.lambda[rv]);
+        const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv < m_hot)) ? lam_s[rv] : (T)(s * g.lambda[rv]);
         T v = (T)(av * lam);
         return (T)(v + (T)(s * cv));
     };
@@ -137,7 +139,10 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             x = project_pointwise(v, pj);
         }
         const T ax = (T)(av * x);
-        if (ax != (T)0) scatter_fixed(gacc, rv, ax, scale);
+        if (ax != (T)0) {
+            if (m_hot == 0 || (int64_t)rv < m_hot) scatter_fixed(gacc, rv, ax, scale);
+            else scatter_fixed(g.cold_grad, rv, ax, scale);
+        }
         obj += (double)(T)(cv * x);
         ssq += (double)(T)(x * x);
         if (g.x_out) g.x_out[k0 + o] = x;
@@ -163,10 +168,11 @@ template <class T, bool LAM_LDS, bool GRAD_LDS>
 __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsigned char* smem, int tid, int lane, int wave, int wg) {
     WgCtx<T> w;
     // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
+    const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;  // rows that live in LDS (all of them unless the hot-rows plan is on)
     w.grad_s = reinterpret_cast<long long*>(smem);
-    size_t off = GRAD_LDS ? (size_t)g.m * 8 : 0;
+    size_t off = GRAD_LDS ? (size_t)m_lds * 8 : 0;
     w.lam_s = reinterpret_cast<T*>(smem + off);
-    off += LAM_LDS ? (size_t)g.m * sizeof(T) : 0;
+    off += LAM_LDS ? (size_t)m_lds * sizeof(T) : 0;
     off = (off + 15) / 16 * 16;
     w.proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
     off += (size_t)kProjLds * sizeof(ProjT<T>);
@@ -186,7 +192,9 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
             for (int u = 0; u < kU; ++u) {
                 const int64_t i = i0 + (int64_t)u * kFusedThreads;
                 if (i < g.m) {
-                    if constexpr (LAM_LDS) w.lam_s[i] = (T)(w.s * l[u]);
+                    if constexpr (LAM_LDS) {
+                        if (i < m_lds) w.lam_s[i] = (T)(w.s * l[u]);
+                    }
                     const double al = fabs((double)l[u]);
                     lmax = al > lmax ? al : lmax;
                 }
@@ -194,7 +202,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         }
     }
     if constexpr (GRAD_LDS) {
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) w.grad_s[i] = 0;
+        for (int64_t i = tid; i < m_lds; i += kFusedThreads) w.grad_s[i] = 0;
     }
     for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
         w.proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
@@ -247,7 +255,8 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
     }
     if constexpr (GRAD_LDS) {
         long long* slab = g.partial + (int64_t)wg * g.mpad;
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) slab[i] = w.grad_s[i];
+        const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;
+        for (int64_t i = tid; i < m_lds; i += kFusedThreads) slab[i] = w.grad_s[i];
     }
 }
 

@@ -263,9 +263,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
 constexpr int kRedThreads = 1024;
 constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
 
+// Hot-rows plan (inv != null): slab column p belongs to the caller's row inv[p]; columns >= m_hot hold nothing -- their sums
+// are in `cold` (one int64 per row, global atomics).
 __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
-                                                                      double* __restrict__ packed) {
+                                                                      double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
+                                                                      const long long* __restrict__ cold) {
     __shared__ long long shi[kRedThreads];
     __shared__ double sh[kRedThreads / 32];
     const int tid = threadIdx.x;
@@ -275,9 +278,11 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         const int64_t row = (int64_t)blockIdx.x * kRedRows + rl;
         const int64_t rc = row < m ? row : (m > 0 ? m - 1 : 0);
         long long acc = 0;
+        const bool in_slabs = !inv || rc < m_hot;
+        if (!in_slabs && ws == 0) acc = cold[rc];
         // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
         constexpr int kU = 8, kStride = kRedThreads / kRedRows;
-        for (int w0 = ws; w0 < n_slabs; w0 += kStride * kU) {
+        for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
             long long v[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         if (ws == 0 && row < m) {
             long long t = shi[rl];
             for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
-            packed[row] = ldexp((double)t, -(*shift_in));
+            packed[inv ? (int64_t)inv[row] : row] = ldexp((double)t, -(*shift_in));
         }
         return;
     }
@@ -382,6 +387,12 @@ int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipSt
 static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) { return launch_fused4_f32(h, args, st); }
 static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) { return launch_fused4_f64(h, args, st); }
 
+template <class T>
+__global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, const int32_t* __restrict__ inv, T* __restrict__ dst) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < m) dst[p] = src[inv[p]];
+}
+
 // the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
 template <class T>
 static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
@@ -412,6 +423,15 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.ablate = h->ablate;
     args.timeline = h->timeline;
     args.eq_heights = h->eq_heights;
+    args.m_hot = h->m_hot;
+    args.cold_grad = h->cold_grad;
+    if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
+        const unsigned blocks = (unsigned)((h->m + 255) / 256);
+        hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
+        DL_HIP(hipGetLastError());
+        DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad, st));
+        args.lambda = static_cast<const T*>(h->lam_perm);
+    }
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
     hipEvent_t ev_stop = nullptr;
     if (h->prof_on) {
@@ -452,7 +472,7 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
-                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out);
+                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad);
     DL_HIP(hipGetLastError());
     return 0;
 }

@@ -43,7 +43,9 @@ __device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, in
     if (tl && tid == 0) tl[4 * (size_t)wg + k] = wall_clock64();
 }
 
-template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS>
+// HOT: the hot-rows plan (common.h) -- rows are renumbered by frequency, rows < g.m_hot gather from / scatter to LDS, the
+// cold tail reads the (renumbered) dual vector through L2 and adds to g.cold_grad with 64-bit global atomics.
+template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool HOT>
 __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             row[j] = (uint32_t)cur.r.v[j];
-            lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+            if constexpr (HOT) lam[j] = (int64_t)row[j] < g.m_hot ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+            else lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
         }
         const uint32_t dv_cur_next = dv_next;
         dv_next = load_desc(ti + 2u * S);
@@ -164,7 +167,14 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             for (int j = 0; j < kSlots; ++j) {
                 const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
                 const T ax = (T)(cur.a.v[j] * xq);
-                if (ax != (T)0) scatter_fixed(w.gacc, row[j], ax, w.scale);
+                if (ax != (T)0) {
+                    if constexpr (HOT) {
+                        if ((int64_t)row[j] < g.m_hot) scatter_fixed(w.gacc, row[j], ax, w.scale);
+                        else scatter_fixed(g.cold_grad, row[j], ax, w.scale);
+                    } else {
+                        scatter_fixed(w.gacc, row[j], ax, w.scale);
+                    }
+                }
                 o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
                 q32 = (T)(q32 + (T)(xq * xq));
                 x[j] = xq;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const uint64_t k0 = (((uint64_t)cur.w0hi << 32) | cur.w0lo) & ((1ull << 40) - 1);
             const uint64_t len = ((uint64_t)rl(cur.dv, 3) << 32) | rl(cur.dv, 2);
             const int32_t* eq_row = (gk.eq_heights && pid != kNoProj && pid != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pid * kEqBuckets : nullptr;
-            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row);
+            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0);
         }
         ti += S;
     };
@@ -203,9 +213,9 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     }
 }
 
-template <class T, class RowT, bool LAM, bool GRAD>
+template <class T, class RowT, bool LAM, bool GRAD, bool HOT>
 static int launch_fused4_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
-    auto kern = matching_fused_kernel4<T, RowT, LAM, GRAD>;
+    auto kern = matching_fused_kernel4<T, RowT, LAM, GRAD, HOT>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
@@ -218,9 +228,10 @@ static int launch_fused4_inst(const dl_matching* h, const FusedArgs<T>& args, hi
 
 template <class T, class RowT>
 static int launch_fused4_rt(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
-    if (h->lam_lds && h->grad_lds) return launch_fused4_inst<T, RowT, true, true>(h, args, st);
-    if (h->grad_lds) return launch_fused4_inst<T, RowT, false, true>(h, args, st);
-    return launch_fused4_inst<T, RowT, false, false>(h, args, st);
+    if (h->m_hot > 0) return launch_fused4_inst<T, RowT, true, true, true>(h, args, st);
+    if (h->lam_lds && h->grad_lds) return launch_fused4_inst<T, RowT, true, true, false>(h, args, st);
+    if (h->grad_lds) return launch_fused4_inst<T, RowT, false, true, false>(h, args, st);
+    return launch_fused4_inst<T, RowT, false, false, false>(h, args, st);
 }
 
 int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {

@@ -50,17 +50,28 @@ def _compare(p, pm, entries, col_proj, gamma, dn, lam, scale=1.0):
     return f
 
 
-def test_more_than_65536_rows():
+@pytest.mark.parametrize("hot", [True, False])
+def test_more_than_65536_rows(hot, monkeypatch):
+    """32-bit row indices; the dual vector and the gradient do not fit the LDS: hot-rows plan, or (plan disabled) global atomics."""
+    import os
+
     from dualip_amd.projections import create_projection_map
 
+    if not hot:
+        monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "0")
     m, n = 70_000, 6_000
     p = _random_problem(m, n, 9, seed=5)
     lam = np.random.default_rng(1).uniform(0, 0.01, m)
+    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"
     for dn in ("f32", "f64"):
         for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0})):
             f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
             info = f.info()
-            assert info["row_index_bytes"] == 4 and info["lambda_in_lds"] == 0 and info["grad_in_lds"] == 0, info
+            assert info["row_index_bytes"] == 4
+            if hot and not narrow:
+                assert info["hot_rows"] > 0 and info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1, info
+            else:
+                assert info["hot_rows"] == 0 and info["lambda_in_lds"] == 0 and info["grad_in_lds"] == 0, info
 
 
 def test_more_projection_entries_than_the_lds_table():
@@ -200,3 +211,72 @@ def test_results_are_bit_reproducible():
             outs.append((r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective)))
     for g, x, o in outs[1:]:
         assert torch.equal(g, outs[0][0]) and torch.equal(x, outs[0][1]) and o == outs[0][2]
+
+
+def _skewed_problem(m, n, mean_deg, seed):
+    """Rows drawn from a heavy-tailed popularity law (a few destinations get most of the edges)."""
+    rng = np.random.default_rng(seed)
+    w = rng.lognormal(0.0, 1.5, m)
+    w /= w.sum()
+    deg = np.minimum(rng.poisson(mean_deg, n), 64).astype(np.int64)
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    rows = []
+    for j in range(n):
+        r = np.unique(rng.choice(m, size=int(deg[j]), p=w)) if deg[j] else np.zeros(0, dtype=np.int64)
+        rows.append(r)
+        colptr[j + 1] = colptr[j] + r.size
+    rows = np.concatenate(rows).astype(np.int64)
+    nnz = rows.size
+    return dict(m=m, n=n, colptr=colptr, rowidx=rows, a=rng.uniform(0.05, 1.0, nnz), c=-rng.uniform(0.01, 0.5, nnz), b=rng.uniform(0.5, 2.0, m))
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_hot_rows_plan(forced, monkeypatch):
+    """Dual vector + gradient larger than the LDS: rows renumbered by frequency, the hot ones in LDS, the cold tail on L2
+    gathers / global atomics.  Natural case: 30 000 dual rows; forced case: a small problem with only 128 hot rows.
+    Checked: one calculate() (slab reduction with the inverse permutation) and a device-resident AGD run (stats kernel
+    reading the renumbered slabs) against the oracle."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if forced:
+        monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "128")
+        p = _skewed_problem(700, 5_000, 9, seed=41)
+    else:
+        p = _skewed_problem(30_000, 8_000, 12, seed=42)
+    m, n = p["m"], p["n"]
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=list(range(0, n // 2))),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(n // 2, n))),
+    }
+    entries = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})]
+    col_proj = np.zeros(n, dtype=np.int32)
+    col_proj[n // 2 :] = 1
+    lam = np.random.default_rng(5).uniform(0, 0.02, m)
+    import os
+
+    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the plan belongs to the 256-wide layout; the numbers must agree anyway)
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.05, dn, lam)
+        info = f.info()
+        if narrow:
+            assert info["hot_rows"] == 0
+            continue
+        assert info["hot_rows"] == (128 if forced else info["hot_rows"]) and 0 < info["hot_rows"] < m, info
+        assert info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1
+        if not forced:
+            assert info["hot_nnz_ppm"] > 500_000  # the frequent rows carry most of the non-zeros
+    # device-resident AGD over the renumbered slabs
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, DEV), gamma=0.05)
+    solver = AcceleratedGradientDescent(max_iter=40, gamma=0.05, initial_step_size=1e-4, max_step_size=1e-2, iteration_callback=False)
+    res = solver.maximize(f, torch.zeros(m, dtype=torch.float64, device=DEV))
+
+    def calc(lam_, gamma):
+        ax, obj0, ssq, _ = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam_, gamma, entries, col_proj=col_proj, dtype=np.float64, want_x=False)
+        grad, obj, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam_, p["b"], gamma, np.float64)
+        return grad, obj, None
+
+    want = agd_oracle.maximize(calc, np.zeros(m), 40, 0.05, initial_step_size=1e-4, max_step_size=1e-2, dtype=np.float64)
+    assert relerr(res.dual_objective_log, want["dual_obj_log"]) < 1e-8
+    assert relerr(res.dual_val.cpu().numpy(), want["dual_val"]) < 1e-8
