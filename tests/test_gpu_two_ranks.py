@@ -1,0 +1,101 @@
+"""Two ranks on ONE GPU (``-m gpu``): the N > 1 route of the maximiser with the real HIP local pass on every rank.
+
+RCCL does not put two ranks on the same device, so the process group is gloo (it all-reduces device tensors through
+host staging); everything else is what an 8-GPU run executes per rank: column shard -> fused pass -> slab reduction ->
+ONE sum-all-reduce of [A x | c.x | sum x^2] -> the identical device-side AGD step on both ranks.  Expected values: the
+golden traces the reference's own distributed objective produced under gloo (tests/golden/g3_syn2000.npz), for the plain
+simplex map and for the mixed map split at the key boundary.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, kind, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunctionDistributed
+        from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+        from dualip_amd.projections import create_projection_map
+        from dualip_amd.utils.dist_utils import balanced_block_ranges, global_to_local_projection_map
+        from tests.helpers import load, problem, sub_problem, torch_args
+
+        z = load("g3_syn2000.npz")
+        p = problem(z)
+        gamma, iters, s0, s1 = z["params"]
+        n = p["n"]
+        if kind == "mixed":
+            half = int(z["mixed_boundary"])
+            pm = {
+                **create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)),
+                **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n)),
+            }
+            # every rank takes its share of BOTH blocks (what bench.py does): two column ranges per rank
+            ranges = balanced_block_ranges([(0, half), (half, n)], world, rank)
+        else:
+            pm = create_projection_map("simplex", {"z": 1.0}, n)
+            ranges = balanced_block_ranges([(0, n)], world, rank)
+        # local problem = concatenation of the rank's column ranges
+        parts = [sub_problem(p, lo, hi) for lo, hi in ranges]
+        colptr = [np.zeros(1, dtype=np.int64)]
+        for q_ in parts:
+            colptr.append(q_["colptr"][1:] + colptr[-1][-1])
+        local = dict(m=p["m"], n=sum(q_["n"] for q_ in parts), colptr=np.concatenate(colptr), rowidx=np.concatenate([q_["rowidx"] for q_ in parts]),
+                     a=np.concatenate([q_["a"] for q_ in parts]), c=np.concatenate([q_["c"] for q_ in parts]), b=p["b"])
+        cols = [c for lo, hi in ranges for c in range(lo, hi)]
+        local_pm = global_to_local_projection_map(pm, cols)
+        args = torch_args(local, "f64", local_pm, "cuda:0", with_b=False)
+        f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0")
+        solver = AcceleratedGradientDescent(max_iter=int(iters), gamma=float(gamma), initial_step_size=float(s0), max_step_size=float(s1), iteration_callback=False)
+        res = solver.maximize(f, torch.zeros(p["m"], dtype=torch.float64, device="cuda:0"), rank=rank)
+        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), f.local_objective.info()["layout"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["simplex", "mixed"])
+def test_two_ranks_share_one_gpu(kind):
+    from tests.helpers import load, relerr
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = {}
+    for _ in procs:
+        rank, log, dual, layout = q.get()
+        out[rank] = (log, dual, layout)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    z = load("g3_syn2000.npz")
+    key = "simplex1|w2|f64" if kind == "simplex" else "mixed|w2|f64"
+    want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
+    # both ranks apply the identical update: identical duals, bit for bit, without a broadcast
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    assert relerr(out[0][0], want_log) < 1e-7, kind
+    assert relerr(out[0][1], want_dual) < 1e-6, kind
