@@ -167,6 +167,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # developer aid: DUALIP_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with gloo collectives (RCCL refuses two ranks on one
+    # device) -- a functional check of the N > 1 harness on a single-GPU box; the number it prints is not a result
+    one_device = os.environ.get("DUALIP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -174,7 +179,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
@@ -229,7 +237,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if sharded:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**({} if one_device else {"device_ids": [local_rank]}))
         torch.cuda.synchronize()
 
     fence()
@@ -310,7 +318,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if sharded:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**({} if one_device else {"device_ids": [local_rank]}))
         dist.destroy_process_group()
 
 
