@@ -67,29 +67,46 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
     return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
 }
 
-// Long tile: one column with more than 64 non-zeros, walked in 64-wide strides by the whole wavefront.
+// Long tile: one column too long for a window, walked by the whole wavefront.  The walk is latency bound (one wavefront,
+// dependent loads), so it moves in batches of four 64-wide strides whose loads are all issued before the first is used;
+// data are re-read (L2-hot) for every Newton pass.  Per-lane partial sums run over the strides in ascending order.
 template <class T, class RowT, bool LAM_LDS>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0) {
+    constexpr int kLB = 4;
     const bool is_simplex = is_simplex_kind(pj.kind);
-    auto value_at = [&](uint64_t k, T& av, T& cv, uint32_t& rv) -> T {
-        av = g.a[k];
-        cv = g.c[k];
-        rv = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
-        const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv < m_hot)) ? lam_s[rv] : (T)(s * g.lambda[rv]);
-        T v = (T)(av * lam);
-        return (T)(v + (T)(s * cv));
+    // v = a * (-lambda/gamma) + (-c/gamma) for the elements o0 + lane + 64 u (ok[u]: inside the column)
+    auto load_batch = [&](uint64_t o0, T (&av)[kLB], T (&cv)[kLB], uint32_t (&rv)[kLB], bool (&ok)[kLB], T (&v)[kLB]) {
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            const uint64_t o = o0 + (uint64_t)lane + 64u * (uint64_t)u;
+            ok[u] = o < len;
+            const uint64_t k = k0 + (ok[u] ? o : len - 1);
+            av[u] = g.a[k];
+            cv[u] = g.c[k];
+            rv[u] = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
+        }
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv[u] < m_hot)) ? lam_s[rv[u]] : (T)(s * g.lambda[rv[u]]);
+            v[u] = (T)((T)(av[u] * lam) + (T)(s * cv[u]));
+        }
     };
     T th = (T)0;
     bool projected = false, onehot = false;
     if (is_simplex) {
         T S = (T)0, v1 = (T)(-INFINITY);
-        for (uint64_t o = lane; o < len; o += 64) {
-            T av, cv;
-            uint32_t rv;
-            const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
-            S = (T)(S + u);
-            v1 = tmax(v1, u);
+        for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
+            T av[kLB], cv[kLB], v[kLB];
+            uint32_t rv[kLB];
+            bool ok[kLB];
+            load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+            for (int u = 0; u < kLB; ++u) {
+                const T uu = tmax(v[u], (T)0);
+                S = ok[u] ? (T)(S + uu) : S;
+                v1 = ok[u] ? tmax(v1, uu) : v1;
+            }
         }
         S = wave_allreduce(S, OpAdd());
         v1 = wave_allreduce(v1, OpMax());
@@ -104,13 +121,17 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             for (int it = 0; it < 4096; ++it) {
                 T sumA = (T)0;
                 long long cntl = 0;
-                for (uint64_t o = lane; o < len; o += 64) {
-                    T av, cv;
-                    uint32_t rv;
-                    const T u = tmax(value_at(k0 + o, av, cv, rv), (T)0);
-                    if (u > th) {
-                        sumA = (T)(sumA + u);
-                        cntl += 1;
+                for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
+                    T av[kLB], cv[kLB], v[kLB];
+                    uint32_t rv[kLB];
+                    bool ok[kLB];
+                    load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+                    for (int u = 0; u < kLB; ++u) {
+                        const T uu = tmax(v[u], (T)0);
+                        const bool in = ok[u] && uu > th;
+                        sumA = in ? (T)(sumA + uu) : sumA;
+                        cntl += in ? 1 : 0;
                     }
                 }
                 sumA = wave_allreduce(sumA, OpAdd());
@@ -120,32 +141,40 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
                     break;
                 }
                 if (cntw == cnt_prev || cntw == 0) break;
-                th = (T)((T)(sumA - z) / (T)cntw);
+                // Michelot's thresholds never decrease in exact arithmetic; enforcing it in floating point keeps the supports
+                // nested, so the loop ends after at most `len` passes (without it a value within rounding of the threshold
+                // can leave and re-enter the support for thousands of passes -- measured on ratings-like data with ties)
+                th = tmax(th, (T)((T)(sumA - z) / (T)cntw));
                 cnt_prev = cntw;
             }
         }
     }
-    for (uint64_t o = lane; o < len; o += 64) {
-        T av, cv;
-        uint32_t rv;
-        const T v = value_at(k0 + o, av, cv, rv);
-        T x;
-        if (is_simplex) {
-            const T u = tmax(v, (T)0);
-            if (!projected) x = u;
-            else if (onehot) x = (u > th) ? pj.z : (T)0;
-            else x = tmax((T)(u - th), (T)0);
-        } else {
-            x = project_pointwise(v, pj);
+    for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
+        T av[kLB], cv[kLB], v[kLB];
+        uint32_t rv[kLB];
+        bool ok[kLB];
+        load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            if (!ok[u]) continue;
+            T x;
+            if (is_simplex) {
+                const T uu = tmax(v[u], (T)0);
+                if (!projected) x = uu;
+                else if (onehot) x = (uu > th) ? pj.z : (T)0;
+                else x = tmax((T)(uu - th), (T)0);
+            } else {
+                x = project_pointwise(v[u], pj);
+            }
+            const T ax = (T)(av[u] * x);
+            if (ax != (T)0) {
+                if (m_hot == 0 || (int64_t)rv[u] < m_hot) scatter_fixed(gacc, rv[u], ax, scale);
+                else scatter_fixed(g.cold_grad, rv[u], ax, scale);
+            }
+            obj += (double)(T)(cv[u] * x);
+            ssq += (double)(T)(x * x);
+            if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + 64u * (uint64_t)u] = x;
         }
-        const T ax = (T)(av * x);
-        if (ax != (T)0) {
-            if (m_hot == 0 || (int64_t)rv < m_hot) scatter_fixed(gacc, rv, ax, scale);
-            else scatter_fixed(g.cold_grad, rv, ax, scale);
-        }
-        obj += (double)(T)(cv * x);
-        ssq += (double)(T)(x * x);
-        if (g.x_out) g.x_out[k0 + o] = x;
     }
 }
 

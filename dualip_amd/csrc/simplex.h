@@ -190,7 +190,7 @@ __device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (
                     const bool feas = it == 0 && pj[q].kind == DL_PROJ_SIMPLEX && !(sumA > pj[q].ztol);
                     const bool upd = act[q] && !feas && cnt != 0;
                     proj[q] = proj[q] || upd;
-                    th[q] = upd ? th_new : th[q];
+                    th[q] = upd ? tmax(th_new, th[q]) : th[q];  // thresholds never decrease: nested supports, guaranteed termination
                     cnt_prev[q] = upd ? cnt : cnt_prev[q];
                     act[q] = upd;
                 }

@@ -302,7 +302,8 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
         bool in[kSlots], dropped = false;
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            in[j] = (T)(u[j] * C[j]) > S[j];  // u > S / C
+            in[j] = ind[j] != (T)0 && (T)(u[j] * C[j]) > S[j];  // still a member: u > S / C (supports only shrink, which also
+                                                               // rules out a rounding-induced leave / re-enter cycle)
             dropped = dropped || (act[j] && ind[j] != (T)0 && !in[j]);
         }
         if (!__any(dropped)) break;  // no support changed: every (S, C) is final
