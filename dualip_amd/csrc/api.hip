@@ -386,7 +386,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     if (h->layout == 4) {
         CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long));
         h->n_tiles = (int64_t)(words4.size() / 12);
-        words4.resize(words4.size() + 12, 0u);  // one all-zero descriptor: what schedule slots past the end read
     } else {
         CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
         h->n_tiles = (int64_t)tiles.size();
@@ -406,7 +405,23 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int64_t want = (h->n_tiles + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
     h->n_wg = (int)(want < n_cu ? want : n_cu);
     if (h->n_wg < 1) h->n_wg = h->n_tiles > 0 ? 1 : 0;
-    if (h->layout == 4 && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(words4, tile_pid4, projs_host, n_proj, h->n_wg);
+    if (h->layout == 4) {
+        // descriptor array = [window tiles in schedule order | one all-zero descriptor (what slots past the end read) |
+        // single-column tiles]: the single-column walker runs in its own loop, outside the hot one
+        std::vector<uint32_t> short_words, long_words, short_pid, long_pid;
+        for (size_t t = 0; t < tile_pid4.size(); ++t) {
+            const bool is_long = (words4[t * 12 + 1] & (1u << 19)) != 0;
+            (is_long ? long_words : short_words).insert((is_long ? long_words : short_words).end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
+            (is_long ? long_pid : short_pid).push_back(tile_pid4[t]);
+        }
+        if (!getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
+        h->n_short = (int64_t)short_pid.size();
+        words4 = short_words;
+        words4.resize(words4.size() + 12, 0u);
+        words4.insert(words4.end(), long_words.begin(), long_words.end());
+        tile_pid4 = short_pid;
+        tile_pid4.insert(tile_pid4.end(), long_pid.begin(), long_pid.end());
+    }
     std::vector<uint32_t> wg_begin((size_t)h->n_wg + 1, 0);
     {
         const uint64_t total = prefix.back();

@@ -77,6 +77,7 @@ struct dl_matching {
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;
     int64_t n_tiles = 0, n_long = 0;
+    int64_t n_short = 0;                // layout 4: window tiles (the single-column ones follow them in the descriptor array)
     int n_wg = 0;
     bool lam_lds = false, grad_lds = false;
     size_t lds_bytes = 0;

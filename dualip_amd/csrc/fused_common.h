@@ -31,7 +31,8 @@ struct FusedArgs {
     int64_t mpad;
     int64_t nnz;
     int32_t n_proj;
-    uint32_t n_tiles;   // layout 4: tiles of the launch (cyclic schedule)
+    uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
+    uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does

@@ -9,7 +9,8 @@
 //   * segment structure = four wave-uniform 64-bit head masks; all predicates are scalar mask arithmetic (simplex4.h).
 // Descriptor: 12 dwords { W[39:0] | hi<<40 | lo<<49 | long<<51 ; H0 ; H1 ; H2 ; H3 ; proj id ; 0 } (long: length in H0).
 // Columns that cannot sit in a window (longer than 253, touching the array's last partial quad, or using a projection
-// entry beyond the LDS table) are single-column "long" tiles handled by process_long_tile.
+// entry beyond the LDS table) are single-column "long" tiles: their descriptors follow the window tiles (after one all-zero
+// descriptor) and are walked by process_long_tile in a separate loop ahead of the hot one.
 #include "fused_common.h"
 #include "simplex4.h"
 
@@ -83,9 +84,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     auto window_of = [&](uint32_t w0lo, uint32_t w0hi) -> uint64_t {  // element index of the window start (0 for padding / long tiles)
         const uint32_t hi = (w0hi >> 8) & 0x1FF;
-        const bool is_long = (w0hi & (1u << 19)) != 0;
         const uint64_t W = ((uint64_t)(w0hi & 0xFFu) << 32) | w0lo;
-        return (hi == 0 || is_long) ? 0ull : W;
+        return hi == 0 ? 0ull : W;
     };
     auto unpack_and_issue = [&](uint32_t dv, Tile& t) {
         t.dv = dv;
@@ -110,6 +110,18 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
     stamp(g, wg, tid, 1);
     const T s = w.s;
+    // ---- single-column tiles first, in their own loop: their walker is large, latency-bound code that must not sit inside
+    //      the hot loop (measured: inlined there, the extra instruction footprint cost the window tiles 6 %) ----
+    for (uint32_t lt = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave; lt < g.n_long; lt += S) {
+        const FusedArgs<T>& gk = kernarg_args(g);
+        const uint32_t dvl = byte_offset(g.tiles32 + (size_t)(n_tiles + 1u + lt) * kDesc4Words, dlane * 4u)[0];
+        const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
+        const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
+        const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
+        const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
+        const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
+        process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0);
+    }
     if (ti < n_tiles) unpack_and_issue(dv0, tA);
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
     // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
@@ -130,70 +142,60 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         unpack_and_issue(dv_cur_next, nxt);
 
         const uint32_t hi = (cur.w0hi >> 8) & 0x1FF, lo = (cur.w0hi >> 17) & 3;
-        const bool is_long = (cur.w0hi & (1u << 19)) != 0;
         const uint32_t pid = rl(cur.dv, 10);
-        if (!is_long) {
-            const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
-            const int kind = __builtin_amdgcn_readfirstlane(pj.kind);
-            T v[kSlots], x[kSlots];
-            const uint32_t e0 = 4u * (uint32_t)lane - lo, span = hi - lo;  // element j of the lane is in the tile iff e0 + j < span
+        const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+        const int kind = __builtin_amdgcn_readfirstlane(pj.kind);
+        T v[kSlots], x[kSlots];
+        const uint32_t e0 = 4u * (uint32_t)lane - lo, span = hi - lo;  // element j of the lane is in the tile iff e0 + j < span
 #pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
-                const T vj = (T)(t1 + (T)(s * cur.c.v[j]));  // matching.py:66,142
-                v[j] = (e0 + (uint32_t)j < span) ? vj : (T)0;
+        for (int j = 0; j < kSlots; ++j) {
+            const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
+            const T vj = (T)(t1 + (T)(s * cur.c.v[j]));  // matching.py:66,142
+            v[j] = (e0 + (uint32_t)j < span) ? vj : (T)0;
+        }
+        if (is_simplex_kind(kind)) {
+            uint64_t H[kSlots];
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
+            const Seg4 sg = make_seg4(H);
+            const int32_t* eq_row = nullptr;
+            if (kind == DL_PROJ_SIMPLEX_EQ) {  // cold: the pointer is re-read from the kernel arguments
+                const int32_t* eqh = kernarg_args(g).eq_heights;
+                eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
             }
-            if (is_simplex_kind(kind)) {
-                uint64_t H[kSlots];
-#pragma unroll
-                for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
-                const Seg4 sg = make_seg4(H);
-                const int32_t* eq_row = nullptr;
-                if (kind == DL_PROJ_SIMPLEX_EQ) {  // cold: the pointer is re-read from the kernel arguments
-                    const int32_t* eqh = kernarg_args(g).eq_heights;
-                    eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
-                }
-                // the instruction-bound section runs at raised issue priority: measured 2-4 % on all-simplex maps, neutral on
-                // mixed ones (the inverse -- loads first -- measured slower)
-                __builtin_amdgcn_s_setprio(2);
-                simplex_tile4(v, sg, pj, lc, x, eq_row);
-                __builtin_amdgcn_s_setprio(0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
-            }
-            T o32 = (T)0, q32 = (T)0;
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
-                const T ax = (T)(cur.a.v[j] * xq);
-                if (ax != (T)0) {
-                    if constexpr (HOT) {
-                        if ((int64_t)row[j] < g.m_hot) scatter_fixed(w.gacc, row[j], ax, w.scale);
-                        else scatter_fixed(g.cold_grad, row[j], ax, w.scale);
-                    } else {
-                        scatter_fixed(w.gacc, row[j], ax, w.scale);
-                    }
-                }
-                o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
-                q32 = (T)(q32 + (T)(xq * xq));
-                x[j] = xq;
-            }
-            obj += (double)o32;
-            ssq += (double)q32;
-            if (g.x_out) {
-                T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
-#pragma unroll
-                for (int j = 0; j < kSlots; ++j)
-                    if (e0 + (uint32_t)j < span) xw[4 * (uint32_t)lane + j] = x[j];  // neighbours own the rest of the quad
-            }
+            // the instruction-bound section runs at raised issue priority: measured 2-4 % on all-simplex maps, neutral on
+            // mixed ones (the inverse -- loads first -- measured slower)
+            __builtin_amdgcn_s_setprio(2);
+            simplex_tile4(v, sg, pj, lc, x, eq_row);
+            __builtin_amdgcn_s_setprio(0);
         } else {
-            const FusedArgs<T>& gk = kernarg_args(g);
-            const ProjT<T> pl = lookup_proj(gk, w.proj_s, pid);
-            const uint64_t k0 = (((uint64_t)cur.w0hi << 32) | cur.w0lo) & ((1ull << 40) - 1);
-            const uint64_t len = ((uint64_t)rl(cur.dv, 3) << 32) | rl(cur.dv, 2);
-            const int32_t* eq_row = (gk.eq_heights && pid != kNoProj && pid != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pid * kEqBuckets : nullptr;
-            process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0);
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
+        }
+        T o32 = (T)0, q32 = (T)0;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
+            const T ax = (T)(cur.a.v[j] * xq);
+            if (ax != (T)0) {
+                if constexpr (HOT) {
+                    if ((int64_t)row[j] < g.m_hot) scatter_fixed(w.gacc, row[j], ax, w.scale);
+                    else scatter_fixed(g.cold_grad, row[j], ax, w.scale);
+                } else {
+                    scatter_fixed(w.gacc, row[j], ax, w.scale);
+                }
+            }
+            o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
+            q32 = (T)(q32 + (T)(xq * xq));
+            x[j] = xq;
+        }
+        obj += (double)o32;
+        ssq += (double)q32;
+        if (g.x_out) {
+            T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j)
+                if (e0 + (uint32_t)j < span) xw[4 * (uint32_t)lane + j] = x[j];  // neighbours own the rest of the quad
         }
         ti += S;
     };
