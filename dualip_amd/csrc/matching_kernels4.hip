@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kDesc4Words ? (uint32_t)lane : (uint32_t)kDesc4Words - 1u;
     auto load_desc = [&](uint32_t q) -> uint32_t {
         const uint32_t t = q < n_tiles ? q : n_tiles;
-        return byte_offset(g.tiles32 + (size_t)t * kDesc4Words, dlane * 4u)[0];
+        return byte_offset(g.tiles32 + (size_t)t * kDesc4Words, dlane * 4u)[0];  // (cached: a 48-byte descriptor shares its lines with its neighbours')
     };
     struct Tile {
         uint32_t dv;  // descriptor words, one per lane; the head masks and the projection id are only unpacked when used
@@ -95,9 +95,18 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         const uint64_t room = last_quad - (W >> 2);                  // quads available after the window start
         const uint32_t lim = room < 63 ? (uint32_t)room : 63u;
         const uint32_t q = (uint32_t)lane < lim ? (uint32_t)lane : lim;  // lanes past the arrays' end re-read the last quad (masked later)
-        t.a = *byte_offset(reinterpret_cast<const Quad<T>*>(g.a + W), q * (uint32_t)sizeof(Quad<T>));
-        t.c = *byte_offset(reinterpret_cast<const Quad<T>*>(g.c + W), q * (uint32_t)sizeof(Quad<T>));
-        t.r = *byte_offset(reinterpret_cast<const RowQuad<RowT>*>(reinterpret_cast<const RowT*>(g.rowidx) + W), q * (uint32_t)sizeof(RowQuad<RowT>));
+        // streamed once per launch: non-temporal loads keep them from displacing the descriptors / dual vector in L2
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        typedef RowT rvec4 __attribute__((ext_vector_type(4)));
+        const vec4 av = __builtin_nontemporal_load(byte_offset(reinterpret_cast<const vec4*>(g.a + W), q * (uint32_t)sizeof(vec4)));
+        const vec4 cv = __builtin_nontemporal_load(byte_offset(reinterpret_cast<const vec4*>(g.c + W), q * (uint32_t)sizeof(vec4)));
+        const rvec4 rv = __builtin_nontemporal_load(byte_offset(reinterpret_cast<const rvec4*>(reinterpret_cast<const RowT*>(g.rowidx) + W), q * (uint32_t)sizeof(rvec4)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t.a.v[j] = av[j];
+            t.c.v[j] = cv[j];
+            t.r.v[j] = rv[j];
+        }
     };
 
     uint32_t ti = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;  // schedule slot
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
 #pragma unroll
             for (int j = 0; j < kSlots; ++j)
-                if (e0 + (uint32_t)j < span) xw[4 * (uint32_t)lane + j] = x[j];  // neighbours own the rest of the quad
+                if (e0 + (uint32_t)j < span) __builtin_nontemporal_store(x[j], &xw[4 * (uint32_t)lane + j]);  // neighbours own the rest of the quad
         }
         ti += S;
     };
