@@ -280,3 +280,20 @@ def test_hot_rows_plan(forced, monkeypatch):
     want = agd_oracle.maximize(calc, np.zeros(m), 40, 0.05, initial_step_size=1e-4, max_step_size=1e-2, dtype=np.float64)
     assert relerr(res.dual_objective_log, want["dual_obj_log"]) < 1e-8
     assert relerr(res.dual_val.cpu().numpy(), want["dual_val"]) < 1e-8
+
+
+def test_hot_rows_with_single_column_tiles_and_primal(monkeypatch):
+    """Hot-rows plan together with columns longer than a window (their walker gathers / scatters cold rows too) and the
+    primal written out."""
+    from dualip_amd.projections import create_projection_map
+
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "192")
+    p = _random_problem(900, 3_000, 10, seed=55, long_cols=((3, 400), (1500, 700), (2999, 260)), empty_every=17)
+    lam = np.random.default_rng(9).uniform(0, 0.02, p["m"])
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.5})):
+            entries = [(pt, pp)]
+            f = _compare(p, create_projection_map(pt, dict(pp), p["n"]), entries, None, 0.05, dn, lam)
+            info = f.info()
+            if info["layout"] == 4:
+                assert info["hot_rows"] == 192 and info["long_columns"] >= 3
