@@ -229,22 +229,32 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
                 _hip.check(self._lib.dl_lp_gradient(self._handle, _hip.ptr(x), _hip.ptr(self._packed), stream))
         return self._packed
 
-    def calculate(self, dual_val: torch.Tensor, gamma: float, save_primal: bool = False, **kwargs) -> ObjectiveResult:
+    def calculate_packed(self, dual_val: torch.Tensor, gamma: float, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Local pass only (the building block of the column-sharded objective below)."""
+        self.gamma = gamma
+        return self.calculate_packed_ptr(_hip.ptr(self._check_dual(dual_val)), gamma, x_out)
+
+    def finish(self, packed: torch.Tensor, dual_val: torch.Tensor, b_vec: torch.Tensor) -> ObjectiveResult:
+        """grad = packed - b, dual objective and slack statistics from a (possibly all-reduced) packed buffer."""
         lam = self._check_dual(dual_val)
-        x_out = self._primal_buffer() if save_primal else None
-        packed = self.calculate_packed_ptr(_hip.ptr(lam), gamma, x_out)
         grad = torch.empty(self.m, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             rc = self._lib.dl_dual_epilogue(
-                self.m, _hip.dtype_code(self.dtype), _hip.ptr(packed), _hip.ptr(self.b_step), _hip.ptr(lam), float(gamma), _hip.ptr(grad),
+                self.m, _hip.dtype_code(self.dtype), _hip.ptr(packed), _hip.ptr(b_vec), _hip.ptr(lam), float(self.gamma), _hip.ptr(grad),
                 _hip.ptr(self._scal), _hip.stream_ptr(self.device),
             )
         _hip.check(rc)
         s = self._scal.to(self.dtype)
-        res = ObjectiveResult(dual_gradient=grad, dual_objective=s[0], reg_penalty=s[1])
+        return ObjectiveResult(dual_gradient=grad, dual_objective=s[0], reg_penalty=s[1], primal_objective=s[2])
+
+    def calculate(self, dual_val: torch.Tensor, gamma: float, save_primal: bool = False, **kwargs) -> ObjectiveResult:
+        x_out = self._primal_buffer() if save_primal else None
+        packed = self.calculate_packed(dual_val, gamma, x_out)
+        res = self.finish(packed, dual_val, self.b_step)
         if save_primal:
             res.primal_var = x_out
-            res.primal_objective = s[2]
+        else:
+            res.primal_objective = None
         return res
 
     def invert_jacobi_precondition(self, dual_val: torch.Tensor, dual_grad: torch.Tensor):
@@ -306,6 +316,45 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
         dual_feas = torch.linalg.vector_norm(r + x_bound_duals) / (1.0 + torch.linalg.vector_norm(self.c))
         converged = bool((gap_upperbound <= tol) and (primal_feas <= tol) and (dual_feas <= tol))
         return gap_upperbound, gap_lower_bound, primal_feas, dual_feas, converged
+
+
+class MIPLIB2017ObjectiveFunctionDistributed(BaseObjective):
+    """The generic-LP objective sharded by VARIABLES (columns of A), one process per GPU -- not in the reference, whose
+    MIPLIB objective is single-device.  x_j depends on column j only and A x is a sum over columns, so the packed
+    [A x | c.x | sum x^2] partials of the shards add up exactly like the matching objective's: one sum-all-reduce per
+    iteration, then the identical device-side step on every rank (the maximizer's sharded route).  ``local_input_args``
+    holds this rank's columns of A, entries of c and projection map (re-based to local indices) and the FULL b_vec."""
+
+    _dualip_native = True
+
+    def __init__(self, local_input_args: MIPLIBInputArgs, gamma: float, process_group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.local_objective = MIPLIB2017ObjectiveFunction(local_input_args, use_jacobi_precondition=False)
+        self.gamma = gamma
+        self.process_group = process_group
+        self.equality_mask = local_input_args.equality_mask
+        self.device, self.dtype, self.m = self.local_objective.device, self.local_objective.dtype, self.local_objective.m
+        self.b_vec = self.local_objective.b_vec.contiguous()
+
+    def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
+        if self._dist.is_available() and self._dist.is_initialized():
+            self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self.process_group)
+        return packed
+
+    def calculate_packed_ptr(self, lambda_ptr: int, gamma: float = None) -> torch.Tensor:
+        if gamma is not None:
+            self.gamma = gamma
+        return self._exchange(self.local_objective.calculate_packed_ptr(lambda_ptr, self.gamma))
+
+    def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, **kwargs) -> ObjectiveResult:
+        if save_primal:
+            raise NotImplementedError("save_primal=True is not supported in distributed mode (each rank holds its own variables)")
+        if gamma is not None:
+            self.gamma = gamma
+        packed = self._exchange(self.local_objective.calculate_packed(dual_val, self.gamma))
+        return self.local_objective.finish(packed, dual_val, self.b_vec)
 
 
 def _operator_for(entry: ProjectionEntry):

@@ -99,3 +99,59 @@ def test_two_ranks_share_one_gpu(kind):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
     assert relerr(out[0][0], want_log) < 1e-7, kind
     assert relerr(out[0][1], want_dual) < 1e-6, kind
+
+
+def _lp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunctionDistributed, MIPLIBInputArgs
+        from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+        from dualip_amd.projections.base import ProjectionEntry
+        from tests.helpers import load, lp_small_entries
+
+        z = load("g6_lp_small.npz")
+        m, n = int(z["m"]), int(z["n"])
+        lo, hi = (0, n // 2) if rank == 0 else (n // 2, n)  # this rank's variables
+        pm = {}
+        for k, (kind, params, idx) in enumerate(lp_small_entries(z)):
+            local = [int(i) - lo for i in idx if lo <= i < hi]
+            if local:
+                pm[f"e{k}"] = ProjectionEntry(kind, dict(params), indices=local)
+        A = torch.from_numpy(z["A"][:, lo:hi].copy()).to(torch.float64).to_sparse_coo().to("cuda:0")
+        args = MIPLIBInputArgs(A=A, c=torch.from_numpy(z["c"][lo:hi].copy()).to("cuda:0"), b_vec=torch.from_numpy(z["b"]).to("cuda:0"),
+                               projection_map=pm, equality_mask=torch.from_numpy(z["eq"]).to("cuda:0"))
+        f = MIPLIB2017ObjectiveFunctionDistributed(args, gamma=1e-2)
+        res = AcceleratedGradientDescent(max_iter=120, gamma=1e-2, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False).maximize(
+            f, torch.zeros(m, dtype=torch.float64, device="cuda:0"), rank=rank)
+        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generic_lp_sharded_by_variables():
+    """The generic-LP objective split by variables over two ranks (one GPU, gloo): the trace of the reference's
+    single-process run (fixture G6, 40 x 60 LP with equality rows) while round-off has not been amplified yet."""
+    from tests.helpers import load, relerr
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = {}
+    for _ in procs:
+        rank, log, dual = q.get()
+        out[rank] = (log, dual)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    z = load("g6_lp_small.npz")
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][0], z["trace|plain|f64|obj_log"][:120]) < 1e-8
