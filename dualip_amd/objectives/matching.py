@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from dualip_amd import _hip
 from dualip_amd.objectives.base import BaseInputArgs, BaseObjective, ObjectiveResult
-from dualip_amd.projections.base import ProjectionEntry, project
+from dualip_amd.projections.base import ProjectionEntry, project  # noqa: F401  (ProjectionEntry is re-exported, as in the reference module)
 
 
 @dataclass
