@@ -14,7 +14,6 @@ import pytest
 import torch
 
 import oracle
-from oracle import agd_oracle  # noqa: F401
 from tests.helpers import NP_DT, RTOL, SCALA_GOLDEN, SINGLE_MAPS, load, problem, relerr, scala_5x5, torch_args
 
 pytestmark = pytest.mark.gpu
