@@ -1,4 +1,11 @@
-"""Objective-function operator interface (reference: src/dualip/objectives/base.py:8-26)."""
+"""Operator interface of the objectives (reference: src/dualip/objectives/base.py:8-26).
+
+Two base classes, both part of the API: input bundles derive from ``BaseInputArgs`` (run_solver moves every tensor field
+of such a dataclass to the host device), objectives from ``BaseObjective``.  The maximizer needs ``calculate`` and the
+attribute ``equality_mask``; an objective that additionally sets ``_dualip_native = True`` and offers
+``calculate_packed_ptr(lambda_ptr, gamma)`` -> float64[m + 2] = [A x | c.x | sum x^2] is driven by the device-resident
+loop instead of the generic torch one (optimizers/agd.py).
+"""
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
 
@@ -7,16 +14,18 @@ from dualip_amd.types import ObjectiveResult  # noqa: F401  (re-exported like th
 
 @dataclass
 class BaseInputArgs(ABC):
-    """Base of the per-objective input bundles."""
+    """Marker base of the per-objective input dataclasses (MatchingInputArgs, MIPLIBInputArgs)."""
 
     def __post_init__(self):
         pass
 
 
 class BaseObjective(ABC):
-    """An objective exposes ``calculate(dual_val, gamma=None, save_primal=False, **kwargs) -> ObjectiveResult`` and the
-    attribute ``equality_mask`` (read by the maximizer, reference optimizers/agd.py:147)."""
+    #: set by native objectives: the maximizer keeps its state on the device and calls calculate_packed_ptr
+    _dualip_native = False
+    #: rows of the dual that are equality constraints (bool tensor or None); read by the maximizer (reference agd.py:147)
+    equality_mask = None
 
     @abstractmethod
     def calculate(self) -> ObjectiveResult:
-        ...
+        """``calculate(dual_val, gamma=None, save_primal=False, **kwargs)``: gradient, objective value and penalty at ``dual_val``."""

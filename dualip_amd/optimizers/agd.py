@@ -284,9 +284,8 @@ class DeviceRun:
         return rows
 
     def result_from_row(self, row, with_grad: bool) -> ObjectiveResult:
-        t = torch.tensor(row, dtype=torch.float64, device=self.device).to(self.dtype)
         grad = self._fetch(2) if with_grad else torch.empty(0, dtype=self.dtype, device=self.device)
-        return ObjectiveResult(dual_gradient=grad, dual_objective=t[0], reg_penalty=t[2], dual_val_times_grad=t[3], max_pos_slack=t[4], sum_pos_slack=t[5])
+        return ObjectiveResult.from_log_row(row, grad, self.dtype, self.device)
 
     def finish(self) -> SolverResult:
         solver = self.solver
