@@ -155,3 +155,24 @@ def test_generic_lp_sharded_by_variables():
     z = load("g6_lp_small.npz")
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert relerr(out[0][0], z["trace|plain|f64|obj_log"][:120]) < 1e-8
+
+
+def test_bench_harness_with_two_ranks_on_one_gpu():
+    """bench.py under torch.distributed.run with WORLD_SIZE=2 (developer mode: both ranks on cuda:0, gloo collectives): the
+    N > 1 harness -- block-balanced shards, the exchange, max-over-ranks timing -- prints exactly ONE JSON line with the
+    contract's fields.  (The number itself means nothing in this mode.)"""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DUALIP_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--entities", "2000000", "--steps", "4", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert d["metric"] == "dual_ascent_iterations_per_sec" and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1000.0) < 1e-6 * 1000
+    assert d["config"]["entities"] == 2000000 and d["config"]["parallelism"] == "column-shard x2" and d["cpu_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
