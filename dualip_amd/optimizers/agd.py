@@ -27,6 +27,7 @@ from dualip_amd import _hip
 from dualip_amd.objectives.base import BaseObjective
 from dualip_amd.optimizers.agd_utils import calculate_step_size
 from dualip_amd.types import ObjectiveResult, SolverResult
+from dualip_amd.utils.mlflow_utils import log_iteration_rows, log_metrics, log_objective_result, tracking_enabled
 
 
 def project_on_nn_cone(y: torch.Tensor, equality_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -153,6 +154,9 @@ class AcceleratedGradientDescent:
                 y = y_next
                 if self.gamma is not None and self.gamma_decay_type is not None:
                     self._update_gamma(i, step)
+                if tracking_enabled():  # (agd.py:189-201)
+                    log_metrics({"step_size": float(step), "dual_objective": dual_obj, **({} if self.gamma is None else {"gamma": float(self.gamma)})}, step=i)
+                    log_objective_result(result, step=i)
             if dist.is_available() and dist.is_initialized():
                 dist.broadcast(x, src=0)
                 dist.broadcast(y, src=0)
@@ -175,9 +179,12 @@ class AcceleratedGradientDescent:
             while run.done < self.max_iter:
                 first = run.done
                 n = run.advance(min(chunk, self.max_iter - run.done))
-                if per_iteration or self._user_callback is None:
+                track = rank == 0 and tracking_enabled()
+                if per_iteration or self._user_callback is None or track:
                     rows = run.read_log(first, n)
-                    for k in range(n):
+                    if track:
+                        log_iteration_rows(first + 1, rows, gammas=run.gammas_after(first + 1, n), with_primal_last=self.save_primal and run.done == self.max_iter)
+                    for k in range(n if (per_iteration or self._user_callback is None) else 0):
                         it = first + k + 1
                         if per_iteration:
                             self.iteration_callback(it, run.result_from_row(rows[k], with_grad=True))
@@ -224,6 +231,7 @@ class DeviceRun:
             self.decay_factor = float(solver.gamma_decay_params["decay_factor"])
         self._beta_host = solver.beta_seq.contiguous()
         self.gamma = ctypes.c_double(float(solver.gamma))
+        self.gamma0 = float(solver.gamma)
         self.done = 0
         self._x_dev = None
         self.state = ctypes.c_void_p()
@@ -276,6 +284,12 @@ class DeviceRun:
                         self.gamma.value = self.gamma.value * self.decay_factor
         self.done += n
         return n
+
+    def gammas_after(self, first_iteration: int, count: int):
+        """gamma as the reference reports it at the end of iterations first_iteration .. +count-1 (after the decay, agd.py:186-196)."""
+        if self.decay_steps <= 0:
+            return [self.gamma0] * count
+        return [self.gamma0 * self.decay_factor ** (it // self.decay_steps) for it in range(first_iteration, first_iteration + count)]
 
     def read_log(self, first: int, count: int) -> np.ndarray:
         rows = np.zeros((max(count, 0), _hip.LOG_COLS), dtype=np.float64)

@@ -6,6 +6,7 @@ one-process-per-GPU mode: call it from every rank of an initialised ``torch.dist
 problem; each rank keeps its own column shard (the reference's multi-device branch cannot be constructed,
 run_solver.py:60-67, so this is the intended behaviour rather than a copy of it).
 """
+import dataclasses
 from dataclasses import fields
 from typing import Optional
 
@@ -21,6 +22,7 @@ from dualip_amd.objectives.matching import (
 )
 from dualip_amd.optimizers.agd import AcceleratedGradientDescent
 from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs, SolverResult
+from dualip_amd.utils.mlflow_utils import MLflowConfig, log_hyperparameters, mlflow_run_context
 from dualip_amd.utils.dist_utils import global_to_local_projection_map, split_tensors_to_devices
 
 
@@ -72,10 +74,17 @@ def run_solver(
     solver_args: SolverArgs,
     compute_args: ComputeArgs,
     objective_args: ObjectiveArgs,
-    mlflow_config: Optional[object] = None,
+    mlflow_config: Optional[MLflowConfig] = None,
 ) -> SolverResult:
-    if mlflow_config is not None and getattr(mlflow_config, "enabled", False):
-        raise NotImplementedError("MLflow tracking is outside the MI355X hot path (SURVEY.md 2, OUT OF SCOPE)")
+    if mlflow_config is None:
+        mlflow_config = MLflowConfig(enabled=False)
+    with mlflow_run_context(mlflow_config):
+        if mlflow_config.enabled and mlflow_config.log_hyperparameters:  # (run_solver.py:100-105)
+            log_hyperparameters({"solver": dataclasses.asdict(solver_args), "objective": dataclasses.asdict(objective_args)})
+        return _run_solver(input_args, solver_args, compute_args, objective_args)
+
+
+def _run_solver(input_args, solver_args, compute_args, objective_args) -> SolverResult:
     host_device = compute_args.host_device
     sharded = compute_args.compute_device_num > 1
     if not sharded:

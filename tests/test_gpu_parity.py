@@ -351,6 +351,44 @@ def test_run_solver_entry_point_and_warm_start(tmp_path):
     assert warm.dual_objective_log[0] > res.dual_objective_log[0]
 
 
+def test_run_solver_tracking_from_the_device_log(tmp_path):
+    """run_solver(mlflow_config=...) on the device-resident route: the per-iteration metrics the reference logs
+    (agd.py:189-201, utils/mlflow_utils.py:176-203) come out of the device log in blocks and match the returned logs."""
+    import csv
+    import json
+
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.run_solver import run_solver
+    from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
+    from dualip_amd.utils.mlflow_utils import MLflowConfig, is_mlflow_available
+
+    if is_mlflow_available():
+        pytest.skip("mlflow installed: the file store is not used")
+    z = load("g2_syn2000.npz")
+    p = problem(z)
+    args = torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), "cpu")
+    sa = SolverArgs(max_iter=250, initial_step_size=1e-3, gamma=0.02, max_step_size=1e-1, save_primal=True, gamma_decay_type="step", gamma_decay_params={"decay_steps": 100, "decay_factor": 0.5})
+    cfg = MLflowConfig(enabled=True, tracking_uri="file:" + str(tmp_path), run_name="r")
+    res = run_solver(args, sa, ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="matching"), mlflow_config=cfg)
+    run = tmp_path / "dualip_experiments" / "r"
+    assert json.loads((run / "params.json").read_text()) == {
+        "solver.max_iter": 250, "solver.initial_step_size": 1e-3, "solver.max_step_size": 1e-1, "solver.gamma": 0.02, "solver.gamma_decay_type": "step", "objective.objective_type": "matching"}
+    got = {}
+    with open(run / "metrics.csv") as fh:
+        for r in csv.DictReader(fh):
+            got.setdefault(r["key"], []).append((int(r["step"]), float(r["value"])))
+    steps = list(range(1, 251))
+    for key in ("step_size", "dual_objective", "gamma", "regularization_penalty", "max_positive_slack", "sum_positive_slack"):
+        assert [s for s, _ in got[key]] == steps, key
+    assert [v for _, v in got["dual_objective"]] == res.dual_objective_log and [v for _, v in got["step_size"]] == res.step_size_log
+    assert [v for _, v in got["gamma"]] == [0.02 * 0.5 ** (i // 100) for i in steps]
+    assert got["primal_objective"] == [(250, pytest.approx(float(res.objective_result.primal_objective), rel=1e-12))]
+    assert got["regularization_penalty"][-1][1] == pytest.approx(float(res.objective_result.reg_penalty), rel=1e-12)
+    # the same solve without tracking gives the same trace (tracking only reads the log)
+    plain = run_solver(args, sa, ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="matching"))
+    assert plain.dual_objective_log == res.dual_objective_log
+
+
 def test_sharded_route_single_rank_nccl():
     """Route 2 of the maximiser (local pass -> RCCL sum-all-reduce -> device step) with a 1-rank nccl group."""
     import torch.distributed as dist

@@ -257,3 +257,57 @@ def test_memmap_cache_format_reads_and_rewrites_the_reference_cache(tmp_path):
     cf.save_matching_args(dst2, args, 0.2, 7)
     back = cf.load_matching_cache(dst2, 1000, 20, 0.2, torch.float32, 7, device="cpu")
     assert torch.equal(back.A.values(), args.A.values()) and torch.equal(back.c.values(), args.c.values()) and torch.equal(back.b_vec, args.b_vec)
+
+
+def _read_metrics(run_dir):
+    import csv
+
+    with open(os.path.join(run_dir, "metrics.csv")) as fh:
+        rows = list(csv.DictReader(fh))
+    by_key = {}
+    for r in rows:
+        by_key.setdefault(r["key"], []).append((int(r["step"]), float(r["value"])))
+    return by_key
+
+
+def test_run_tracking_file_store(tmp_path):
+    """Tracking (reference: utils/mlflow_utils.py) with the file store that stands in when mlflow is not installed: the
+    generic AGD route logs step_size / dual_objective / gamma and the objective's scalars every iteration (agd.py:189-201),
+    hyper-parameters go to params.json, nothing is written outside a run context or with enabled=False, and a broken
+    backend never stops the solve."""
+    import json
+
+    from dualip_amd.utils import mlflow_utils as mu
+
+    if mu.is_mlflow_available():
+        pytest.skip("mlflow installed: the file store is not used")
+    cfg = mu.MLflowConfig(enabled=True, tracking_uri=str(tmp_path), experiment_name="exp", run_name="quad")
+    solver = AcceleratedGradientDescent(max_iter=20, gamma=0.5, initial_step_size=1e-3, gamma_decay_type="step", gamma_decay_params={"decay_steps": 8, "decay_factor": 0.5}, iteration_callback=False)
+    with mu.mlflow_run_context(cfg) as run:
+        assert run == os.path.join(str(tmp_path), "exp", "quad") and mu.tracking_enabled()
+        mu.log_hyperparameters({"solver": {"max_iter": 20, "gamma": 0.5, "save_primal": False, "gamma_decay_type": None}, "objective": {"objective_type": "matching", "objective_kwargs": {}}})
+        res = solver.maximize(_Quadratic2D(), torch.tensor([0.0, 0.0]))
+    assert not mu.tracking_enabled()
+    with open(os.path.join(run, "params.json")) as fh:
+        assert json.load(fh) == {"solver.max_iter": 20, "solver.gamma": 0.5, "solver.gamma_decay_type": "None", "objective.objective_type": "matching"}
+    got = _read_metrics(run)
+    assert [s for s, _ in got["step_size"]] == list(range(1, 21))
+    assert [v for _, v in got["step_size"]] == res.step_size_log
+    # the per-iteration record and the objective record both carry the dual objective (as the reference)
+    assert [v for s, v in got["dual_objective"]][0::2] == pytest.approx(res.dual_objective_log, rel=1e-15)
+    assert [v for _, v in got["gamma"]] == [0.5 * 0.5 ** (i // 8) for i in range(1, 21)]
+    assert "regularization_penalty" not in got  # the toy objective reports none
+    # disabled config: no directory, no state
+    with mu.mlflow_run_context(mu.MLflowConfig(enabled=False, tracking_uri=str(tmp_path / "off"))) as run2:
+        assert run2 is None and not mu.tracking_enabled()
+        mu.log_metrics({"a": 1.0}, step=1)
+    assert not (tmp_path / "off").exists()
+    # a second run of the same name gets its own directory
+    with mu.mlflow_run_context(cfg) as run3:
+        mu.log_metrics({"a": 1.0, "skipped": "text"}, step=3)
+    assert run3.endswith("quad_1") and _read_metrics(run3) == {"a": [(3, 1.0)]}
+    # an unusable location is reported, not raised
+    blocker = tmp_path / "file"
+    blocker.write_text("x")
+    with mu.mlflow_run_context(mu.MLflowConfig(enabled=True, tracking_uri=str(blocker))) as run4:
+        assert run4 is None and not mu.tracking_enabled()
