@@ -178,3 +178,34 @@ def test_simplex_eq_padded_blocks_match_reference():
                     assert relerr(scal[:2], ge[f"{key}|scal"]) < RTOL[dn] * 10, key
     # the two modes really differ on this problem (z = 40: most columns sum to less than z)
     assert np.abs(ge["40.0|1|zero|f64|x"] - ge["40.0|0|zero|f64|x"]).max() > 1.0
+
+
+def test_fairness_rows_match_reference_operators():
+    """oracle/fairness_oracle.py against gf_fairness.npz (the documentation's two-group fairness extension evaluated with
+    the reference's own sparse operators, tests/golden/make_golden_fair.py)."""
+    from oracle import fairness_oracle
+
+    z = load("gf_fairness.npz")
+    p = problem(load("g1_syn2000.npz"))
+    ratio, delta = float(z["group_ratio"]), float(z["delta"])
+    for dn, dt in NP_DT.items():
+        f = fairness_oracle.fairness_coefficients(p["colptr"], p["a"], ratio, dt)
+        assert relerr(f, z[f"f|{dn}"]) < (1e-7 if dn == "f32" else 1e-15)
+        b_full = np.concatenate([p["b"], [delta, delta]])
+        for mn in ("simplex1", "box01"):
+            for ln in ("zero", "rand", "tilt"):
+                grad, obj, reg, primal, x = fairness_oracle.fairness_calculate(p, f, z[f"lam_{ln}"], 0.02, SINGLE_MAPS[mn], b_full, dt)
+                pre = f"calc|{mn}|{ln}|{dn}"
+                assert relerr(x, z[pre + "|x"]) < RTOL[dn], pre
+                assert relerr(grad, z[pre + "|grad"]) < RTOL[dn], pre
+                assert relerr([obj, reg, primal], z[pre + "|scal"]) < RTOL[dn], pre
+        if dn == "f64":
+            for mn in ("simplex1", "box01"):
+                def calc(lam, gamma, mn=mn):
+                    grad, obj, _, _, x = fairness_oracle.fairness_calculate(p, f, lam, gamma, SINGLE_MAPS[mn], b_full, dt)
+                    return grad, obj, x
+                r = agd_oracle.maximize(calc, np.zeros(p["m"] + 2), 60, 0.02, initial_step_size=1e-3, max_step_size=0.1, dtype=dt)
+                pre = f"trace|{mn}|{dn}"
+                assert relerr(r["dual_obj_log"][:40], z[pre + "|obj_log"][:40]) < 1e-8, pre
+                assert relerr(r["dual_obj_log"], z[pre + "|obj_log"]) < 2e-2, pre  # (chaotic tail, as the other traces)
+                assert r["dual_val"][-2] > 0 and r["dual_val"][-1] == 0  # the constraint binds on one side
