@@ -40,7 +40,9 @@ def _column_projection_table(projection_map, n: int, device):
     descs = []
     entries = list(projection_map.items())
     for _, entry in entries:
-        descs.append(project(entry.proj_type, **entry.proj_params).descriptor())  # raises ValueError like the reference
+        d = project(entry.proj_type, **entry.proj_params).descriptor()  # raises ValueError like the reference
+        # an operator without a kernel form: the fused pass zeroes its columns (clamp to [0, 0]); _CustomBlocks adds them back
+        descs.append(d if d is not None else _hip.ProjDesc(_hip.PROJ_BOX, 0, 0.0, 0.0))
     if len(entries) == 1:
         idx = entries[0][1].indices
         if isinstance(idx, range) and idx == range(n):
@@ -62,6 +64,57 @@ def _column_projection_table(projection_map, n: int, device):
                     raise ValueError("projection_map index outside [0, n)")
                 col_proj[t] = q
     return descs, col_proj
+
+
+class _CustomBlocks:
+    """Columns whose projection is a user-registered operator the kernel has no form for (such operators
+    must keep working).  They go through zero-padded dense blocks, one per nnz-bucket -- the reference's
+    apply_F_to_columns (sparse_utils.py:133-220) with its buckets (matching.py:87-114) -- built with torch ops on the
+    device; index tensors are prepared once, a call does no host synchronisation."""
+
+    def __init__(self, obj, colptr, rowidx, entries):
+        dev = obj.device
+        lengths = (colptr[1:] - colptr[:-1]).to(torch.int64)
+        thresholds = [0]
+        i = 1
+        while 2**i <= obj.m:
+            thresholds.append(2**i)
+            i += 1
+        thresholds.append(obj.m + 1)
+        th = torch.tensor(thresholds, dtype=torch.int64, device=dev)
+        self.blocks = []
+        for entry in entries:
+            op = project(entry.proj_type, **entry.proj_params)
+            idx = entry.indices
+            idx = torch.arange(idx.start, idx.stop, idx.step, device=dev) if isinstance(idx, range) else torch.as_tensor(idx, dtype=torch.int64, device=dev)
+            lens = lengths[idx]
+            idx, lens = idx[lens > 0], lens[lens > 0]
+            if idx.numel() == 0:
+                continue
+            bucket = torch.bucketize(lens, th) if obj.batching else torch.zeros_like(lens)
+            for bk in torch.unique(bucket).tolist():
+                sel = bucket == bk
+                cols, ln = idx[sel], lens[sel]
+                K, L, E = int(cols.numel()), int(ln.max()), int(ln.sum())
+                colpos = torch.repeat_interleave(torch.arange(K, device=dev), ln)
+                offs = torch.arange(E, device=dev) - torch.repeat_interleave(torch.cumsum(ln, 0) - ln, ln)
+                k = colptr[cols].to(torch.int64)[colpos] + offs
+                self.blocks.append((op, k, rowidx[k].to(torch.int64), offs, colpos, L, K))
+
+    def add(self, obj, lam, gamma, packed, x_out):
+        a, c, m = obj._a_vals, obj._c_vals, obj.m
+        scaled = -1.0 / gamma * lam  # matching.py:136
+        for op, k, rows, offs, colpos, L, K in self.blocks:
+            ak, ck = a[k], c[k]
+            v = ak * scaled[rows] + (-1.0 / gamma * ck)  # :139-142
+            block = torch.zeros((L, K), dtype=obj.dtype, device=obj.device)
+            block[offs, colpos] = v
+            xk = op(block)[offs, colpos]
+            packed[:m].index_add_(0, rows, (ak * xk).to(torch.float64))
+            packed[m] += (ck * xk).to(torch.float64).sum()
+            packed[m + 1] += (xk.to(torch.float64) ** 2).sum()
+            if x_out is not None:
+                x_out[k] = xk
 
 
 class MatchingSolverDualObjectiveFunction(BaseObjective):
@@ -142,6 +195,11 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         self._packed = torch.zeros(self.m + 2, dtype=torch.float64, device=self.device)
         self._scal = torch.zeros(6, dtype=torch.float64, device=self.device)
         self._primal = None  # allocated on the first save_primal, then reused (the reference aliases its scratch too)
+        custom = [e for e in self.projection_map.values() if project(e.proj_type, **e.proj_params).descriptor() is None]
+        self._custom = _CustomBlocks(self, colptr, rowidx, custom) if custom else None
+        if self._custom is not None:  # the optimiser must hand over the duals as a tensor, one call per iteration
+            self._dualip_packed = True
+            self._needs_dual_tensor = True
         if simplex_eq_padding not in ("exact", "reference"):
             raise ValueError("simplex_eq_padding must be 'exact' or 'reference'")
         self.simplex_eq_padding = simplex_eq_padding
@@ -225,10 +283,18 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
     def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Local pass only: returns the internal float64 buffer [A x (m) | c.x | sum x^2] (overwritten by the next call)."""
         lam = self._check_dual(dual_val)
-        return self.calculate_packed_ptr(_hip.ptr(lam), gamma, x_out)
+        packed = self._fused_pass(_hip.ptr(lam), gamma, x_out)
+        if self._custom is not None:
+            self._custom.add(self, lam, self.gamma, packed, x_out)
+        return packed
 
     def calculate_packed_ptr(self, lambda_ptr: int, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same, with the dual vector given as a raw device address (the optimiser state lives inside the C library)."""
+        if self._custom is not None:
+            raise RuntimeError("a map with user-defined operators needs the dual vector as a tensor: use calculate_packed")
+        return self._fused_pass(lambda_ptr, gamma, x_out)
+
+    def _fused_pass(self, lambda_ptr: int, gamma: float = None, x_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if gamma is not None and gamma != self.gamma:
             self.gamma = gamma
         with torch.cuda.device(self.device):
@@ -312,6 +378,7 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
                 raise ValueError("local partitions must be built with b_vec=None (b_vec is shared by all ranks)")
             local_objective = MatchingSolverDualObjectiveFunction(local_matching_input_args, gamma, batching)
         self.local_objective = local_objective
+        self._needs_dual_tensor = bool(getattr(local_objective, "_needs_dual_tensor", False))
         self.device = local_objective.device
         self.dtype = local_objective.dtype
         self.m = local_objective.m

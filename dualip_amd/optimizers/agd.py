@@ -271,13 +271,14 @@ class DeviceRun:
                     )
                 )
             else:
+                by_address = hasattr(self.f, "calculate_packed_ptr") and not getattr(self.f, "_needs_dual_tensor", False)
                 for it in range(self.done + 1, self.done + n + 1):
-                    if hasattr(self.f, "calculate_packed_ptr"):
-                        extra = {"x_out": self.primal} if (self.primal is not None and it == self.max_iter and not self.sharded) else {}
+                    extra = {"x_out": self.primal} if (self.primal is not None and it == self.max_iter and not self.sharded) else {}
+                    if by_address:
                         packed = self.f.calculate_packed_ptr(int(lib.dl_agd_x(self.state)), self.gamma.value, **extra)  # local pass [+ ONE sum-all-reduce]
-                    else:
+                    else:  # objectives that read the duals with torch ops (user-defined projection operators, fairness rows)
                         self._x_dev = self._fetch(0, out=self._x_dev)
-                        packed = self.f.calculate_packed(self._x_dev, self.gamma.value)
+                        packed = self.f.calculate_packed(self._x_dev, self.gamma.value, **extra)
                     decay_now = int(self.decay_steps > 0 and it % self.decay_steps == 0)
                     _hip.check(lib.dl_agd_step(self.state, _hip.ptr(packed), _hip.ptr(self.b_vec), self.gamma.value, it, decay_now, self.decay_factor, stream))
                     if decay_now:

@@ -6,7 +6,7 @@ to dense blocks through ``dl_project_dense`` (include/dualip_hip.h), i.e. on the
 """
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence, Union
+from typing import Optional, Dict, List, Sequence, Union
 
 import torch
 
@@ -31,11 +31,15 @@ class ProjectionOperator(ABC):
     def __init__(self, **params):
         ...
 
-    @abstractmethod
-    def descriptor(self) -> _hip.ProjDesc:
-        """Kernel-side description of this operator."""
+    def descriptor(self) -> Optional[_hip.ProjDesc]:
+        """Kernel-side description of this operator, or None: an operator the fused kernel does not know (a user's own
+        subclass that only defines ``__call__``, as the reference's interface asks) is applied to zero-padded dense
+        blocks of columns instead, like the reference's apply_F_to_columns does for every operator."""
+        return None
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.descriptor() is None:
+            raise NotImplementedError("a ProjectionOperator defines descriptor() (built-in kinds) or overrides __call__")
         return _apply_dense(self, x)
 
 

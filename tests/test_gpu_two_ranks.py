@@ -46,10 +46,23 @@ def _worker(rank, world, port, kind, q):
         p = problem(z)
         gamma, iters, s0, s1 = z["params"]
         n = p["n"]
-        if kind == "mixed":
+        if kind in ("mixed", "mixed_custom"):
             half = int(z["mixed_boundary"])
+            first = ("box", {"lower": 0.0, "upper": 1.0})
+            if kind == "mixed_custom":  # the box block through a user-registered operator (dense-block route beside the fused kernel)
+                from dualip_amd.projections.base import ProjectionOperator, register
+
+                @register("user_unit_clamp")
+                class UnitClamp(ProjectionOperator):
+                    def __init__(self):
+                        pass
+
+                    def __call__(self, x):
+                        return x.clamp(0.0, 1.0)
+
+                first = ("user_unit_clamp", {})
             pm = {
-                **create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)),
+                **create_projection_map(first[0], first[1], n, indices=range(0, half)),
                 **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n)),
             }
             # every rank takes its share of BOTH blocks (what bench.py does): two column ranges per rank
@@ -75,7 +88,7 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["simplex", "mixed"])
+@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom"])
 def test_two_ranks_share_one_gpu(kind):
     from tests.helpers import load, relerr
 
@@ -93,7 +106,7 @@ def test_two_ranks_share_one_gpu(kind):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     z = load("g3_syn2000.npz")
-    key = "simplex1|w2|f64" if kind == "simplex" else "mixed|w2|f64"
+    key = "simplex1|w2|f64" if kind == "simplex" else "mixed|w2|f64"  # (the custom clamp is the same projection as box [0, 1])
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
     # both ranks apply the identical update: identical duals, bit for bit, without a broadcast
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])

@@ -311,3 +311,18 @@ def test_run_tracking_file_store(tmp_path):
     blocker.write_text("x")
     with mu.mlflow_run_context(mu.MLflowConfig(enabled=True, tracking_uri=str(blocker))) as run4:
         assert run4 is None and not mu.tracking_enabled()
+
+
+def test_user_defined_projection_operator_registers_without_a_kernel_form():
+    from dualip_amd.projections.base import ProjectionOperator, register
+
+    @register("user_halve")
+    class Halve(ProjectionOperator):
+        def __init__(self, factor=0.5):
+            self.factor = factor
+
+        def __call__(self, x):
+            return x * self.factor
+
+    op = project("user_halve", factor=0.25)
+    assert op.descriptor() is None and torch.equal(op(torch.tensor([4.0, 8.0])), torch.tensor([1.0, 2.0]))
