@@ -408,12 +408,44 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     if (h->layout == 4) {
         // descriptor array = [window tiles in schedule order | one all-zero descriptor (what slots past the end read) |
         // single-column tiles]: the single-column walker runs in its own loop, outside the hot one
-        std::vector<uint32_t> short_words, long_words, short_pid, long_pid;
+        // single-column tiles of more than xlong_min non-zeros are walked by a whole workgroup (listed last): one wavefront
+        // walking thousands of non-zeros alone would set the critical path of the launch
+        std::vector<uint32_t> short_words, long_words, short_pid, long_pid, xlong_words, xlong_pid;
+        uint64_t xlong_min = 1024;
+        if (const char* e = getenv("DUALIP_HIP_XLONG_MIN")) xlong_min = strtoull(e, nullptr, 10);
         for (size_t t = 0; t < tile_pid4.size(); ++t) {
             const bool is_long = (words4[t * 12 + 1] & (1u << 19)) != 0;
-            (is_long ? long_words : short_words).insert((is_long ? long_words : short_words).end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
-            (is_long ? long_pid : short_pid).push_back(tile_pid4[t]);
+            const uint64_t len = ((uint64_t)words4[t * 12 + 3] << 32) | words4[t * 12 + 2];
+            std::vector<uint32_t>& wv = !is_long ? short_words : (len > xlong_min ? xlong_words : long_words);
+            std::vector<uint32_t>& pv = !is_long ? short_pid : (len > xlong_min ? xlong_pid : long_pid);
+            wv.insert(wv.end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
+            pv.push_back(tile_pid4[t]);
         }
+        // longest first, dealt in snake order (wavefront W takes slots W, W + S, ...: reversing every other round pairs the
+        // longest columns with the shortest ones); the workgroup-walked ones likewise over the workgroups
+        auto snake = [](std::vector<uint32_t>& wv, std::vector<uint32_t>& pv, size_t width) {
+            const size_t nt = pv.size();
+            if (nt < 2 || width == 0) return;
+            std::vector<size_t> order(nt);
+            for (size_t i = 0; i < nt; ++i) order[i] = i;
+            auto len_of = [&](size_t t) { return ((uint64_t)wv[t * 12 + 3] << 32) | wv[t * 12 + 2]; };
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return len_of(x) > len_of(y); });
+            for (size_t r0 = width; r0 < nt; r0 += 2 * width) std::reverse(order.begin() + (ptrdiff_t)r0, order.begin() + (ptrdiff_t)std::min(r0 + width, nt));
+            std::vector<uint32_t> w2(wv.size()), p2(nt);
+            for (size_t i = 0; i < nt; ++i) {
+                std::copy(wv.begin() + (ptrdiff_t)(order[i] * 12), wv.begin() + (ptrdiff_t)(order[i] * 12 + 12), w2.begin() + (ptrdiff_t)(i * 12));
+                p2[i] = pv[order[i]];
+            }
+            wv.swap(w2);
+            pv.swap(p2);
+        };
+        if (!getenv("DUALIP_HIP_NO_SNAKE")) {
+            snake(long_words, long_pid, (size_t)h->n_wg * (size_t)kFusedWaves);
+            snake(xlong_words, xlong_pid, (size_t)h->n_wg);
+        }
+        h->n_xlong = (int64_t)xlong_pid.size();
+        long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
+        long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
         if (!getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
         h->n_short = (int64_t)short_pid.size();
         words4 = short_words;
@@ -639,6 +671,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 8: return h->layout;
         case 9: return h->m_hot;
         case 10: return (int64_t)(h->hot_fraction * 1e6);
+        case 11: return h->n_xlong;
         default: return -1;
     }
 }

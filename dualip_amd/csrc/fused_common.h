@@ -33,6 +33,7 @@ struct FusedArgs {
     int32_t n_proj;
     uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
     uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
+    uint32_t n_xlong;   // layout 4: very long single-column tiles (walked by a whole workgroup), descriptors after those
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does
@@ -71,16 +72,43 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 // Long tile: one column too long for a window, walked by the whole wavefront.  The walk is latency bound (one wavefront,
 // dependent loads), so it moves in batches of four 64-wide strides whose loads are all issued before the first is used;
 // data are re-read (L2-hot) for every Newton pass.  Per-lane partial sums run over the strides in ascending order.
-template <class T, class RowT, bool LAM_LDS>
+// WG = true: the same walk by the whole workgroup (columns of thousands of non-zeros: one wavefront walking them alone sets
+// the critical path of the launch).  `lane` is then the thread index, strides are kFusedThreads wide, reductions go through
+// `red` (>= kFusedWaves doubles of LDS) with workgroup barriers -- every thread of the workgroup must make the call.
+template <class T, class RowT, bool LAM_LDS, bool WG = false>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
-                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0) {
+                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
+                                              double* red = nullptr) {
     constexpr int kLB = 4;
+    constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
+    auto all_sum = [&](double x) -> double {
+        x = wave_allreduce(x, OpAdd());
+        if constexpr (WG) {
+            __syncthreads();  // the previous reduction's readers are done
+            if ((lane & 63) == 0) red[lane >> 6] = x;
+            __syncthreads();
+            x = red[0];
+            for (int q = 1; q < kFusedWaves; ++q) x += red[q];  // fixed order
+        }
+        return x;
+    };
+    auto all_max = [&](double x) -> double {
+        x = wave_allreduce(x, OpMax());
+        if constexpr (WG) {
+            __syncthreads();
+            if ((lane & 63) == 0) red[lane >> 6] = x;
+            __syncthreads();
+            x = red[0];
+            for (int q = 1; q < kFusedWaves; ++q) x = red[q] > x ? red[q] : x;
+        }
+        return x;
+    };
     const bool is_simplex = is_simplex_kind(pj.kind);
-    // v = a * (-lambda/gamma) + (-c/gamma) for the elements o0 + lane + 64 u (ok[u]: inside the column)
+    // v = a * (-lambda/gamma) + (-c/gamma) for the elements o0 + lane + kStride u (ok[u]: inside the column)
     auto load_batch = [&](uint64_t o0, T (&av)[kLB], T (&cv)[kLB], uint32_t (&rv)[kLB], bool (&ok)[kLB], T (&v)[kLB]) {
 #pragma unroll
         for (int u = 0; u < kLB; ++u) {
-            const uint64_t o = o0 + (uint64_t)lane + 64u * (uint64_t)u;
+            const uint64_t o = o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u;
             ok[u] = o < len;
             const uint64_t k = k0 + (ok[u] ? o : len - 1);
             av[u] = g.a[k];
@@ -95,22 +123,53 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
     };
     T th = (T)0;
     bool projected = false, onehot = false;
+    // columns of up to kRB strides keep their clamped values in registers across the Newton passes (-inf outside the column);
+    // longer ones re-read the arrays (L2-hot) in every pass
+    constexpr int kRB = WG ? 8 : 16;
+    const bool cached = len <= (uint64_t)kStride * kRB && !(g.ablate & 8);
+    T vr[kRB];
     if (is_simplex) {
         T S = (T)0, v1 = (T)(-INFINITY);
-        for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
-            T av[kLB], cv[kLB], v[kLB];
-            uint32_t rv[kLB];
-            bool ok[kLB];
-            load_batch(o0, av, cv, rv, ok, v);
+        if (cached) {
 #pragma unroll
-            for (int u = 0; u < kLB; ++u) {
-                const T uu = tmax(v[u], (T)0);
-                S = ok[u] ? (T)(S + uu) : S;
-                v1 = ok[u] ? tmax(v1, uu) : v1;
+            for (int bt = 0; bt < kRB / kLB; ++bt) {
+#pragma unroll
+                for (int u = 0; u < kLB; ++u) vr[bt * kLB + u] = (T)(-INFINITY);
+                if ((uint64_t)bt * kStride * kLB < len) {
+                    T av[kLB], cv[kLB], v[kLB];
+                    uint32_t rv[kLB];
+                    bool ok[kLB];
+                    load_batch((uint64_t)bt * kStride * kLB, av, cv, rv, ok, v);
+#pragma unroll
+                    for (int u = 0; u < kLB; ++u) {
+                        const T uu = tmax(v[u], (T)0);
+                        S = ok[u] ? (T)(S + uu) : S;
+                        v1 = ok[u] ? tmax(v1, uu) : v1;
+                        vr[bt * kLB + u] = ok[u] ? uu : (T)(-INFINITY);
+                    }
+                }
+            }
+        } else {
+            for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
+                T av[kLB], cv[kLB], v[kLB];
+                uint32_t rv[kLB];
+                bool ok[kLB];
+                load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+                for (int u = 0; u < kLB; ++u) {
+                    const T uu = tmax(v[u], (T)0);
+                    S = ok[u] ? (T)(S + uu) : S;
+                    v1 = ok[u] ? tmax(v1, uu) : v1;
+                }
             }
         }
-        S = wave_allreduce(S, OpAdd());
-        v1 = wave_allreduce(v1, OpMax());
+        if constexpr (WG) {  // (wavefront partials combined in double, rounded once)
+            S = (T)all_sum((double)S);
+            v1 = (T)all_max((double)v1);
+        } else {
+            S = wave_allreduce(S, OpAdd());
+            v1 = wave_allreduce(v1, OpMax());
+        }
         projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
         const bool padded = eq_row && pj.kind == DL_PROJ_SIMPLEX_EQ && S < pj.z;
         if (padded) {  // every entry and every padding zero is in the support: theta = (S - z) / L, final
@@ -122,21 +181,36 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             for (int it = 0; it < 4096; ++it) {
                 T sumA = (T)0;
                 long long cntl = 0;
-                for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
-                    T av[kLB], cv[kLB], v[kLB];
-                    uint32_t rv[kLB];
-                    bool ok[kLB];
-                    load_batch(o0, av, cv, rv, ok, v);
+                if (cached) {
 #pragma unroll
-                    for (int u = 0; u < kLB; ++u) {
-                        const T uu = tmax(v[u], (T)0);
-                        const bool in = ok[u] && uu > th;
-                        sumA = in ? (T)(sumA + uu) : sumA;
+                    for (int i = 0; i < kRB; ++i) {
+                        const bool in = vr[i] > th;
+                        sumA = in ? (T)(sumA + vr[i]) : sumA;
                         cntl += in ? 1 : 0;
                     }
+                } else {
+                    for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
+                        T av[kLB], cv[kLB], v[kLB];
+                        uint32_t rv[kLB];
+                        bool ok[kLB];
+                        load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+                        for (int u = 0; u < kLB; ++u) {
+                            const T uu = tmax(v[u], (T)0);
+                            const bool in = ok[u] && uu > th;
+                            sumA = in ? (T)(sumA + uu) : sumA;
+                            cntl += in ? 1 : 0;
+                        }
+                    }
                 }
-                sumA = wave_allreduce(sumA, OpAdd());
-                const long long cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                long long cntw;
+                if constexpr (WG) {
+                    sumA = (T)all_sum((double)sumA);
+                    cntw = (long long)all_sum((double)cntl);
+                } else {
+                    sumA = wave_allreduce(sumA, OpAdd());
+                    cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                }
                 if (it == 0 && cntw == 1) {
                     onehot = true;
                     break;
@@ -150,7 +224,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             }
         }
     }
-    for (uint64_t o0 = 0; o0 < len; o0 += 64u * kLB) {
+    for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
         T av[kLB], cv[kLB], v[kLB];
         uint32_t rv[kLB];
         bool ok[kLB];
@@ -174,7 +248,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             }
             obj += (double)(T)(cv[u] * x);
             ssq += (double)(T)(x * x);
-            if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + 64u * (uint64_t)u] = x;
+            if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] = x;
         }
     }
 }

@@ -420,7 +420,8 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.nnz = h->nnz;
     args.n_proj = h->n_proj;
     args.n_tiles = (uint32_t)(h->layout == 4 ? h->n_short : h->n_tiles);
-    args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short : 0);
+    args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short - h->n_xlong : 0);
+    args.n_xlong = (uint32_t)(h->layout == 4 ? h->n_xlong : 0);
     args.ablate = h->ablate;
     args.timeline = h->timeline;
     args.eq_heights = h->eq_heights;

@@ -10,7 +10,8 @@
 // Descriptor: 12 dwords { W[39:0] | hi<<40 | lo<<49 | long<<51 ; H0 ; H1 ; H2 ; H3 ; proj id ; 0 } (long: length in H0).
 // Columns that cannot sit in a window (longer than 253, touching the array's last partial quad, or using a projection
 // entry beyond the LDS table) are single-column "long" tiles: their descriptors follow the window tiles (after one all-zero
-// descriptor) and are walked by process_long_tile in a separate loop ahead of the hot one.
+// descriptor) and are walked by process_long_tile in separate loops ahead of the hot one: by one wavefront each, or -- the
+// very long ones, listed last -- by a whole workgroup.
 #include "fused_common.h"
 #include "simplex4.h"
 
@@ -121,6 +122,20 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const T s = w.s;
     // ---- single-column tiles first, in their own loop: their walker is large, latency-bound code that must not sit inside
     //      the hot loop (measured: inlined there, the extra instruction footprint cost the window tiles 6 %) ----
+    {   // very long columns first: the whole workgroup walks one together (a single wavefront would set the launch's critical path)
+        const uint32_t n_xlong = kernarg_args(g).n_xlong;
+        for (uint32_t xt = (uint32_t)wg; xt < n_xlong; xt += (uint32_t)gridDim.x) {
+            const FusedArgs<T>& gk = kernarg_args(g);
+            const uint32_t dvl = byte_offset(g.tiles32 + (size_t)(n_tiles + 1u + gk.n_long + xt) * kDesc4Words, dlane * 4u)[0];
+            const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
+            const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
+            const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
+            const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
+            const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
+            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s);
+        }
+        if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
+    }
     for (uint32_t lt = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave; lt < g.n_long; lt += S) {
         const FusedArgs<T>& gk = kernarg_args(g);
         const uint32_t dvl = byte_offset(g.tiles32 + (size_t)(n_tiles + 1u + lt) * kDesc4Words, dlane * 4u)[0];

@@ -247,7 +247,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
 
     def info(self) -> dict:
         """Kernel-side layout facts (tiles, workgroups, LDS plan) for benchmarks and tests."""
-        names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm"]
+        names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns"]
         return {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
 
     def profile(self, enable: bool) -> None:

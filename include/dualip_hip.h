@@ -86,7 +86,8 @@ int dl_matching_destroy(dl_matching* h);
 /* Size/introspection: what = 0 number of wave tiles, 1 workgroups used, 2 LDS bytes per workgroup,
  * 3 lambda staged in LDS (0/1), 4 gradient privatised in LDS (0/1), 5 bytes of owned device memory,
  * 6 number of single-column ("long") tiles, 7 row-index width in bytes, 8 tile layout (non-zeros per lane: 4 or 1),
- * 9 rows kept in LDS by the hot-rows plan (0 = plan not in use: all rows or none are), 10 share of the non-zeros in those rows x 1e6. */
+ * 9 rows kept in LDS by the hot-rows plan (0 = plan not in use: all rows or none are), 10 share of the non-zeros in those rows x 1e6,
+ * 11 single-column tiles long enough (> 1024 non-zeros) to be walked by a whole workgroup instead of one wavefront. */
 int64_t dl_matching_info(const dl_matching* h, int what);
 
 /* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays

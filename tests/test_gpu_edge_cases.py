@@ -297,3 +297,62 @@ def test_hot_rows_with_single_column_tiles_and_primal(monkeypatch):
             info = f.info()
             if info["layout"] == 4:
                 assert info["hot_rows"] == 192 and info["long_columns"] >= 3
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
+    """Columns of thousands of non-zeros are walked by all 16 wavefronts of a workgroup together (one wavefront alone would
+    set the critical path of the launch); ``forced`` lowers the threshold so that every single-column tile takes that path.
+    Simplex (several Newton passes over a 9 000-entry support), simplex_eq exact and padded, point-wise, columns in no
+    entry, with and without the hot-rows plan, primal written out."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.projections.base import ProjectionEntry
+    from tests.helpers import padded_eq_entries
+
+    if forced:
+        monkeypatch.setenv("DUALIP_HIP_XLONG_MIN", "256")
+    m, n = 10_000, 3_000
+    long_cols = ((2, 9000), (700, 3000), (1500, 2049), (2999, 2048), (5, 600), (2000, 5000))
+    p = _random_problem(m, n, 10, seed=77, long_cols=long_cols, empty_every=19)
+    lam = np.random.default_rng(10).uniform(0, 0.01, m)
+    want = 6 if forced else 5  # columns of more than 1024 non-zeros
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("simplex", {"z": 40.0}), ("box", {"lower": 0.0, "upper": 0.5})):
+            f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
+            info = f.info()
+            assert info["layout"] == 4 and info["workgroup_columns"] == want and info["long_columns"] >= 6, info
+        # simplex_eq, exact mode (the oracle's padded blocks differ wherever a clamped column sums to less than z): every
+        # non-empty column sums to z, and columns without a deficit agree with the oracle
+        td = torch.float32 if dn == "f32" else torch.float64
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map("simplex_eq", {"z": 25.0}, n), DEV), gamma=0.05)
+        x = f.calculate(torch.from_numpy(lam).to(td).to(DEV), save_primal=True).primal_var.cpu().numpy().astype(np.float64)
+        _, _, _, xo = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.05, [("simplex_eq", {"z": 25.0})], dtype=NP_DT[dn])
+        v = p["a"] * (-lam / 0.05)[p["rowidx"]] - p["c"] / 0.05
+        assert x.min() >= 0
+        for j in range(n):
+            k0, k1 = int(p["colptr"][j]), int(p["colptr"][j + 1])
+            if k1 > k0:
+                assert abs(x[k0:k1].sum() - 25.0) < 25.0 * (1e-4 if dn == "f32" else 1e-10), j
+                if np.maximum(v[k0:k1], 0).sum() > 25.5:
+                    assert np.abs(x[k0:k1] - xo[k0:k1]).max() < RTOL[dn] * 25, j
+        pm = {
+            "s": ProjectionEntry("simplex", {"z": 3.0}, indices=list(range(0, 1000))),
+            "b": ProjectionEntry("box", {"lower": 0.0, "upper": 0.7}, indices=list(range(1000, 1800))),
+            "e": ProjectionEntry("simplex_eq", {"z": 2.0}, indices=list(range(2500, 3000))),
+        }
+        col_proj = np.full(n, -1, dtype=np.int32)
+        col_proj[0:1000], col_proj[1000:1800], col_proj[2500:3000] = 0, 1, 2
+        _compare(p, pm, [("simplex", {"z": 3.0}), ("box", {"lower": 0.0, "upper": 0.7}), ("simplex_eq", {"z": 2.0})], col_proj, 0.03, dn, lam)
+    # padded simplex_eq blocks through the workgroup walker
+    zz = 4000.0
+    entries, _, col_proj = padded_eq_entries(p, zz, True)
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex_eq", {"z": zz}, n), DEV), gamma=0.03, simplex_eq_padding="reference")
+    res = f.calculate(torch.from_numpy(lam).to(DEV), save_primal=True)
+    ax, obj0, ssq, x = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.03, entries, col_proj=col_proj, dtype=np.float64)
+    assert relerr(res.primal_var.cpu().numpy(), x) < RTOL["f64"]
+    # hot-rows plan: the walker gathers / scatters cold rows through memory
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "2048")
+    for dn in ("f32", "f64"):
+        f = _compare(p, create_projection_map("simplex", {"z": 1.0}, n), [("simplex", {"z": 1.0})], None, 0.05, dn, lam)
+        assert f.info()["hot_rows"] == 2048 and f.info()["workgroup_columns"] == want

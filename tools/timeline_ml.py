@@ -1,0 +1,32 @@
+"""Developer tool: per-workgroup timeline of one fused launch on the MovieLens-shaped problem (benchmark/movielens_like.py)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DUALIP_HIP_TIMELINE", "1")
+import numpy as np
+import torch
+
+from benchmark.movielens_like import generate
+from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+
+from dualip_amd.objectives.matching import MatchingInputArgs
+from dualip_amd.projections import create_projection_map
+
+A, C, counts = generate()
+m, n = int(A.shape[0]), int(A.shape[1])
+inp = MatchingInputArgs(A=A, c=C, projection_map=create_projection_map("simplex", {"z": 1.0}, n, indices=range(n)), b_vec=torch.full((m,), 30.0, device="cuda:0"))
+f = MatchingSolverDualObjectiveFunction(inp, 0.1)
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+solver = AcceleratedGradientDescent(max_iter=iters, gamma=0.1, initial_step_size=1e-8, max_step_size=1e-6, iteration_callback=False)
+run = solver.start_device_run(f, torch.zeros(m, dtype=torch.float32, device="cuda:0"), rank=0)
+run.advance(iters)
+torch.cuda.synchronize()
+us = (f.timeline().astype(np.int64) - f.timeline().astype(np.int64)[:, 0].min()) / 100.0
+print("info", f.info())
+for k, name in enumerate(["start", "stamp1", "loop_done", "end"]):
+    print(f"{name:10s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
+print("phase durations (mean / max): 0->1 %.1f / %.1f   1->2 %.1f / %.1f   2->3 %.1f / %.1f" % (
+    (us[:, 1] - us[:, 0]).mean(), (us[:, 1] - us[:, 0]).max(), (us[:, 2] - us[:, 1]).mean(), (us[:, 2] - us[:, 1]).max(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
