@@ -103,7 +103,8 @@ struct StatsArgs {
     // hot-rows plan of the matching handle (inv != null): slab column p is the caller's row inv[p]; columns >= m_hot are in `cold`
     const int32_t* __restrict__ inv;
     int64_t m_hot;
-    const long long* __restrict__ cold;
+    const long long* cold;
+    long long* cold_zero;  // == cold when the step should leave the accumulators zeroed for the next fused launch, else null
     // ... or an already reduced (and, when sharded, all-reduced) packed buffer
     const double* __restrict__ packed_in;
     double* __restrict__ packed_out;  // [m+2]: written when reducing slabs (kept for logging / callers)
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
         {   // latency bound: eight slabs in flight before the first is added (slabs past the end re-read the last one)
             const int64_t rc = live ? col : p.m - 1;
             const bool in_slabs = !p.inv || rc < p.m_hot;
-            if (!in_slabs && ws == 0) acc = p.cold[rc];
+            if (!in_slabs && ws == 0) {
+                acc = p.cold[rc];
+                if (p.cold_zero && live) p.cold_zero[rc] = 0;  // consumed: ready for the next fused launch (no memset launch)
+            }
             constexpr int kU = 8;
             for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
                 long long v[kU];
@@ -247,6 +251,8 @@ struct ApplyArgs {
     const uint8_t* __restrict__ eq_mask;
     const float* __restrict__ beta;
     int64_t iter;
+    T* __restrict__ x_perm;              // or null
+    const int32_t* __restrict__ perm;    // caller's row -> renumbered row
 };
 
 template <class T>
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(kApplyThreads) void agd_apply_kernel(ApplyArgs<T> p
         const T xn = (T)((T)(yn * omb) + (T)(p.y[mine] * bb));       // agd.py:184
         p.y_new[mine] = yn;
         p.x_next[mine] = xn;
+        if (p.x_perm) p.x_perm[p.perm[mine]] = xn;  // hot-rows plan of the matching handle: next launch's dual vector, renumbered
     }
 }
 
@@ -496,7 +503,7 @@ int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t s
 }
 
 template <class T>
-static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
+static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
                           double decay_factor, hipStream_t st) {
     const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
     AgdDevState* states = (AgdDevState*)s->state;
@@ -514,6 +521,7 @@ static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed,
         sa.inv = (f && f->m_hot > 0) ? f->row_inv : nullptr;
         sa.m_hot = f ? f->m_hot : 0;
         sa.cold = f ? f->cold_grad : nullptr;
+        sa.cold_zero = (f && f->m_hot > 0) ? f->cold_grad : nullptr;
         sa.packed_in = packed;
         sa.packed_out = s->packed;
         sa.b = (const T*)b;
@@ -546,6 +554,8 @@ static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed,
     aa.eq_mask = s->eq_mask;
     aa.beta = s->beta;
     aa.iter = iter;
+    aa.x_perm = (f && f->m_hot > 0) ? (T*)f->lam_perm : nullptr;
+    aa.perm = f ? f->row_perm : nullptr;
     const unsigned grid = (unsigned)std::max<int64_t>(1, (s->m + kApplyThreads - 1) / kApplyThreads);
     hipLaunchKernelGGL(agd_apply_kernel<T>, dim3(grid), dim3(kApplyThreads), 0, st, aa);
     DL_HIP(hipGetLastError());
@@ -554,12 +564,16 @@ static int agd_step_typed(dl_agd* s, const dl_matching* f, const double* packed,
     std::swap(s->g, s->g_old);
     std::swap(s->x, s->x_alt);
     s->state_cur ^= 1;
+    if (f && f->m_hot > 0) {
+        f->hot_ready = true;
+        f->hot_ready_lambda = s->x;
+    }
     return 0;
 }
 
 // f != nullptr: A x is taken from the matching handle's integer slabs (single-device loop, no separate slab reduction);
 // f == nullptr: A x is read from `packed` (already reduced, and all-reduced when sharded).
-int launch_agd_step(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
+int launch_agd_step(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
                     hipStream_t st) {
     if (s->val_dtype == DL_F32) return agd_step_typed<float>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);
     return agd_step_typed<double>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);

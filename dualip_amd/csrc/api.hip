@@ -40,7 +40,7 @@ int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* 
 size_t agd_state_bytes();
 int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st);
 int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t st);
-int launch_agd_step(dl_agd* s, const dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
+int launch_agd_step(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
                     double decay_factor, hipStream_t st);
 size_t agd_partial_stats_bytes(int64_t m);
 int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st);
@@ -104,6 +104,7 @@ static void matching_free(dl_matching* h) {
     if (h->timeline) (void)hipFree(h->timeline);
     if (h->eq_heights) (void)hipFree(h->eq_heights);
     if (h->row_inv) (void)hipFree(h->row_inv);
+    if (h->row_perm) (void)hipFree(h->row_perm);
     if (h->lam_perm) (void)hipFree(h->lam_perm);
     if (h->cold_grad) (void)hipFree(h->cold_grad);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
@@ -530,6 +531,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     if (h->m_hot > 0) {
         CK(owned_malloc(h, (void**)&h->row_inv, sizeof(int32_t) * (size_t)m));
+        CK(owned_malloc(h, (void**)&h->row_perm, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, &h->lam_perm, (size_t)m * (val_dtype == DL_F32 ? 4 : 8)));
         CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad));
     }
@@ -595,9 +597,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         for (int64_t i = 0; i < m; ++i) inv[(size_t)i] = (int32_t)i;
         std::stable_sort(inv.begin(), inv.end(), [&](int32_t x, int32_t y) { return row_count_h[(size_t)x] > row_count_h[(size_t)y]; });
         for (int64_t pnew = 0; pnew < m; ++pnew) perm[(size_t)inv[(size_t)pnew]] = (int32_t)pnew;
-        int32_t* perm_dev = nullptr;
-        e = hipMalloc((void**)&perm_dev, sizeof(int32_t) * (size_t)m);
-        if (e == hipSuccess) e = hipMemcpyAsync(perm_dev, perm.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, st);
+        int32_t* perm_dev = h->row_perm;  // kept: the AGD step kernel writes the next dual vector in renumbered order with it
+        e = hipMemcpyAsync(perm_dev, perm.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(h->row_inv, inv.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             const int threads = 256;
@@ -608,7 +609,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);  // perm / inv are host temporaries
-        if (perm_dev) (void)hipFree(perm_dev);
         if (e != hipSuccess) {
             matching_free(h);
             return hip_fail(e, "row renumbering");
@@ -824,6 +824,8 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
     if (first_iter < 1 || n_iters < 0 || first_iter + n_iters - 1 > s->max_iter) return fail(DL_E_STATE, "iteration range outside 1..max_iter");
     hipStream_t st = (hipStream_t)stream;
     double gamma = *gamma_io_host;
+    if (first_iter == 1 || f->hot_ready_owner != s) f->hot_ready = false;  // a new run (or another optimiser) starts from its own dual vector
+    f->hot_ready_owner = s;
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
         const bool empty = f->n_tiles == 0 || f->n_wg == 0;

@@ -99,6 +99,12 @@ struct dl_matching {
     int64_t m_hot = 0;                // 0 = plan not in use
     double hot_fraction = 1.0;        // share of the non-zeros whose row is hot
     int32_t* row_inv = nullptr;       // owned, [m]: renumbered row -> caller's row
+    int32_t* row_perm = nullptr;      // owned, [m]: caller's row -> renumbered row
+    // device-resident AGD loop: its step kernels leave the renumbered dual vector in lam_perm and the cold accumulators
+    // zeroed for the next launch (two launches less per iteration); valid only for the dual vector at hot_ready_lambda
+    bool hot_ready = false;
+    const void* hot_ready_lambda = nullptr;
+    const void* hot_ready_owner = nullptr;  // the dl_agd whose loop prepared them
     void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
     long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
     int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)

@@ -428,10 +428,13 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.m_hot = h->m_hot;
     args.cold_grad = h->cold_grad;
     if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
-        const unsigned blocks = (unsigned)((h->m + 255) / 256);
-        hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
-        DL_HIP(hipGetLastError());
-        DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad, st));
+        if (!(h->hot_ready && h->hot_ready_lambda == lambda)) {  // (the device-resident AGD loop leaves both prepared, common.h)
+            const unsigned blocks = (unsigned)((h->m + 255) / 256);
+            hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
+            DL_HIP(hipGetLastError());
+            DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad, st));
+        }
+        h->hot_ready = false;  // this launch fills the cold accumulators
         args.lambda = static_cast<const T*>(h->lam_perm);
     }
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));

@@ -356,3 +356,37 @@ def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
     for dn in ("f32", "f64"):
         f = _compare(p, create_projection_map("simplex", {"z": 1.0}, n), [("simplex", {"z": 1.0})], None, 0.05, dn, lam)
         assert f.info()["layout"] != 4 or (f.info()["hot_rows"] == 2048 and f.info()["workgroup_columns"] == want)
+
+
+def test_hot_rows_state_survives_outside_calls_between_iterations(monkeypatch):
+    """The device-resident loop leaves the renumbered dual vector and the zeroed cold accumulators ready for its next fused
+    launch; a calculate() from outside on the same objective (here: from the iteration callback, with another dual vector)
+    must not be mistaken for that state, and neither must a second run on the same objective."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "128")
+    p = _skewed_problem(700, 5_000, 9, seed=43)
+    m = p["m"]
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), DEV), gamma=0.05)
+    if f.info()["layout"] == 4:
+        assert f.info()["hot_rows"] == 128
+    kw = dict(max_iter=30, gamma=0.05, initial_step_size=1e-4, max_step_size=1e-2)
+    zero = torch.zeros(m, dtype=torch.float64, device=DEV)
+    plain = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, zero)
+    other = torch.rand(m, dtype=torch.float64, device=DEV) * 0.05
+    seen = []
+
+    def intrude(it, result):
+        seen.append(float(f.calculate(other).dual_objective))
+
+    poked = AcceleratedGradientDescent(iteration_callback=intrude, **kw).maximize(f, zero)
+    again = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, zero)
+    assert len(seen) == 30 and max(seen) - min(seen) == 0.0
+    assert poked.dual_objective_log == plain.dual_objective_log and again.dual_objective_log == plain.dual_objective_log
+    assert torch.equal(poked.dual_val, plain.dual_val) and torch.equal(again.dual_val, plain.dual_val)
+    # a warm start from another vector on the same objective
+    warm = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, other)
+    ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), DEV), gamma=0.05)
+    assert AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(ref, other).dual_objective_log == warm.dual_objective_log
