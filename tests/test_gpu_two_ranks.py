@@ -46,6 +46,15 @@ def _worker(rank, world, port, kind, q):
         p = problem(z)
         gamma, iters, s0, s1 = z["params"]
         n = p["n"]
+        if kind == "run_solver":  # the entry point with compute_device_num = 2: every rank passes the GLOBAL problem (CPU tensors)
+            from dualip_amd.run_solver import run_solver
+            from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
+
+            args = torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, n), "cpu")
+            res = run_solver(args, SolverArgs(max_iter=int(iters), gamma=float(gamma), initial_step_size=float(s0), max_step_size=float(s1)),
+                             ComputeArgs(host_device="cuda:0", compute_device_num=2), ObjectiveArgs(objective_type="matching"))
+            q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), 0))
+            return
         if kind in ("mixed", "mixed_custom"):
             half = int(z["mixed_boundary"])
             first = ("box", {"lower": 0.0, "upper": 1.0})
@@ -88,7 +97,7 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom"])
+@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom", "run_solver"])
 def test_two_ranks_share_one_gpu(kind):
     from tests.helpers import load, relerr
 
@@ -106,7 +115,7 @@ def test_two_ranks_share_one_gpu(kind):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     z = load("g3_syn2000.npz")
-    key = "simplex1|w2|f64" if kind == "simplex" else "mixed|w2|f64"  # (the custom clamp is the same projection as box [0, 1])
+    key = "simplex1|w2|f64" if kind in ("simplex", "run_solver") else "mixed|w2|f64"  # (the custom clamp is the same projection as box [0, 1])
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
     # both ranks apply the identical update: identical duals, bit for bit, without a broadcast
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
