@@ -174,10 +174,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
-            const T vj = (T)(t1 + (T)(s * cur.c.v[j]));  // matching.py:66,142
-            v[j] = (e0 + (uint32_t)j < span) ? vj : (T)0;
+            v[j] = (T)(t1 + (T)(s * cur.c.v[j]));      // matching.py:66,142
         }
         if (is_simplex_kind(kind)) {
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) v[j] = (e0 + (uint32_t)j < span) ? v[j] : (T)0;  // slots outside the tile: dummy columns of zeros
             uint64_t H[kSlots];
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) H[j] = ((uint64_t)rl(cur.dv, 3 + 2 * j) << 32) | rl(cur.dv, 2 + 2 * j);
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
                     scatter_fixed(w.gacc, row[j], ax, w.scale);
                 }
             }
-            o32 = (T)(o32 + (T)(cur.c.v[j] * xq));
-            q32 = (T)(q32 + (T)(xq * xq));
+            o32 = fma_exact(cur.c.v[j], xq, o32);  // (the two objective sums are not bit-specified by the reference: fused multiply-adds)
+            q32 = fma_exact(xq, xq, q32);
             x[j] = xq;
         }
         obj += (double)o32;
