@@ -105,6 +105,7 @@ struct StatsArgs {
     int64_t m_hot;
     const long long* cold;
     long long* cold_zero;  // == cold when the step should leave the accumulators zeroed for the next fused launch, else null
+    const double* dense;   // fairness pair of the matching handle: (A x) of rows m-2, m-1, or null
     // ... or an already reduced (and, when sharded, all-reduced) packed buffer
     const double* __restrict__ packed_in;
     double* __restrict__ packed_out;  // [m+2]: written when reducing slabs (kept for logging / callers)
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
             long long t = shi[rl];
             for (int q = 1; q < kStatSlices; ++q) t += shi[q * kStatRows + rl];
             ax = ldexp((double)t, -(*p.shift_in));
+            if (p.dense && row >= p.m - 2) ax = p.dense[row - (p.m - 2)];  // fairness pair of the matching handle: the two dense rows
             p.packed_out[row] = ax;
         }
     } else {
@@ -522,6 +524,7 @@ static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const
         sa.m_hot = f ? f->m_hot : 0;
         sa.cold = f ? f->cold_grad : nullptr;
         sa.cold_zero = (f && f->m_hot > 0) ? f->cold_grad : nullptr;
+        sa.dense = (f && f->fair) ? f->dense_ax : nullptr;
         sa.packed_in = packed;
         sa.packed_out = s->packed;
         sa.b = (const T*)b;

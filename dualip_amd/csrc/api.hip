@@ -105,6 +105,8 @@ static void matching_free(dl_matching* h) {
     if (h->eq_heights) (void)hipFree(h->eq_heights);
     if (h->row_inv) (void)hipFree(h->row_inv);
     if (h->row_perm) (void)hipFree(h->row_perm);
+    if (h->partial_fair) (void)hipFree(h->partial_fair);
+    if (h->dense_ax) (void)hipFree(h->dense_ax);
     if (h->lam_perm) (void)hipFree(h->lam_perm);
     if (h->cold_grad) (void)hipFree(h->cold_grad);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
@@ -686,6 +688,40 @@ int dl_matching_profile(dl_matching* h, int enable) {
     if (!h) return fail(DL_E_ARG, "null handle");
     h->prof_on = enable != 0;
     h->prof_used = 0;
+    return 0;
+}
+
+int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t stream) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    if (!f_values) {
+        h->fair = nullptr;
+        return 0;
+    }
+    if (h->m < 2) return fail(DL_E_ARG, "the fairness pair needs at least its own two rows");
+    if (h->n_tiles > 0 && (h->layout != 4 || !h->lam_lds || !h->grad_lds))
+        return fail(DL_E_STATE, "the fairness pair needs the 256-wide tile layout with the dual vector and the gradient in LDS (16-byte aligned values, nnz >= 1024)");
+    if ((reinterpret_cast<uintptr_t>(f_values) & 15u) != 0) return fail(DL_E_ARG, "fairness values must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->partial_fair) {
+        int rc = owned_malloc(h, (void**)&h->partial_fair, sizeof(double) * (size_t)(h->n_wg > 0 ? h->n_wg : 1));
+        if (!rc) rc = owned_malloc(h, (void**)&h->dense_ax, sizeof(double) * 2);
+        if (rc) return rc;
+        DL_HIP(hipMemsetAsync(h->dense_ax, 0, sizeof(double) * 2, st));
+    }
+    {   // max |f| (bounds |v| for unbounded projections, like max |a| and max |c| taken at create time)
+        unsigned long long* mx_dev = nullptr;
+        unsigned long long bits = 0;
+        DL_HIP(hipMalloc((void**)&mx_dev, sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(mx_dev, 0, sizeof(unsigned long long), st);
+        if (e == hipSuccess && launch_absmax(h->val_dtype, h->nnz, f_values, mx_dev, st)) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bits, mx_dev, sizeof(bits), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(mx_dev);
+        if (e != hipSuccess) return hip_fail(e, "fairness values");
+        memcpy(&h->fair_max, &bits, sizeof(double));
+    }
+    h->fair = f_values;
+    h->hot_ready = false;
     return 0;
 }
 

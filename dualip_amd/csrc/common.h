@@ -105,6 +105,11 @@ struct dl_matching {
     bool hot_ready = false;
     const void* hot_ready_lambda = nullptr;
     const void* hot_ready_owner = nullptr;  // the dl_agd whose loop prepared them
+    // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 are dense, +f_k / -f_k on every non-zero
+    const void* fair = nullptr;       // caller-owned val[nnz]
+    double fair_max = 0.0;            // max |f|
+    double* partial_fair = nullptr;   // owned, [n_wg]
+    double* dense_ax = nullptr;       // owned, [2]: (A x) of the two rows, written after every fused launch
     void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
     long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
     int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)

@@ -39,6 +39,11 @@ struct FusedArgs {
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does
     long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed)
     const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
+    // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 carry +f_k / -f_k on EVERY non-zero k
+    const T* fair;                 // f, in the order of a / c, or null
+    const T* lambda_orig;          // the caller's dual vector (g.lambda is the renumbered copy under the hot-rows plan)
+    double* partial_fair;          // [n_wg]: sum f_k x_k of the workgroup
+    double fair_max;               // max |f| (0 without the pair): enters the |v| bound of unbounded projections
 };
 
 // a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
@@ -78,7 +83,7 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 template <class T, class RowT, bool LAM_LDS, bool WG = false>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
-                                              double* red = nullptr) {
+                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr) {
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
     auto all_sum = [&](double x) -> double {
@@ -119,6 +124,13 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
         for (int u = 0; u < kLB; ++u) {
             const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv[u] < m_hot)) ? lam_s[rv[u]] : (T)(s * g.lambda[rv[u]]);
             v[u] = (T)((T)(av[u] * lam) + (T)(s * cv[u]));
+        }
+        if (fair_acc) {  // fairness pair: + f_k * (-(lambda_K - lambda_{K+1}) / gamma)
+#pragma unroll
+            for (int u = 0; u < kLB; ++u) {
+                const uint64_t o = o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u;
+                v[u] = (T)(v[u] + (T)(sd * g.fair[k0 + (ok[u] ? o : len - 1)]));
+            }
         }
     };
     T th = (T)0;
@@ -248,6 +260,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             }
             obj += (double)(T)(cv[u] * x);
             ssq += (double)(T)(x * x);
+            if (fair_acc) *fair_acc += (double)(T)(g.fair[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] * x);
             if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] = x;
         }
     }
@@ -322,7 +335,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     {
         double xmax = g.xmax_bounded;
         if (g.has_unbounded) {
-            const double vmax = fabs(-1.0 / g.gamma) * (g.amax * lmax + g.cmax);
+            const double vmax = fabs(-1.0 / g.gamma) * ((g.amax + 2.0 * g.fair_max) * lmax + g.cmax);  // (|lambda_K - lambda_{K+1}| <= 2 lmax)
             const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
             xmax = ub > xmax ? ub : xmax;
         }
@@ -339,13 +352,16 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
 }
 
 // Epilogue: scalar partials of the workgroup, then its private gradient slab.
-template <class T, bool GRAD_LDS>
-__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, double obj, double ssq, int tid, int lane, int wave, int wg) {
+template <class T, bool GRAD_LDS, bool FAIR = false>
+__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, double obj, double ssq, int tid, int lane, int wave, int wg,
+                                               double fair = 0.0) {
     obj = wave_allreduce(obj, OpAdd());
     ssq = wave_allreduce(ssq, OpAdd());
+    if constexpr (FAIR) fair = wave_allreduce(fair, OpAdd());
     if (lane == 0) {
         w.red_s[2 * wave] = obj;
         w.red_s[2 * wave + 1] = ssq;
+        if constexpr (FAIR) w.red_s[2 * kFusedWaves + wave] = fair;
     }
     __syncthreads();
     if (tid == 0) {
@@ -356,6 +372,11 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
         }
         g.partial_scal[2 * (int64_t)wg] = o;
         g.partial_scal[2 * (int64_t)wg + 1] = q;
+        if constexpr (FAIR) {
+            double fsum = 0.0;
+            for (int k = 0; k < kFusedWaves; ++k) fsum += w.red_s[2 * kFusedWaves + k];
+            g.partial_fair[wg] = fsum;
+        }
     }
     if constexpr (GRAD_LDS) {
         long long* slab = g.partial + (int64_t)wg * g.mpad;

@@ -268,7 +268,7 @@ constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
 __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
-                                                                      const long long* __restrict__ cold) {
+                                                                      const long long* __restrict__ cold, const double* __restrict__ dense) {
     __shared__ long long shi[kRedThreads];
     __shared__ double sh[kRedThreads / 32];
     const int tid = threadIdx.x;
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         if (ws == 0 && row < m) {
             long long t = shi[rl];
             for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
-            packed[inv ? (int64_t)inv[row] : row] = ldexp((double)t, -(*shift_in));
+            const int64_t orow = inv ? (int64_t)inv[row] : row;
+            packed[orow] = (dense && orow >= m - 2) ? dense[orow - (m - 2)] : ldexp((double)t, -(*shift_in));  // (fairness pair: the two dense rows)
         }
         return;
     }
@@ -393,6 +394,21 @@ __global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, cons
     if (p < m) dst[p] = src[inv[p]];
 }
 
+// fairness pair: (A x) of the two dense rows from the workgroups' partial sums (fixed order)
+__global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restrict__ partial_fair, int n_wg, double* __restrict__ dense_ax) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int w = threadIdx.x; w < n_wg; w += 256) v += partial_fair[w];
+    v = wave_allreduce(v, OpAdd());
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double f = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        dense_ax[0] = f;
+        dense_ax[1] = -f;
+    }
+}
+
 // the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
 template <class T>
 static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
@@ -427,6 +443,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.eq_heights = h->eq_heights;
     args.m_hot = h->m_hot;
     args.cold_grad = h->cold_grad;
+    args.fair = static_cast<const T*>(h->fair);
+    args.lambda_orig = static_cast<const T*>(lambda);
+    args.partial_fair = h->partial_fair;
+    args.fair_max = h->fair ? h->fair_max : 0.0;
     if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
         if (!(h->hot_ready && h->hot_ready_lambda == lambda)) {  // (the device-resident AGD loop leaves both prepared, common.h)
             const unsigned blocks = (unsigned)((h->m + 255) / 256);
@@ -458,6 +478,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
+    if (h->fair) {
+        hipLaunchKernelGGL(fair_finish_kernel, dim3(1), dim3(256), 0, st, h->partial_fair, h->n_wg, h->dense_ax);
+        DL_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -477,7 +501,8 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
-                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad);
+                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad,
+                       h->fair ? h->dense_ax : nullptr);
     DL_HIP(hipGetLastError());
     return 0;
 }

@@ -47,7 +47,9 @@ __device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, in
 
 // HOT: the hot-rows plan (common.h) -- rows are renumbered by frequency, rows < g.m_hot gather from / scatter to LDS, the
 // cold tail reads the (renumbered) dual vector through L2 and adds to g.cold_grad with 64-bit global atomics.
-template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool HOT>
+// FAIR: the fairness pair of dl_matching_set_fairness -- one more streamed value f_k per non-zero, entering v_k with the
+// difference of the last two duals; its sum f.x goes to g.partial_fair (rows m-2 / m-1 of the gradient are +- that sum).
+template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool HOT, bool FAIR = false>
 __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArgs<T> g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const int wg = blockIdx.x;
     stamp(g, wg, tid, 0);
     const LaneConst lc = make_lane_const(lane);
-    double obj = 0.0, ssq = 0.0;
+    double obj = 0.0, ssq = 0.0, fair = 0.0;
 
     // ---- tile schedule ----
     // Descriptors are stored in SCHEDULE order (api.hip: schedule_tiles4) and dealt cyclically to the S = 16 * workgroups
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         uint32_t w0lo, w0hi;
         Quad<T> a, c;
         RowQuad<RowT> r;
+        Quad<T> f;  // (FAIR only)
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     auto window_of = [&](uint32_t w0lo, uint32_t w0hi) -> uint64_t {  // element index of the window start (0 for padding / long tiles)
@@ -108,6 +111,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             t.c.v[j] = cv[j];
             t.r.v[j] = rv[j];
         }
+        if constexpr (FAIR) {
+            const vec4 fv = __builtin_nontemporal_load(byte_offset(reinterpret_cast<const vec4*>(g.fair + W), q * (uint32_t)sizeof(vec4)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.f.v[j] = fv[j];
+        }
     };
 
     uint32_t ti = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;  // schedule slot
@@ -120,6 +128,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
     stamp(g, wg, tid, 1);
     const T s = w.s;
+    T sd = (T)0;  // -(lambda_K - lambda_{K+1}) / gamma, K = m - 2
+    if constexpr (FAIR) sd = (T)(s * (T)(g.lambda_orig[g.m - 2] - g.lambda_orig[g.m - 1]));
     // ---- single-column tiles first, in their own loop: their walker is large, latency-bound code that must not sit inside
     //      the hot loop (measured: inlined there, the extra instruction footprint cost the window tiles 6 %) ----
     {   // very long columns first: the whole workgroup walks one together (a single wavefront would set the launch's critical path)
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
             const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
-            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s);
+            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
+                                                      FAIR ? &fair : nullptr);
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
     }
@@ -144,7 +155,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
         const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
         const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
-        process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0);
+        process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
+                                            FAIR ? &fair : nullptr);
     }
     if (ti < n_tiles) unpack_and_issue(dv0, tA);
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         for (int j = 0; j < kSlots; ++j) {
             const T t1 = (T)(cur.a.v[j] * lam[j]);     // sparse_utils.py:79
             v[j] = (T)(t1 + (T)(s * cur.c.v[j]));      // matching.py:66,142
+            if constexpr (FAIR) v[j] = (T)(v[j] + (T)(sd * cur.f.v[j]));
         }
         if (is_simplex_kind(kind)) {
 #pragma unroll
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) x[j] = project_pointwise(v[j], pj);
         }
-        T o32 = (T)0, q32 = (T)0;
+        T o32 = (T)0, q32 = (T)0, f32 = (T)0;
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             const T xq = (e0 + (uint32_t)j < span) ? x[j] : (T)0;  // (a clamp with lower > 0 moves the zero-filled slots)
@@ -212,10 +225,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             }
             o32 = fma_exact(cur.c.v[j], xq, o32);  // (the two objective sums are not bit-specified by the reference: fused multiply-adds)
             q32 = fma_exact(xq, xq, q32);
+            if constexpr (FAIR) f32 = fma_exact(cur.f.v[j], xq, f32);
             x[j] = xq;
         }
         obj += (double)o32;
         ssq += (double)q32;
+        if constexpr (FAIR) fair += (double)f32;
         if (g.x_out) {
             T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
 #pragma unroll
@@ -233,16 +248,16 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         __syncthreads();
         stamp(g, wg, tid, 2);
     }
-    fused_epilogue<T, GRAD_LDS>(g, w, obj, ssq, tid, lane, wave, wg);
+    fused_epilogue<T, GRAD_LDS, FAIR>(g, w, obj, ssq, tid, lane, wave, wg, fair);
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 3);
     }
 }
 
-template <class T, class RowT, bool LAM, bool GRAD, bool HOT>
+template <class T, class RowT, bool LAM, bool GRAD, bool HOT, bool FAIR = false>
 static int launch_fused4_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
-    auto kern = matching_fused_kernel4<T, RowT, LAM, GRAD, HOT>;
+    auto kern = matching_fused_kernel4<T, RowT, LAM, GRAD, HOT, FAIR>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
@@ -255,6 +270,10 @@ static int launch_fused4_inst(const dl_matching* h, const FusedArgs<T>& args, hi
 
 template <class T, class RowT>
 static int launch_fused4_rt(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
+    if (args.fair) {  // (dl_matching_set_fairness only accepts handles whose dual vector and gradient live in LDS)
+        if (h->m_hot > 0) return launch_fused4_inst<T, RowT, true, true, true, true>(h, args, st);
+        return launch_fused4_inst<T, RowT, true, true, false, true>(h, args, st);
+    }
     if (h->m_hot > 0) return launch_fused4_inst<T, RowT, true, true, true>(h, args, st);
     if (h->lam_lds && h->grad_lds) return launch_fused4_inst<T, RowT, true, true, false>(h, args, st);
     if (h->grad_lds) return launch_fused4_inst<T, RowT, false, true, false>(h, args, st);

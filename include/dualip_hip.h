@@ -105,6 +105,16 @@ int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, doub
  * returns the number of launches and their summed duration in milliseconds since the hook was (re-)enabled. */
 int dl_matching_profile(dl_matching* h, int enable);
 int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host);
+/* Fairness pair -- the extension the reference documents in docs/demo/matching_complex.rst:8-168 (two extra constraint
+ * rows whose coefficients +f_k / -f_k sit on EVERY stored non-zero k; A_fairness there is a scaled copy of A's values).
+ * Create the handle with m = K + 2 rows (row indices stay < K); after this call rows K and K+1 are that pair:
+ *     v_k = a_k s[r_k] + f_k (s[K] - s[K+1]) + c_k (-1/gamma),   (A x)_K = sum_k f_k x_k,   (A x)_{K+1} = -(A x)_K
+ * so lambda / packed_out / b keep their m = K + 2 layout and the optimiser entry points need no change.
+ *   f_values: val_dtype[nnz] in the order of a / c, 16-byte aligned, caller-owned, read by every launch (NULL: switch off).
+ * One more streamed value per non-zero (16 instead of 12 bytes in fp32).  Needs the 256-wide tile layout with the dual vector
+ * and the gradient (or their hot rows) in LDS; otherwise DL_E_STATE. */
+int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t stream);
+
 /* simplex_eq reference-compatibility mode.  By default "simplex_eq" is the exact projection onto
  * {x >= 0, sum x = z} over the column's own entries.  The reference projects inside a zero-padded [L x K] block per
  * nnz-bucket (sparse_utils.py:185-209; matching.py:87-114), so when a clamped column sums to less than z its deficit is

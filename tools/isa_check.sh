@@ -4,7 +4,7 @@ cd /tmp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe
 python3 - <<'PY'
 import re
 s=open('/tmp/k4.s').read()
-name='_ZN2dl22matching_fused_kernel4IftLb1ELb1ELb0EEEvNS_9FusedArgsIT_EE'
+name='_ZN2dl22matching_fused_kernel4IftLb1ELb1ELb0ELb0EEEvNS_9FusedArgsIT_EE'
 i=s.index('\n'+name+':'); j=s.index('.Lfunc_end', i)
 body=s[i:j]; L=body.split('\n')
 print('lines', len(L), 'writelane', body.count('v_writelane'), 'readlane', body.count('v_readlane'), 'scratch', body.count('scratch_'))
