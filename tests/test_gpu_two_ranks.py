@@ -46,6 +46,24 @@ def _worker(rank, world, port, kind, q):
         p = problem(z)
         gamma, iters, s0, s1 = z["params"]
         n = p["n"]
+        if kind == "fairness":  # the fairness pair, column-sharded: every rank streams its slice of f; the pair's rows are all-reduced like the others
+            from dualip_amd.objectives.matching_fairness import MatchingFairnessDualObjectiveFunction
+
+            zf = load("gf_fairness.npz")
+            p1 = problem(load("g1_syn2000.npz"))
+            n1, m1 = p1["n"], p1["m"]
+            lo, hi = (0, n1 // 2) if rank == 0 else (n1 // 2, n1)
+            sub = sub_problem(p1, lo, hi)
+            k0, k1 = int(p1["colptr"][lo]), int(p1["colptr"][hi])
+            b_full = torch.cat([torch.from_numpy(p1["b"]), torch.tensor([float(zf["delta"])] * 2, dtype=torch.float64)])
+            largs = torch_args(sub, "f64", create_projection_map("simplex", {"z": 1.0}, sub["n"]), "cuda:0")
+            largs.b_vec = b_full.to("cuda:0")
+            ff = MatchingFairnessDualObjectiveFunction(largs, 0.02, A_fairness=torch.from_numpy(zf["f|f64"][k0:k1].copy()).to("cuda:0"), native=True)
+            f = MatchingSolverDualObjectiveFunctionDistributed(None, b_full, 0.02, host_device="cuda:0", local_objective=ff.inner)
+            solver = AcceleratedGradientDescent(max_iter=60, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
+            res = solver.maximize(f, torch.zeros(m1 + 2, dtype=torch.float64, device="cuda:0"), rank=rank)
+            q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), 0))
+            return
         if kind == "run_solver":  # the entry point with compute_device_num = 2: every rank passes the GLOBAL problem (CPU tensors)
             from dualip_amd.run_solver import run_solver
             from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
@@ -97,9 +115,12 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom", "run_solver"])
+@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom", "run_solver", "fairness"])
 def test_two_ranks_share_one_gpu(kind):
     from tests.helpers import load, relerr
+
+    if kind == "fairness" and os.environ.get("DUALIP_HIP_LAYOUT") == "1":
+        pytest.skip("the fairness stream belongs to the 256-wide tile layout")
 
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -114,6 +135,12 @@ def test_two_ranks_share_one_gpu(kind):
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    if kind == "fairness":  # the single-process trace of the reference's operators (gf_fairness.npz)
+        zf = load("gf_fairness.npz")
+        assert relerr(out[0][0][:40], zf["trace|simplex1|f64|obj_log"][:40]) < 1e-8
+        assert out[0][1][-2] > 0 and out[0][1][-1] == 0
+        return
     z = load("g3_syn2000.npz")
     key = "simplex1|w2|f64" if kind in ("simplex", "run_solver") else "mixed|w2|f64"  # (the custom clamp is the same projection as box [0, 1])
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
