@@ -507,3 +507,30 @@ def test_simplex_eq_reference_padding_mode(batching, scan_mode):
     x = f.calculate(torch.zeros(p["m"], dtype=torch.float64, device=DEV), save_primal=True).primal_var.cpu().numpy()
     sums = np.add.reduceat(x, p["colptr"][:-1][np.diff(p["colptr"]) > 0])
     assert np.allclose(sums, 40.0, atol=1e-9)
+
+
+def test_int32_csc_indices_and_views_give_the_same_bits():
+    """CSC tensors with int32 index arrays (torch allows both widths) and value arrays that are views into larger buffers
+    (16-byte aligned offsets) produce bit-identical results to the int64 / owning-tensor form."""
+    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    z = load("g1_syn2000.npz")
+    p = problem(z)
+    pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
+    lam = torch.from_numpy(z["lam_small"]).to(DEV)
+    base = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, DEV), 0.02).calculate(lam, save_primal=True)
+    nnz = len(p["a"])
+    big_a = torch.zeros(nnz + 8, dtype=torch.float64, device=DEV)
+    big_c = torch.zeros(nnz + 8, dtype=torch.float64, device=DEV)
+    big_a[2 : 2 + nnz] = torch.from_numpy(p["a"]).to(DEV)  # offset of 16 bytes
+    big_c[4 : 4 + nnz] = torch.from_numpy(p["c"]).to(DEV)
+    ccol = torch.from_numpy(p["colptr"]).to(torch.int32).to(DEV)
+    rows = torch.from_numpy(p["rowidx"]).to(torch.int32).to(DEV)
+    A = torch.sparse_csc_tensor(ccol, rows, big_a[2 : 2 + nnz], size=(p["m"], p["n"]))
+    C = torch.sparse_csc_tensor(ccol, rows, big_c[4 : 4 + nnz], size=(p["m"], p["n"]))
+    assert A.ccol_indices().dtype == torch.int32
+    f = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.from_numpy(p["b"]).to(DEV)), 0.02)
+    r = f.calculate(lam, save_primal=True)
+    assert torch.equal(r.dual_gradient, base.dual_gradient) and torch.equal(r.primal_var, base.primal_var)
+    assert float(r.dual_objective) == float(base.dual_objective)
