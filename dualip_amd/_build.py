@@ -1,4 +1,6 @@
 """Builds libdualip_hip.so (the C-ABI HIP library, include/dualip_hip.h) in-tree with hipcc for gfx950."""
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -29,24 +31,56 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libdualip_hip.so")
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """Digest of everything the binary is made from.  Staleness is decided by content, not by modification times: the tree
+    is copied to other machines (where times may not survive) and several ranks may import the package at once."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in SOURCES + HEADERS:
+        path = os.path.join(CSRC, name)
+        h.update(name.encode())
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    try:
+        with open(HASH_PATH) as fh:
+            return fh.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), *FLAGS, "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)  # one builder at a time; the others find a fresh binary when they get the lock
+        try:
+            if not force and not is_stale():
+                return LIB_PATH
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [_hipcc(), *FLAGS, "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+            if verbose:
+                print(" ".join(cmd).replace(tmp, LIB_PATH))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB_PATH)  # atomic: a process that already mapped the old file keeps it
+            with open(HASH_PATH + ".tmp", "w") as fh:
+                fh.write(source_hash())
+            os.replace(HASH_PATH + ".tmp", HASH_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
