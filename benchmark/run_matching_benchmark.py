@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--gamma-decay", action="store_true", help="gamma continuation, 35 steps / factor 0.7 (USE_GAMMA_DECAY)")
     ap.add_argument("--precondition", action="store_true", help="Jacobi row normalisation (USE_PRECONDITIONING)")
     ap.add_argument("--projection", choices=["simplex", "box", "mixed"], default="simplex", help="reference default: one simplex z=1 over all sources")
+    ap.add_argument("--fairness", type=float, default=None, metavar="DELTA",
+                    help="add the two fairness rows of docs/demo/matching_complex.rst (first half of the sources against the second, tolerance DELTA); single GPU")
     args = ap.parse_args()
     n = args.num_sources or NUM_SOURCES
     max_iter = args.max_iter or MAX_ITER
@@ -94,6 +96,8 @@ def main():
 
         inp = generate_matching_problem(n, NUM_DESTINATIONS, TARGET_SPARSITY, seed=SEED, device=device, dtype=DTYPE, col_ranges=ranges, reduce_loads=reduce_loads)["input_args"]
         inp.projection_map = pm_local
+    if args.fairness is not None and world > 1:
+        raise NotImplementedError("--fairness: wrap the per-rank objective as tests/test_gpu_two_ranks.py[fairness] does; the driver runs it on one GPU")
     if args.precondition:
         if world > 1:
             raise NotImplementedError("Jacobi row norms of a column-sharded matrix need one more all-reduce; run it single-GPU")
@@ -107,6 +111,13 @@ def main():
     if world > 1:
         b_vec, inp.b_vec = inp.b_vec, None
         objective = MatchingSolverDualObjectiveFunctionDistributed(inp, b_vec, gamma0, host_device=device)
+    elif args.fairness is not None:
+        from dualip_amd.objectives.matching_fairness import MatchingFairnessDualObjectiveFunction
+
+        b_vec = torch.cat([inp.b_vec, torch.full((2,), float(args.fairness), dtype=DTYPE, device=device)])
+        inp.b_vec = b_vec
+        objective = MatchingFairnessDualObjectiveFunction(inp, gamma0, group_ratio=0.5)
+        log(f"      fairness pair: {'streamed by the fused kernel' if objective.native else 'folded into the cost'}")
     else:
         b_vec = inp.b_vec
         objective = MatchingSolverDualObjectiveFunction(matching_input_args=inp, gamma=gamma0)
