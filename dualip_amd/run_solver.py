@@ -27,12 +27,8 @@ from dualip_amd.utils.dist_utils import global_to_local_projection_map, split_te
 
 
 def transfer_tensors_to_device(input_args: BaseInputArgs, device: str):
-    """New instance of the same dataclass with every tensor field moved to ``device``."""
-    moved = {}
-    for f in fields(input_args):
-        value = getattr(input_args, f.name)
-        moved[f.name] = value.to(device) if isinstance(value, torch.Tensor) else value
-    return type(input_args)(**moved)
+    """New instance of the same dataclass with every tensor field moved to ``device`` (run_solver.py:17-32)."""
+    return input_args.to(device)
 
 
 def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device) -> MatchingInputArgs:

@@ -18,14 +18,14 @@ LOG_DUAL_OBJECTIVE, LOG_STEP_SIZE, LOG_REG_PENALTY, LOG_DUAL_TIMES_GRAD, LOG_MAX
 class SolverArgs:
     """Maximizer settings (consumed by run_solver -> AcceleratedGradientDescent)."""
 
-    max_iter: int = 10000
-    initial_step_size: float = 1e-5
-    gamma: float = 1e-3
-    max_step_size: float = 0.1
+    max_iter: int = 10000                              # iterations of the maximiser (no early stop)
+    initial_step_size: float = 1e-5                    # used until 14 Lipschitz estimates exist
+    gamma: float = 1e-3                                # ridge weight of the smoothed LP
+    max_step_size: float = 0.1                         # cap of 1 / L_max
     initial_dual_path: Optional[str] = None            # torch.save'd dual vector to warm-start from
     gamma_decay_type: Optional[Literal["step"]] = None
     gamma_decay_params: Optional[dict] = None          # {"decay_steps": int, "decay_factor": float}
-    save_primal: bool = False
+    save_primal: bool = False                          # keep x of the LAST iteration
 
     def decay_schedule(self):
         """(decay_steps, decay_factor) of the gamma continuation, or (0, 1.0) when there is none."""
@@ -45,8 +45,8 @@ class ComputeArgs:
     """Where to run: ``host_device`` is a torch device string of a ROCm GPU; ``compute_device_num`` > 1 selects the
     one-process-per-GPU column-sharded objective (call run_solver from every rank of an initialised process group)."""
 
-    host_device: str
-    compute_device_num: int = 1
+    host_device: str                # e.g. "cuda:0"
+    compute_device_num: int = 1     # ranks of the process group (one per GPU)
 
     @property
     def sharded(self) -> bool:
@@ -57,9 +57,9 @@ class ComputeArgs:
 class ObjectiveArgs:
     """Which objective run_solver builds and with what extra constructor arguments."""
 
-    objective_type: Literal["miplib2017", "matching"]
-    use_jacobi_precondition: bool = False
-    objective_kwargs: Optional[Dict[str, Any]] = None
+    objective_type: Literal["miplib2017", "matching"]   # anything else: ValueError in build_objective
+    use_jacobi_precondition: bool = False               # row-normalise A and b before the solve
+    objective_kwargs: Optional[Dict[str, Any]] = None   # passed to the objective's constructor
 
 
 @dataclass
@@ -67,14 +67,14 @@ class ObjectiveResult:
     """One evaluation of the dual objective.  ``primal_var`` aliases a buffer owned by the objective (it is overwritten
     by the next ``calculate(save_primal=True)``), as in the reference."""
 
-    dual_gradient: torch.Tensor
-    dual_objective: torch.Tensor
-    reg_penalty: Optional[torch.Tensor] = None
-    primal_objective: Optional[torch.Tensor] = None
-    primal_var: Optional[torch.Tensor] = None
-    dual_val_times_grad: Optional[torch.Tensor] = None
-    max_pos_slack: Optional[torch.Tensor] = None
-    sum_pos_slack: Optional[torch.Tensor] = None
+    dual_gradient: torch.Tensor                          # A x - b, [m]
+    dual_objective: torch.Tensor                         # c.x + reg + lambda.(A x - b), 0-dim
+    reg_penalty: Optional[torch.Tensor] = None           # gamma / 2 * ||x||^2
+    primal_objective: Optional[torch.Tensor] = None      # c.x (with save_primal)
+    primal_var: Optional[torch.Tensor] = None            # x, one entry per stored non-zero (with save_primal)
+    dual_val_times_grad: Optional[torch.Tensor] = None   # lambda.(A x - b)
+    max_pos_slack: Optional[torch.Tensor] = None         # max(max_i grad_i, 0)
+    sum_pos_slack: Optional[torch.Tensor] = None         # sum_i max(grad_i, 0)
 
     @classmethod
     def from_log_row(cls, row: Sequence[float], dual_gradient: torch.Tensor, dtype: torch.dtype, device) -> "ObjectiveResult":
@@ -95,11 +95,11 @@ class SolverResult:
     """What ``maximize`` returns: the last dual iterate y, the last logged dual objective, the last ObjectiveResult and
     the per-iteration logs (Python floats)."""
 
-    dual_val: torch.Tensor
-    dual_objective: float
-    objective_result: ObjectiveResult
-    dual_objective_log: list
-    step_size_log: list
+    dual_val: torch.Tensor              # y of the last iteration
+    dual_objective: float               # last entry of dual_objective_log
+    objective_result: ObjectiveResult   # evaluation at the last x
+    dual_objective_log: list            # one float per iteration
+    step_size_log: list                 # one float per iteration
 
     @property
     def iterations(self) -> int:
