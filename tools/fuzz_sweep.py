@@ -18,6 +18,14 @@ for seed in range(first, first + count):
     grad = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], gamma, NP_DT[dn])[0]
     e = max(relerr(res.primal_var.cpu().numpy(), x), relerr(res.dual_gradient.cpu().numpy(), grad))
     worst[dn] = max(worst[dn], e)
+    if e > RTOL[dn] * 2 and dn == "f32":
+        # ill-conditioned in float32 (u ~ 1e4 against z = 1)?  compare with the oracle's own f32-vs-f64 spread on the same f32 inputs
+        f32 = lambda v: np.asarray(v, dtype=np.float32)
+        x64 = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], f32(p["a"]), f32(p["c"]), f32(lam), gamma, entries, col_proj=col_proj, dtype=np.float64)[3]
+        spread = relerr(x, x64)
+        if e <= 4 * spread:
+            print("note: seed", seed, "is ill-conditioned in float32: HIP-vs-oracle", e, "oracle f32-vs-f64", spread)
+            e = 0.0
     if e > RTOL[dn] * 2:
         bad += 1
         print("MISMATCH seed", seed, dn, p["m"], p["n"], int(p["colptr"][-1]), e, f.info())
