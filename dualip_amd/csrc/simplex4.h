@@ -298,6 +298,8 @@ __device__ __forceinline__ void simplex_tile4(const T (&v)[kSlots], const Seg4& 
             C[j] = padded ? L : cnt[j];
         }
     }
+    // (tiles without a column whose support exceeds two elements -- most tiles early in a solve -- skip even the first test)
+    if (__any(act[0] || act[1] || act[2] || act[3]))
     for (int it = 0; it < kTile4; ++it) {
         bool in[kSlots], dropped = false;
 #pragma unroll
