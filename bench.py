@@ -18,6 +18,7 @@ The JSON line carries, besides the contract fields:
                   (rank 0, N = 1 only), scaled to whole-problem iterations/s.  Reported baseline, not a target.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -242,10 +243,12 @@ def main():
 
     fence()
     local.profile(True)
+    gc.disable()  # (the sharded loop issues every iteration from Python: keep collector pauses out of the timed region)
     t0 = time.perf_counter()
     run.advance(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     launches, kernel_ms = local.profile_read()
     local.profile(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
