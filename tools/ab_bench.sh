@@ -1,4 +1,5 @@
 #!/bin/bash
+# _ab_head: rm -rf _ab_head && mkdir _ab_head && git archive HEAD dualip_amd benchmark bench.py include oracle | tar -x -C _ab_head && (cd _ab_head && python -m dualip_amd._build)   (git-ignored; travels with gpurun)
 # developer aid: HEAD copy (_ab_head/) against the working tree on the same box, bench.py kernel times
 # usage: bash tools/ab_bench.sh "<bench args>" [reps]
 A="$1"; R=${2:-3}
