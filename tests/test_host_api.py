@@ -326,3 +326,30 @@ def test_user_defined_projection_operator_registers_without_a_kernel_form():
 
     op = project("user_halve", factor=0.25)
     assert op.descriptor() is None and torch.equal(op(torch.tensor([4.0, 8.0])), torch.tensor([1.0, 2.0]))
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/dualip_hip.h is consumable by a C compiler (the boundary has no C++ or torch types), and a C translation
+    unit that only includes it links against the shared object and can call an entry point that needs no GPU."""
+    import shutil
+    import subprocess
+
+    from dualip_amd import _build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = os.path.join(root, "include", "dualip_hip.h")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
+    src = tmp_path / "use.c"
+    src.write_text('#include <stdio.h>\n#include "dualip_hip.h"\nint main(void) { printf("%d\\n", dl_version()); return dl_last_error_string() == 0; }\n')
+    exe = tmp_path / "use"
+    lib_dir = os.path.dirname(_build.build())
+    r = subprocess.run([gcc, "-std=c99", "-I", os.path.dirname(header), str(src), "-o", str(exe), "-L", lib_dir, "-ldualip_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot link against the HIP runtime here: " + r.stderr[-300:])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    if out.returncode == 0:
+        assert int(out.stdout.strip()) >= 1
