@@ -115,7 +115,7 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom", "run_solver", "fairness"])
+@pytest.mark.parametrize("kind", ["simplex", "mixed", "mixed_custom", "run_solver", "fairness", "simplex_w4"])
 def test_two_ranks_share_one_gpu(kind):
     from tests.helpers import load, relerr
 
@@ -125,7 +125,8 @@ def test_two_ranks_share_one_gpu(kind):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    world = 4 if kind == "simplex_w4" else 2  # (four ranks: the reference's 4-rank golden trace)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "simplex" if kind == "simplex_w4" else kind, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = {}
@@ -142,10 +143,11 @@ def test_two_ranks_share_one_gpu(kind):
         assert out[0][1][-2] > 0 and out[0][1][-1] == 0
         return
     z = load("g3_syn2000.npz")
-    key = "simplex1|w2|f64" if kind in ("simplex", "run_solver") else "mixed|w2|f64"  # (the custom clamp is the same projection as box [0, 1])
+    key = "simplex1|w4|f64" if kind == "simplex_w4" else ("simplex1|w2|f64" if kind in ("simplex", "run_solver") else "mixed|w2|f64")  # (the custom clamp is the same projection as box [0, 1])
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
-    # both ranks apply the identical update: identical duals, bit for bit, without a broadcast
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    # all ranks apply the identical update: identical duals, bit for bit, without a broadcast
+    for r in range(1, world):
+        assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][0], out[r][0])
     assert relerr(out[0][0], want_log) < 1e-7, kind
     assert relerr(out[0][1], want_dual) < 1e-6, kind
 
