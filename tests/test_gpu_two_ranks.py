@@ -227,3 +227,10 @@ def test_bench_harness_with_two_ranks_on_one_gpu():
     assert d["metric"] == "dual_ascent_iterations_per_sec" and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1000.0) < 1e-6 * 1000
     assert d["config"]["entities"] == 2000000 and d["config"]["parallelism"] == "column-shard x2" and d["cpu_baseline"] is None
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
+    # the same global problem on one rank: same non-zeros, same objective after the same iterations
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--entities", "2000000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=dict(os.environ), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["config"]["nnz"] == d["config"]["nnz"]
+    assert abs(d1["aux"]["final_dual_objective"] - d["aux"]["final_dual_objective"]) <= 1e-5 * abs(d1["aux"]["final_dual_objective"])
