@@ -60,7 +60,8 @@ def generate_matching_problem(num_sources, num_destinations, target_sparsity, se
     col_ranges=[(lo, hi), ...]: several such ranges, concatenated in the given order (a shard that takes its share of
     every projection block).
     reduce_loads: callable applied to the float64[m] greedy-load vector before b is formed (pass an all-reduce when
-    sharded).  Returns dict(input_args=MatchingInputArgs(projection_map=None -- set by the caller), nnz, m, n_local).
+    sharded).  Returns dict(input_args=MatchingInputArgs(projection_map=None -- set by the caller), nnz, m, n_local,
+    loads_local = this call's greedy loads before reduce_loads, rho).
     """
     from dualip_amd.objectives.matching import MatchingInputArgs
 
@@ -99,10 +100,11 @@ def generate_matching_problem(num_sources, num_destinations, target_sparsity, se
     del a_parts
     c_vals = torch.cat(c_parts).to(dtype) if c_parts else torch.zeros(0, dtype=dtype, device=device)
     del c_parts
+    loads_local = loads.clone()
     if reduce_loads is not None:
         loads = reduce_loads(loads)
     b = (torch.from_numpy(rho).to(device) * (loads + 1e-8)).to(dtype)
     A = torch.sparse_csc_tensor(colptr, rowidx, a_vals, size=(m, n_local), check_invariants=False)
     C = torch.sparse_csc_tensor(colptr, rowidx, c_vals, size=(m, n_local), check_invariants=False)
     args = MatchingInputArgs(A=A, c=C, projection_map=None, b_vec=b, equality_mask=None)
-    return dict(input_args=args, nnz=nnz, m=m, n_local=n_local)
+    return dict(input_args=args, nnz=nnz, m=m, n_local=n_local, loads_local=loads_local, rho=rho)

@@ -53,6 +53,19 @@ _SIGNATURES = {
     "dl_agd_get": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp]),
     "dl_agd_step": (_c_int, [_c_vp, _c_vp, _c_vp, _c_dbl, _c_i64, _c_int, _c_dbl, _c_vp]),
     "dl_agd_run_matching": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.POINTER(_c_dbl), _c_i64, _c_dbl, _c_vp, _c_vp]),
+    "dl_agd_run_matching_sharded": (_c_int, [_c_vp, ctypes.POINTER(_c_vp), ctypes.c_int32, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.POINTER(_c_dbl), _c_i64, _c_dbl, _c_vp]),
+    "dl_comm_rccl_unique_id": (_c_int, [_c_vp]),
+    "dl_comm_create_rccl": (_c_int, [ctypes.POINTER(_c_vp), ctypes.c_int32, ctypes.c_int32, _c_vp, _c_i64]),
+    "dl_comm_adopt_rccl": (_c_int, [ctypes.POINTER(_c_vp), _c_vp, _c_i64]),
+    "dl_comm_p2p_begin": (_c_int, [ctypes.POINTER(_c_vp), ctypes.c_int32, ctypes.c_int32, _c_i64, _c_vp]),
+    "dl_comm_p2p_connect": (_c_int, [_c_vp, _c_vp]),
+    "dl_comm_destroy": (_c_int, [_c_vp]),
+    "dl_comm_info": (_c_i64, [_c_vp, _c_int]),
+    "dl_allreduce_sum": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
+    "dl_comm_check": (_c_int, [_c_vp, _c_vp]),
+    "dl_comm_set_emulation": (_c_int, [_c_vp, _c_dbl]),
+    "dl_comm_profile": (_c_int, [_c_vp, _c_int]),
+    "dl_comm_profile_read": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "dl_agd_read_log": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "dl_agd_read_max_step": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), _c_vp]),
     "dl_project_dense": (_c_int, [_c_i64, _c_i64, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_vp]),

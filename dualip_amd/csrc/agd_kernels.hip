@@ -1,7 +1,7 @@
 // agd_kernels.hip -- the m-sized side of the dual ascent on gfx950: dual epilogue, accelerated-gradient step with the
 // Lipschitz-history step size (device resident, no host round trip), dense-block projection operator and
 // Jacobi row scaling.
-#include "common.h"
+#include "comm.h"
 #include <algorithm>
 #include <cstring>
 #include "wave.h"
@@ -106,9 +106,13 @@ struct StatsArgs {
     const long long* cold;
     long long* cold_zero;  // == cold when the step should leave the accumulators zeroed for the next fused launch, else null
     const double* dense;   // fairness pair of the matching handle: (A x) of rows m-2, m-1, or null
-    // ... or an already reduced (and, when sharded, all-reduced) packed buffer
-    const double* __restrict__ packed_in;
-    double* __restrict__ packed_out;  // [m+2]: written when reducing slabs (kept for logging / callers)
+    // ... or already reduced (and, when sharded over RCCL, all-reduced) packed buffers, one per block of a split shard ...
+    const double* packed_in[4];
+    int n_packed;
+    // ... or this rank's mailbox of the P2P exchange (comm.h): the kernel waits for every rank's slot and adds them in rank order
+    MailArgs mail;
+    double scale;                     // developer aid (dl_comm_set_emulation): factor on the exchanged sums
+    double* packed_out;               // [m+2]: A x and the two scalars as this step used them (kept for logging / callers; may alias packed_in[0])
     const T* __restrict__ b;
     const T* __restrict__ x;
     const T* __restrict__ y;
@@ -119,10 +123,13 @@ struct StatsArgs {
     double* __restrict__ partial_stats;  // [gridDim.x][kStatCols]
 };
 
-template <class T, bool FROM_SLABS>
+// SRC: 0 = packed buffers, 1 = the matching handle's integer slabs, 2 = the P2P mailbox
+template <class T, int SRC>
 __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(StatsArgs<T> p) {
+    constexpr bool FROM_SLABS = SRC == 1;
     __shared__ long long shi[kStatRows * kStatSlices];
     const int tid = threadIdx.x;
+    if constexpr (SRC == 2) mail_wait(p.mail);
     const int rl = tid & (kStatRows - 1);
     const int ws = tid / kStatRows;
     const int64_t col = (int64_t)blockIdx.x * kStatRows + rl;  // slab column
@@ -163,7 +170,28 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
             p.packed_out[row] = ax;
         }
     } else {
-        if (ws == 0 && live) ax = p.packed_in[row];
+        if (ws == 0 && live) {
+            if constexpr (SRC == 2) {
+                ax = mail_sum(p.mail, row) * p.scale;
+            } else {
+                ax = p.packed_in[0][row];
+                for (int k = 1; k < p.n_packed; ++k) ax += p.packed_in[k][row];
+                ax *= p.scale;
+            }
+            p.packed_out[row] = ax;
+        }
+        if (blockIdx.x == 0 && tid == kStatRows) {  // the two scalars (c.x, sum x^2), by a thread without a row
+            for (int64_t i = p.m; i < p.m + 2; ++i) {
+                double v;
+                if constexpr (SRC == 2) {
+                    v = mail_sum(p.mail, i);
+                } else {
+                    v = p.packed_in[0][i];
+                    for (int k = 1; k < p.n_packed; ++k) v += p.packed_in[k][i];
+                }
+                p.packed_out[i] = v * p.scale;
+            }
+        }
     }
     const bool has_prev = p.st->steps_done > 0;
     double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
@@ -505,14 +533,16 @@ int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t s
 }
 
 template <class T>
-static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
-                          double decay_factor, hipStream_t st) {
+static int agd_step_typed(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st) {
     const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
     AgdDevState* states = (AgdDevState*)s->state;
     const AgdDevState* st_in = states + s->state_cur;
     AgdDevState* st_out = states + (s->state_cur ^ 1);
+    dl_matching* f = src.slabs;
+    dl_matching* hot = (src.hot && src.hot->m_hot > 0) ? src.hot : nullptr;
     if (n_blocks > 0) {
         StatsArgs<T> sa;
+        memset(&sa, 0, sizeof(sa));
         sa.m = s->m;
         sa.partial = f ? static_cast<const long long*>(f->partial) : nullptr;
         sa.partial_scal = f ? f->partial_scal : nullptr;
@@ -525,7 +555,10 @@ static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const
         sa.cold = f ? f->cold_grad : nullptr;
         sa.cold_zero = (f && f->m_hot > 0) ? f->cold_grad : nullptr;
         sa.dense = (f && f->fair) ? f->dense_ax : nullptr;
-        sa.packed_in = packed;
+        for (int k = 0; k < 4; ++k) sa.packed_in[k] = k < src.n_packed ? src.packed[k] : nullptr;
+        sa.n_packed = src.n_packed;
+        if (src.mail) sa.mail = *src.mail;
+        sa.scale = src.scale;
         sa.packed_out = s->packed;
         sa.b = (const T*)b;
         sa.x = (const T*)s->x;
@@ -535,15 +568,16 @@ static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const
         sa.g_new = (T*)s->g_old;
         sa.st = st_in;
         sa.partial_stats = s->partial_stats;
-        if (f) hipLaunchKernelGGL((agd_stats_kernel<T, true>), dim3(n_blocks + 1), dim3(kStatRows * kStatSlices), 0, st, sa);  // + the scalar-sum block
-        else hipLaunchKernelGGL((agd_stats_kernel<T, false>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
+        if (f) hipLaunchKernelGGL((agd_stats_kernel<T, 1>), dim3(n_blocks + 1), dim3(kStatRows * kStatSlices), 0, st, sa);  // + the scalar-sum block
+        else if (src.mail) hipLaunchKernelGGL((agd_stats_kernel<T, 2>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
+        else hipLaunchKernelGGL((agd_stats_kernel<T, 0>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
     }
     ApplyArgs<T> aa;
     aa.m = s->m;
     aa.partial_stats = s->partial_stats;
     aa.n_blocks = n_blocks;
     aa.g_new = (const T*)s->g_old;
-    aa.scal = (f ? s->packed : packed) + s->m;
+    aa.scal = (n_blocks > 0 || !src.n_packed) ? s->packed + s->m : src.packed[0] + s->m;  // (the stats launch leaves the scalars it used in s->packed)
     aa.st_in = st_in;
     aa.st_out = st_out;
     aa.log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
@@ -557,8 +591,8 @@ static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const
     aa.eq_mask = s->eq_mask;
     aa.beta = s->beta;
     aa.iter = iter;
-    aa.x_perm = (f && f->m_hot > 0) ? (T*)f->lam_perm : nullptr;
-    aa.perm = f ? f->row_perm : nullptr;
+    aa.x_perm = hot ? (T*)hot->lam_perm : nullptr;
+    aa.perm = hot ? hot->row_perm : nullptr;
     const unsigned grid = (unsigned)std::max<int64_t>(1, (s->m + kApplyThreads - 1) / kApplyThreads);
     hipLaunchKernelGGL(agd_apply_kernel<T>, dim3(grid), dim3(kApplyThreads), 0, st, aa);
     DL_HIP(hipGetLastError());
@@ -567,19 +601,19 @@ static int agd_step_typed(dl_agd* s, dl_matching* f, const double* packed, const
     std::swap(s->g, s->g_old);
     std::swap(s->x, s->x_alt);
     s->state_cur ^= 1;
-    if (f && f->m_hot > 0) {
-        f->hot_ready = true;
-        f->hot_ready_lambda = s->x;
+    if (hot && f == hot) {  // (the slab route also re-zeroed the cold accumulators: the next fused launch needs no preparation at all)
+        hot->hot_ready = true;
+        hot->hot_ready_lambda = s->x;
+        hot->hot_ready_owner = s->uid;
     }
     return 0;
 }
 
-// f != nullptr: A x is taken from the matching handle's integer slabs (single-device loop, no separate slab reduction);
-// f == nullptr: A x is read from `packed` (already reduced, and all-reduced when sharded).
-int launch_agd_step(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor,
-                    hipStream_t st) {
-    if (s->val_dtype == DL_F32) return agd_step_typed<float>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);
-    return agd_step_typed<double>(s, f, packed, b, gamma, iter, decay_now, decay_factor, st);
+// Where A x comes from: the matching handle's integer slabs (single-device loop, no separate slab reduction), reduced
+// packed buffers (all-reduced when sharded over RCCL; one per block of a split shard), or the P2P mailbox.
+int launch_agd_step(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st) {
+    if (s->val_dtype == DL_F32) return agd_step_typed<float>(s, src, b, gamma, iter, decay_now, decay_factor, st);
+    return agd_step_typed<double>(s, src, b, gamma, iter, decay_now, decay_factor, st);
 }
 
 size_t agd_partial_stats_bytes(int64_t m) { return sizeof(double) * kStatCols * (size_t)((m + kStatRows - 1) / kStatRows + 1); }

@@ -9,7 +9,9 @@
 #include <new>
 #include <vector>
 
-#include "common.h"
+#include <atomic>
+
+#include "comm.h"
 
 namespace dl {
 
@@ -40,10 +42,7 @@ int launch_epilogue(int64_t m, int val_dtype, const double* packed, const void* 
 size_t agd_state_bytes();
 int agd_state_init(void* dev_state, double initial_step, double max_step, hipStream_t st);
 int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t st);
-int launch_agd_step(dl_agd* s, dl_matching* f, const double* packed, const void* b, double gamma, int64_t iter, int decay_now,
-                    double decay_factor, hipStream_t st);
 size_t agd_partial_stats_bytes(int64_t m);
-int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st);
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
@@ -779,7 +778,7 @@ int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void*
 // ---------------------------------------------------------------------------------------------------------
 static void agd_free(dl_agd* s) {
     if (!s) return;
-    void* ptrs[] = {s->x, s->x_alt, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats};
+    void* ptrs[] = {s->x, s->x_alt, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats, s->packed_blk[0], s->packed_blk[1], s->packed_blk[2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -794,6 +793,8 @@ int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, cons
     hipStream_t st = (hipStream_t)stream;
     dl_agd* s = new (std::nothrow) dl_agd();
     if (!s) return fail(DL_E_NOMEM, "out of host memory");
+    static std::atomic<uint64_t> next_uid{1};
+    s->uid = next_uid.fetch_add(1);
     s->m = m;
     s->max_iter = max_iter;
     s->val_dtype = val_dtype;
@@ -850,7 +851,10 @@ int dl_agd_step(dl_agd* s, const double* packed, const void* b, double gamma, in
                 dl_stream_t stream) {
     if (!s || !packed || (s->m > 0 && !b)) return fail(DL_E_ARG, "null argument");
     if (iter < 1 || iter > s->max_iter) return fail(DL_E_STATE, "iteration %lld outside 1..max_iter=%lld", (long long)iter, (long long)s->max_iter);
-    return launch_agd_step(s, nullptr, packed, b, gamma, iter, decay_now, decay_factor, (hipStream_t)stream);
+    StepSource src;
+    src.packed[0] = packed;
+    src.n_packed = 1;
+    return launch_agd_step(s, src, b, gamma, iter, decay_now, decay_factor, (hipStream_t)stream);
 }
 
 int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_iter, int64_t n_iters, double* gamma_io_host,
@@ -860,16 +864,118 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
     if (first_iter < 1 || n_iters < 0 || first_iter + n_iters - 1 > s->max_iter) return fail(DL_E_STATE, "iteration range outside 1..max_iter");
     hipStream_t st = (hipStream_t)stream;
     double gamma = *gamma_io_host;
-    if (first_iter == 1 || f->hot_ready_owner != s) f->hot_ready = false;  // a new run (or another optimiser) starts from its own dual vector
-    f->hot_ready_owner = s;
+    if (first_iter == 1 || f->hot_ready_owner != s->uid) f->hot_ready = false;  // a new run (or another optimiser) starts from its own dual vector
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
         const bool empty = f->n_tiles == 0 || f->n_wg == 0;
-        int rc = empty ? matching_calculate(f, s->x, gamma, s->packed, xo, st) : matching_launch_fused(f, s->x, gamma, xo, st);
+        int rc = empty ? matching_calculate(f, s->x, gamma, s->packed, xo, st) : matching_launch_fused(f, s->x, gamma, xo, st, s->uid);
         if (rc) return rc;
         const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
-        rc = launch_agd_step(s, empty ? nullptr : f, s->packed, b, gamma, it, decay_now, decay_factor, st);
+        StepSource src;
+        if (empty) {
+            src.packed[0] = s->packed;
+            src.n_packed = 1;
+        } else {
+            src.slabs = f;
+            src.hot = f;
+        }
+        rc = launch_agd_step(s, src, b, gamma, it, decay_now, decay_factor, st);
         if (rc) return rc;
+        if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
+    }
+    *gamma_io_host = gamma;
+    return 0;
+}
+
+// The column-sharded loop: what dl_agd_run_matching does on one device, for this rank's block(s) of columns, with the ONE
+// exchange of an iteration inside (comm.h).  Per iteration and rank:
+//   P2P   fused pass -> slab reduction that stores its sums into every rank's mailbox -> step kernels (the first waits for all
+//         ranks' slots and adds them in rank order) : 4 launches, no collective launch
+//   RCCL  fused pass -> slab reduction -> ncclAllReduce (m + 2 doubles) -> step kernels
+// A shard split into n_blocks handles runs the blocks back to back; with RCCL the collective of every block but the last
+// goes to the communicator's side stream, overlapping the next block's fused pass (the all-reduce is linear: the step adds
+// the blocks' all-reduced buffers); with P2P the blocks accumulate locally and the last reduction pushes.
+int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n_blocks, dl_comm* comm, const void* b, int64_t first_iter,
+                                int64_t n_iters, double* gamma_io_host, int64_t gamma_decay_steps, double decay_factor, dl_stream_t stream) {
+    if (!s || !blocks || n_blocks < 1 || n_blocks > 4 || !comm || !gamma_io_host || (s->m > 0 && !b)) return fail(DL_E_ARG, "bad argument");
+    for (int k = 0; k < n_blocks; ++k) {
+        if (!blocks[k]) return fail(DL_E_ARG, "null block handle");
+        if (s->m != blocks[k]->m || s->val_dtype != blocks[k]->val_dtype) return fail(DL_E_STATE, "optimizer state and objective disagree on m / dtype");
+    }
+    if (comm->max_count < s->m + 2) return fail(DL_E_STATE, "communicator capacity %lld is below m + 2", (long long)comm->max_count);
+    if (comm->backend == DL_COMM_P2P && !comm->connected) return fail(DL_E_STATE, "P2P communicator is not connected (dl_comm_p2p_connect)");
+    if (first_iter < 1 || n_iters < 0 || first_iter + n_iters - 1 > s->max_iter) return fail(DL_E_STATE, "iteration range outside 1..max_iter");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pbytes = sizeof(double) * (size_t)(s->m + 2);
+    for (int k = 1; k < n_blocks && comm->backend == DL_COMM_RCCL; ++k)
+        if (!s->packed_blk[k - 1]) DL_HIP(hipMalloc((void**)&s->packed_blk[k - 1], pbytes));
+    double gamma = *gamma_io_host;
+    for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
+        StepSource src;
+        src.scale = comm->emu_scale;
+        MailArgs mail;
+        hipEvent_t ev_stop = nullptr;
+        for (int k = 0; k < n_blocks; ++k) {
+            dl_matching* f = blocks[k];
+            const bool last = k == n_blocks - 1;
+            const bool empty = f->n_tiles == 0 || f->n_wg == 0;
+            double* pk = k == 0 ? s->packed : s->packed_blk[k - 1];
+            int rc = 0;
+            if (!empty) rc = matching_launch_fused(f, s->x, gamma, nullptr, st, 0);
+            if (rc) return rc;
+            if (last && comm->prof_on) {  // measurement: from the end of the last fused pass to the end of the step's first kernel
+                if (comm->prof_used == comm->prof_start.size() && comm->prof_start.size() < 16384) {
+                    hipEvent_t e0, e1;
+                    DL_HIP(hipEventCreate(&e0));
+                    DL_HIP(hipEventCreate(&e1));
+                    comm->prof_start.push_back(e0);
+                    comm->prof_stop.push_back(e1);
+                }
+                if (comm->prof_used < comm->prof_start.size()) {
+                    DL_HIP(hipEventRecord(comm->prof_start[comm->prof_used], st));
+                    ev_stop = comm->prof_stop[comm->prof_used];
+                    comm->prof_used += 1;
+                }
+            }
+            if (comm->backend == DL_COMM_P2P) {
+                if (empty) {  // nothing to add: an all-zero partial (accumulated blocks stay as they are)
+                    if (k == 0) DL_HIP(hipMemsetAsync(s->packed, 0, pbytes, st));
+                    if (last) return fail(DL_E_STATE, "the last block of a shard must hold non-zeros");
+                } else if (!last) {
+                    rc = matching_reduce(f, s->packed, k == 0 ? 0 : 1, nullptr, st, 0);
+                } else {
+                    const unsigned long long seq = ++comm->seq;
+                    const PushArgs push = comm_push_args(comm, seq);
+                    mail = comm_mail_args(comm, seq);
+                    rc = matching_reduce(f, s->packed, 2, &push, st, k > 0 ? 1 : 0);
+                    src.mail = &mail;
+                }
+                if (rc) return rc;
+            } else {
+                if (empty) DL_HIP(hipMemsetAsync(pk, 0, pbytes, st));
+                else rc = matching_reduce(f, pk, 0, nullptr, st, 0);
+                if (rc) return rc;
+                if (n_blocks == 1) {
+                    rc = comm_rccl_allreduce(comm, pk, s->m + 2, st);
+                } else {  // split shard: every collective on the side stream, in block order (one communicator, one queue);
+                          // all but the last overlap the next block's fused pass
+                    DL_HIP(hipEventRecord(comm->ev_ready[k], st));
+                    DL_HIP(hipStreamWaitEvent(comm->side, comm->ev_ready[k], 0));
+                    rc = comm_rccl_allreduce(comm, pk, s->m + 2, comm->side);
+                    if (!rc && last) {
+                        DL_HIP(hipEventRecord(comm->ev_done, comm->side));
+                        DL_HIP(hipStreamWaitEvent(st, comm->ev_done, 0));
+                    }
+                }
+                if (rc) return rc;
+                src.packed[k] = pk;
+                src.n_packed = k + 1;
+            }
+        }
+        const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
+        int rc = launch_agd_step(s, src, b, gamma, it, decay_now, decay_factor, st);
+        if (rc) return rc;
+        if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
         if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
     }
     *gamma_io_host = gamma;

@@ -1,0 +1,138 @@
+// comm.h -- the exchange step of the column-sharded iteration (include/dualip_hip.h: dl_comm, dl_allreduce_sum,
+// dl_agd_run_matching_sharded).  Replaces the reference's per-iteration collectives: three torch.distributed.reduce calls, a
+// barrier and two broadcasts (src/dualip/objectives/matching.py:272-277, src/dualip/optimizers/agd.py:204-206) by ONE
+// sum-all-reduce of [A x (m) | c.x | sum x^2] doubles after which every rank applies the identical update.
+//
+// Two back-ends behind one handle:
+//   RCCL  ncclAllReduce(double, sum) on the caller's stream (or a handle-owned side stream when the local shard is split
+//         into blocks); librccl is opened at run time (dlopen of the soname PyTorch-ROCm already loaded).
+//   P2P   one-shot all-to-all over hipIpc-mapped mailboxes: every rank owns a fine-grained buffer with one slot per sending
+//         rank (double buffered by the parity of a sequence number).  The slab-reduction kernel of the fused pass stores its
+//         sums straight into slot [parity][my rank] of EVERY rank's mailbox (remote stores over xGMI), releases them with a
+//         system-scope fence and raises the flag word of that slot; the step kernel of every rank polls its OWN flags (local
+//         memory), acquires, and adds the slots in rank order 0..W-1 -- so all ranks obtain bit-identical sums without a
+//         second hop, and an iteration costs no collective launch at all.
+#pragma once
+#include "common.h"
+
+namespace dl {
+
+constexpr int kMaxWorld = 16;          // ranks of one node (8 on an MI355X node)
+constexpr int kFlagStride = 8;         // one 64-byte line per flag word (uint64 units)
+constexpr size_t kMailHeaderBytes = 2 * kMaxWorld * kFlagStride * sizeof(unsigned long long);  // flags [2][kMaxWorld]
+
+// Where one rank's sums go: slot (parity, my rank) of every rank's mailbox.
+struct PushArgs {
+    double* dst[kMaxWorld];               // slot base in rank r's mailbox
+    unsigned long long* flag[kMaxWorld];  // its flag word
+    int world;
+    unsigned long long seq;
+    unsigned int* counter;                // arrival counter of the pushing launch (device memory, zero between launches)
+};
+
+// What a rank reads: its own mailbox of the parity.
+struct MailArgs {
+    const double* slots;                  // [world][stride]
+    const unsigned long long* flags;      // [world] at kFlagStride
+    int64_t stride;
+    int world;
+    unsigned long long seq;
+    int* dead;                            // sticky: a wait timed out (the run's results are invalid)
+    unsigned long long timeout_ticks;     // 100 MHz wall clock
+};
+
+__device__ __forceinline__ void push_value(const PushArgs& p, int64_t i, double v) {
+    for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.dst[r] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Called by EVERY thread of EVERY block of the pushing launch after its push_value calls: the block that arrives last
+// raises the flags.  Stores of a block are complete (acknowledged) before its arrival is counted; the last arriver's flag
+// stores are therefore ordered after all data stores of the launch.
+__device__ __forceinline__ void push_finish(const PushArgs& p) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == gridDim.x) {
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (stream ordered)
+            __threadfence_system();
+            for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Whole block: returns once every rank's slot of this exchange has arrived (or the wait timed out: *dead = 1).
+__device__ __forceinline__ void mail_wait(const MailArgs& a) {
+    if ((int)threadIdx.x < a.world) {
+        if (__hip_atomic_load(a.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            const unsigned long long t0 = wall_clock64();
+            const unsigned long long* f = a.flags + (size_t)threadIdx.x * kFlagStride;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    __hip_atomic_store(a.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope
+        __threadfence_system();
+    }
+    __syncthreads();
+}
+
+// Sum of element i over the ranks' slots, in rank order (identical on every rank).
+__device__ __forceinline__ double mail_sum(const MailArgs& a, int64_t i) {
+    double v = 0.0;
+    for (int r = 0; r < a.world; ++r) v += __hip_atomic_load(a.slots + (int64_t)r * a.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return v;
+}
+
+}  // namespace dl
+
+struct dl_comm {
+    int backend = 0;  // DL_COMM_*
+    int world = 1, rank = 0;
+    int device = 0;
+    int64_t max_count = 0;
+    int64_t stride = 0;  // doubles per slot
+    double emu_scale = 1.0;  // developer aid (dl_comm_set_emulation): the all-reduced sums are multiplied by this
+    // RCCL
+    void* nccl = nullptr;
+    bool owns_nccl = false;
+    hipStream_t side = nullptr;  // owned: collectives of all but the last block of a split shard run here
+    hipEvent_t ev_ready[4] = {nullptr, nullptr, nullptr, nullptr}, ev_done = nullptr;
+    // P2P
+    void* mail = nullptr;                         // owned, fine-grained: header + data [2][world][stride]
+    size_t mail_bytes = 0;
+    void* peer[dl::kMaxWorld] = {};               // mapped mailbox of every rank (own entry = mail)
+    bool opened[dl::kMaxWorld] = {};
+    bool connected = false;
+    unsigned long long seq = 0;                   // exchanges issued
+    unsigned int* counter = nullptr;              // owned
+    int* dead = nullptr;                          // owned
+    unsigned long long timeout_ticks = 500000000ull;  // 5 s at 100 MHz
+    double* scratch = nullptr;                    // owned, double[stride]: result staging of the stand-alone all-reduce
+    // measurement (dl_comm_profile): event pairs around the exchanges of dl_agd_run_matching_sharded
+    bool prof_on = false;
+    size_t prof_used = 0;
+    std::vector<hipEvent_t> prof_start, prof_stop;
+};
+
+namespace dl {
+// Source of A x for one optimiser step (agd_kernels.hip: launch_agd_step)
+struct StepSource {
+    dl_matching* slabs = nullptr;   // the handle whose integer slabs hold this launch's sums (single-device loop), or
+    const double* packed[4] = {nullptr, nullptr, nullptr, nullptr};  // n_packed reduced buffers to add up, or
+    int n_packed = 0;
+    const MailArgs* mail = nullptr;  // this rank's mailbox of the P2P exchange
+    double scale = 1.0;              // factor on exchanged sums (emulation aid)
+    dl_matching* hot = nullptr;      // handle under the hot-rows plan that wants the next dual vector in renumbered order, or null
+};
+int launch_agd_step(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st);
+int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* push, hipStream_t st, int push_accumulate);
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid);
+PushArgs comm_push_args(dl_comm* c, unsigned long long seq);
+MailArgs comm_mail_args(dl_comm* c, unsigned long long seq);
+int comm_rccl_allreduce(dl_comm* c, double* buf, int64_t count, hipStream_t st);
+}  // namespace dl

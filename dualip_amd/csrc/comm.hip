@@ -1,0 +1,361 @@
+// comm.hip -- dl_comm: the one exchange of a column-sharded iteration (see comm.h for the protocol).
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "comm.h"
+
+namespace dl {
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL, opened at run time: the copy PyTorch-ROCm already loaded when there is one (same soname), else the system's
+// ---------------------------------------------------------------------------------------------------------
+struct UniqueId128 {  // ncclUniqueId (passed by value)
+    char b[128];
+};
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+    if (g_rccl.lib) return 0;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(DL_E_STATE, "librccl.so.1 cannot be opened: %s", dlerror());
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    *(void**)&g_rccl.GetUniqueId = sym("ncclGetUniqueId");
+    *(void**)&g_rccl.CommInitRank = sym("ncclCommInitRank");
+    *(void**)&g_rccl.CommDestroy = sym("ncclCommDestroy");
+    *(void**)&g_rccl.AllReduce = sym("ncclAllReduce");
+    *(void**)&g_rccl.GetErrorString = sym("ncclGetErrorString");
+    *(void**)&g_rccl.CommCount = sym("ncclCommCount");
+    *(void**)&g_rccl.CommUserRank = sym("ncclCommUserRank");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.CommCount || !g_rccl.CommUserRank)
+        return fail(DL_E_STATE, "librccl.so.1 lacks an expected entry point");
+    g_rccl.lib = lib;
+    return 0;
+}
+static int rccl_fail(int r, const char* what) {
+    return fail(DL_E_STATE, "RCCL error %d (%s) in %s", r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", what);
+}
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+int comm_rccl_allreduce(dl_comm* c, double* buf, int64_t count, hipStream_t st) {
+    const int r = g_rccl.AllReduce(buf, buf, (size_t)count, kNcclFloat64, kNcclSum, c->nccl, st);
+    if (r != 0) return rccl_fail(r, "ncclAllReduce");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// P2P mailboxes
+// ---------------------------------------------------------------------------------------------------------
+static inline unsigned long long* flags_of(void* mail, int par) {
+    return reinterpret_cast<unsigned long long*>(mail) + (size_t)par * kMaxWorld * kFlagStride;
+}
+static inline double* slots_of(void* mail, int par, int world, int64_t stride) {
+    return reinterpret_cast<double*>(reinterpret_cast<char*>(mail) + kMailHeaderBytes) + (size_t)par * (size_t)world * (size_t)stride;
+}
+
+PushArgs comm_push_args(dl_comm* c, unsigned long long seq) {
+    PushArgs p;
+    const int par = (int)(seq & 1ull);
+    for (int r = 0; r < kMaxWorld; ++r) {
+        p.dst[r] = nullptr;
+        p.flag[r] = nullptr;
+    }
+    for (int r = 0; r < c->world; ++r) {
+        p.dst[r] = slots_of(c->peer[r], par, c->world, c->stride) + (size_t)c->rank * (size_t)c->stride;
+        p.flag[r] = flags_of(c->peer[r], par) + (size_t)c->rank * kFlagStride;
+    }
+    p.world = c->world;
+    p.seq = seq;
+    p.counter = c->counter;
+    return p;
+}
+MailArgs comm_mail_args(dl_comm* c, unsigned long long seq) {
+    MailArgs a;
+    const int par = (int)(seq & 1ull);
+    a.slots = slots_of(c->mail, par, c->world, c->stride);
+    a.flags = flags_of(c->mail, par);
+    a.stride = c->stride;
+    a.world = c->world;
+    a.seq = seq;
+    a.dead = c->dead;
+    a.timeout_ticks = c->timeout_ticks;
+    return a;
+}
+
+// stand-alone all-reduce, P2P: push the buffer, then gather the sum back into it
+__global__ __launch_bounds__(256) void p2p_push_kernel(const double* __restrict__ src, int64_t count, PushArgs p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) push_value(p, i, src[i]);
+    push_finish(p);
+}
+__global__ __launch_bounds__(256) void p2p_gather_kernel(double* __restrict__ dst, int64_t count, MailArgs a, double scale) {
+    mail_wait(a);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = mail_sum(a, i) * scale;
+}
+
+static int p2p_allreduce(dl_comm* c, double* buf, int64_t count, hipStream_t st) {
+    const unsigned long long seq = ++c->seq;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(p2p_push_kernel, dim3(blocks), dim3(256), 0, st, (const double*)buf, count, comm_push_args(c, seq));
+    hipLaunchKernelGGL(p2p_gather_kernel, dim3(blocks), dim3(256), 0, st, buf, count, comm_mail_args(c, seq), c->emu_scale);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_kernel(double* __restrict__ v, int64_t n, double s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= s;
+}
+
+static void comm_free(dl_comm* c) {
+    if (!c) return;
+    for (int r = 0; r < kMaxWorld; ++r)
+        if (c->opened[r] && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->mail) (void)hipFree(c->mail);
+    if (c->counter) (void)hipFree(c->counter);
+    if (c->dead) (void)hipFree(c->dead);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->nccl && c->owns_nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    for (hipEvent_t& e : c->ev_ready)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (hipEvent_t e : c->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->prof_stop) (void)hipEventDestroy(e);
+    delete c;
+}
+
+static int comm_common_init(dl_comm* c) {
+    DL_HIP(hipGetDevice(&c->device));
+    DL_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (hipEvent_t& e : c->ev_ready) DL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    DL_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    DL_HIP(hipMalloc((void**)&c->dead, sizeof(int)));
+    DL_HIP(hipMemset(c->dead, 0, sizeof(int)));
+    return 0;
+}
+
+}  // namespace dl
+
+using namespace dl;
+
+extern "C" {
+
+int dl_comm_rccl_unique_id(void* id_out_host) {
+    if (!id_out_host) return fail(DL_E_ARG, "null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    const int r = g_rccl.GetUniqueId(id_out_host);
+    if (r != 0) return rccl_fail(r, "ncclGetUniqueId");
+    return 0;
+}
+
+int dl_comm_create_rccl(dl_comm** out, int32_t world, int32_t rank, const void* unique_id_host, int64_t max_count) {
+    if (!out) return fail(DL_E_ARG, "out is null");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !unique_id_host || max_count < 1) return fail(DL_E_ARG, "bad communicator arguments");
+    int rc = load_rccl();
+    if (rc) return rc;
+    dl_comm* c = new (std::nothrow) dl_comm();
+    if (!c) return fail(DL_E_NOMEM, "out of host memory");
+    c->backend = DL_COMM_RCCL;
+    c->world = world;
+    c->rank = rank;
+    c->max_count = max_count;
+    c->stride = (max_count + 7) / 8 * 8;
+    rc = comm_common_init(c);
+    if (rc) {
+        comm_free(c);
+        return rc;
+    }
+    UniqueId128 id;
+    memcpy(id.b, unique_id_host, sizeof(id.b));
+    const int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+    if (r != 0) {
+        comm_free(c);
+        return rccl_fail(r, "ncclCommInitRank");
+    }
+    c->owns_nccl = true;
+    *out = c;
+    return 0;
+}
+
+int dl_comm_adopt_rccl(dl_comm** out, void* nccl_comm, int64_t max_count) {
+    if (!out) return fail(DL_E_ARG, "out is null");
+    *out = nullptr;
+    if (!nccl_comm || max_count < 1) return fail(DL_E_ARG, "bad communicator arguments");
+    int rc = load_rccl();
+    if (rc) return rc;
+    int world = 0, rank = 0;
+    int r = g_rccl.CommCount(nccl_comm, &world);
+    if (r == 0) r = g_rccl.CommUserRank(nccl_comm, &rank);
+    if (r != 0) return rccl_fail(r, "ncclCommCount");
+    dl_comm* c = new (std::nothrow) dl_comm();
+    if (!c) return fail(DL_E_NOMEM, "out of host memory");
+    c->backend = DL_COMM_RCCL;
+    c->world = world;
+    c->rank = rank;
+    c->max_count = max_count;
+    c->stride = (max_count + 7) / 8 * 8;
+    c->nccl = nccl_comm;
+    c->owns_nccl = false;
+    rc = comm_common_init(c);
+    if (rc) {
+        comm_free(c);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int dl_comm_p2p_begin(dl_comm** out, int32_t world, int32_t rank, int64_t max_count, void* ipc_handle_out_host) {
+    if (!out) return fail(DL_E_ARG, "out is null");
+    *out = nullptr;
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || max_count < 1 || !ipc_handle_out_host)
+        return fail(DL_E_ARG, "bad communicator arguments (the P2P exchange serves up to %d ranks of one node)", kMaxWorld);
+    static_assert(sizeof(hipIpcMemHandle_t) == DL_IPC_HANDLE_BYTES, "DL_IPC_HANDLE_BYTES must match hipIpcMemHandle_t");
+    dl_comm* c = new (std::nothrow) dl_comm();
+    if (!c) return fail(DL_E_NOMEM, "out of host memory");
+    c->backend = DL_COMM_P2P;
+    c->world = world;
+    c->rank = rank;
+    c->max_count = max_count;
+    c->stride = (max_count + 7) / 8 * 8;
+    int rc = comm_common_init(c);
+    if (rc) {
+        comm_free(c);
+        return rc;
+    }
+    if (const char* e = getenv("DUALIP_COMM_TIMEOUT_MS")) {
+        const long long ms = atoll(e);
+        if (ms > 0) c->timeout_ticks = (unsigned long long)ms * 100000ull;
+    }
+    c->mail_bytes = kMailHeaderBytes + sizeof(double) * 2 * (size_t)world * (size_t)c->stride;
+    // fine-grained (uncached) device memory: stores from other devices and from other processes become visible to a
+    // running kernel, which ordinary (coarse-grained) allocations only guarantee at kernel boundaries
+    hipError_t e = hipExtMallocWithFlags(&c->mail, c->mail_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&c->mail, c->mail_bytes, hipDeviceMallocFinegrained);
+    }
+    if (e == hipSuccess) e = hipMemset(c->mail, 0, c->mail_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(c->counter, 0, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->scratch, sizeof(double) * (size_t)c->stride);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipIpcMemHandle_t hd;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, c->mail);
+    if (e != hipSuccess) {
+        comm_free(c);
+        return hip_fail(e, "P2P mailbox allocation / hipIpcGetMemHandle");
+    }
+    memcpy(ipc_handle_out_host, &hd, sizeof(hd));
+    c->peer[rank] = c->mail;
+    *out = c;
+    return 0;
+}
+
+int dl_comm_p2p_connect(dl_comm* c, const void* all_handles_host) {
+    if (!c || c->backend != DL_COMM_P2P || !all_handles_host) return fail(DL_E_ARG, "bad argument");
+    if (c->connected) return fail(DL_E_STATE, "already connected");
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, reinterpret_cast<const char*>(all_handles_host) + (size_t)r * sizeof(hd), sizeof(hd));
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle");
+        c->peer[r] = p;
+        c->opened[r] = true;
+    }
+    c->connected = true;
+    return 0;
+}
+
+int dl_comm_destroy(dl_comm* c) {
+    comm_free(c);
+    return 0;
+}
+
+int64_t dl_comm_info(const dl_comm* c, int what) {
+    if (!c) return -1;
+    switch (what) {
+        case 0: return c->backend;
+        case 1: return c->world;
+        case 2: return c->rank;
+        case 3: return (int64_t)c->seq;
+        case 4: return c->max_count;
+        default: return -1;
+    }
+}
+
+int dl_comm_set_emulation(dl_comm* c, double scale) {
+    if (!c || !(scale > 0.0)) return fail(DL_E_ARG, "bad argument");
+    c->emu_scale = scale;
+    return 0;
+}
+
+int dl_comm_check(dl_comm* c, dl_stream_t stream) {
+    if (!c) return fail(DL_E_ARG, "null communicator");
+    int dead = 0;
+    DL_HIP(hipMemcpyAsync(&dead, c->dead, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (dead) return fail(DL_E_STATE, "a P2P exchange timed out waiting for another rank's partial sums: the results of this run are invalid");
+    return 0;
+}
+
+int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream) {
+    if (!c || !buf || count < 0) return fail(DL_E_ARG, "bad argument");
+    if (count > c->max_count) return fail(DL_E_ARG, "count %lld exceeds the communicator's capacity %lld", (long long)count, (long long)c->max_count);
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->backend == DL_COMM_RCCL) {
+        int rc = comm_rccl_allreduce(c, buf, count, st);
+        if (rc) return rc;
+        if (c->emu_scale != 1.0) {
+            hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, buf, count, c->emu_scale);
+            DL_HIP(hipGetLastError());
+        }
+        return 0;
+    }
+    if (!c->connected) return fail(DL_E_STATE, "P2P communicator is not connected (dl_comm_p2p_connect)");
+    return p2p_allreduce(c, buf, count, st);
+}
+
+int dl_comm_profile(dl_comm* c, int enable) {
+    if (!c) return fail(DL_E_ARG, "null communicator");
+    c->prof_on = enable != 0;
+    c->prof_used = 0;
+    return 0;
+}
+
+int dl_comm_profile_read(dl_comm* c, double* total_ms_host, int64_t* exchanges_host) {
+    if (!c || !total_ms_host || !exchanges_host) return fail(DL_E_ARG, "null argument");
+    double total = 0.0;
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        DL_HIP(hipEventSynchronize(c->prof_stop[i]));
+        float ms = 0.f;
+        DL_HIP(hipEventElapsedTime(&ms, c->prof_start[i], c->prof_stop[i]));
+        total += (double)ms;
+    }
+    *total_ms_host = total;
+    *exchanges_host = (int64_t)c->prof_used;
+    return 0;
+}
+
+}  // extern "C"

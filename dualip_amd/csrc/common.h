@@ -104,7 +104,8 @@ struct dl_matching {
     // zeroed for the next launch (two launches less per iteration); valid only for the dual vector at hot_ready_lambda
     bool hot_ready = false;
     const void* hot_ready_lambda = nullptr;
-    const void* hot_ready_owner = nullptr;  // the dl_agd whose loop prepared them
+    uint64_t hot_ready_owner = 0;           // uid of the dl_agd whose loop prepared them (never an address: a freed optimiser's
+                                            // buffers can be handed out again at the same addresses)
     // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 are dense, +f_k / -f_k on every non-zero
     const void* fair = nullptr;       // caller-owned val[nnz]
     double fair_max = 0.0;            // max |f|
@@ -121,6 +122,7 @@ struct dl_matching {
 };
 
 struct dl_agd {
+    uint64_t uid = 0;        // process-unique, never reused
     int64_t m = 0, max_iter = 0;
     int val_dtype = DL_F32;
     void* x = nullptr;       // owned, val[m]: point of evaluation
@@ -134,6 +136,7 @@ struct dl_agd {
     void* state = nullptr;   // owned, two dl::AgdDevState (double buffered)
     int state_cur = 0;
     void* x_alt = nullptr;   // owned: the buffer the next iterate is written to
-    double* packed = nullptr;  // owned scratch double[m+2] for dl_agd_run_matching
+    double* packed = nullptr;  // owned scratch double[m+2]: the sums the latest step used
+    double* packed_blk[3] = {nullptr, nullptr, nullptr};  // owned, lazily: reduced sums of the further blocks of a split shard
     double* partial_stats = nullptr;  // owned: per-workgroup partial reductions of the step kernel
 };

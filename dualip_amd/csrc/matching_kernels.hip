@@ -24,6 +24,9 @@
 //     per Newton pass);
 //   * every workgroup writes its private integer gradient to its own slab; a second small kernel sums the slabs
 //     (exactly) and converts to double.
+#include <atomic>
+
+#include "comm.h"
 #include "fused_common.h"
 
 namespace dl {
@@ -265,10 +268,20 @@ constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
 
 // Hot-rows plan (inv != null): slab column p belongs to the caller's row inv[p]; columns >= m_hot hold nothing -- their sums
 // are in `cold` (one int64 per row, global atomics).
+// MODE 0: packed[i] = sum.  MODE 1: packed[i] += sum (second and later blocks of a split shard).  MODE 2: the sum (plus
+// packed[i] when `accumulate`) goes to this rank's slot in EVERY rank's mailbox (comm.h: the P2P exchange) -- the slab
+// reduction is the pushing launch, no separate collective.
+template <int MODE>
 __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
-                                                                      const long long* __restrict__ cold, const double* __restrict__ dense) {
+                                                                      const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
+                                                                      int accumulate) {
+    auto emit = [&](int64_t i, double v) {
+        if constexpr (MODE == 0) packed[i] = v;
+        else if constexpr (MODE == 1) packed[i] += v;
+        else push_value(push, i, accumulate ? packed[i] + v : v);
+    };
     __shared__ long long shi[kRedThreads];
     __shared__ double sh[kRedThreads / 32];
     const int tid = threadIdx.x;
@@ -298,8 +311,9 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
             long long t = shi[rl];
             for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
             const int64_t orow = inv ? (int64_t)inv[row] : row;
-            packed[orow] = (dense && orow >= m - 2) ? dense[orow - (m - 2)] : ldexp((double)t, -(*shift_in));  // (fairness pair: the two dense rows)
+            emit(orow, (dense && orow >= m - 2) ? dense[orow - (m - 2)] : ldexp((double)t, -(*shift_in)));  // (fairness pair: the two dense rows)
         }
+        if constexpr (MODE == 2) push_finish(push);
         return;
     }
     {
@@ -321,9 +335,10 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
                 oo += sh[2 * w];
                 qq += sh[2 * w + 1];
             }
-            packed[m] = oo;
-            packed[m + 1] = qq;
+            emit(m, oo);
+            emit(m + 1, qq);
         }
+        if constexpr (MODE == 2) push_finish(push);
     }
 }
 
@@ -365,10 +380,11 @@ size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad) {
 template <class T, class RowT, bool LAM, bool GRAD, bool DPP>
 static int launch_fused_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
     auto kern = matching_fused_kernel<T, RowT, LAM, GRAD, DPP>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};  // per instantiation, one bit per device (the opt-in to > 64 KB of LDS is per device)
+    const uint64_t bit = 1ull << (h->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
         DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(h->n_wg), dim3(kFusedThreads), h->lds_bytes, st, args);
     DL_HIP(hipGetLastError());
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restri
 
 // the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
 template <class T>
-static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
+static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid) {
     FusedArgs<T> args;
     args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
     args.wg_tile_begin = h->wg_tile_begin;
@@ -448,7 +464,8 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.partial_fair = h->partial_fair;
     args.fair_max = h->fair ? h->fair_max : 0.0;
     if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
-        if (!(h->hot_ready && h->hot_ready_lambda == lambda)) {  // (the device-resident AGD loop leaves both prepared, common.h)
+        // (the device-resident AGD loop leaves both prepared, common.h -- only honoured for the optimiser that prepared them)
+        if (!(h->hot_ready && owner_uid != 0 && h->hot_ready_owner == owner_uid && h->hot_ready_lambda == lambda)) {
             const unsigned blocks = (unsigned)((h->m + 255) / 256);
             hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
             DL_HIP(hipGetLastError());
@@ -485,10 +502,11 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     return 0;
 }
 
-int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st) {
-    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st);
-    return fused_typed<double>(h, lambda, gamma, x_out, st);
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid) {
+    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st, owner_uid);
+    return fused_typed<double>(h, lambda, gamma, x_out, st, owner_uid);
 }
+
 
 template <class T>
 static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
@@ -496,13 +514,22 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
         DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
         return 0;
     }
-    int rc = fused_typed<T>(h, lambda, gamma, x_out, st);
+    int rc = fused_typed<T>(h, lambda, gamma, x_out, st, 0);
     if (rc) return rc;
+    return matching_reduce(h, packed_out, 0, nullptr, st, 0);
+}
+
+// The slab reduction alone (after matching_launch_fused).  mode 0: packed = sums; 1: packed += sums; 2: the sums
+// (+ packed when `push_accumulate`) go to the mailboxes described by *push.
+int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* push, hipStream_t st, int push_accumulate) {
     const int n_slabs = h->grad_lds ? h->n_wg : 1;
     const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial),
-                       h->partial_scal, h->shift_dev, n_slabs, h->n_wg, h->m, h->mpad, packed_out, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad,
-                       h->fair ? h->dense_ax : nullptr);
+    PushArgs pa = PushArgs();
+    if (push) pa = *push;
+    auto kern = mode == 0 ? reduce_partials_kernel<0> : (mode == 1 ? reduce_partials_kernel<1> : reduce_partials_kernel<2>);
+    hipLaunchKernelGGL(kern, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial), h->partial_scal, h->shift_dev, n_slabs,
+                       h->n_wg, h->m, h->mpad, packed, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad, h->fair ? h->dense_ax : nullptr, pa,
+                       push_accumulate);
     DL_HIP(hipGetLastError());
     return 0;
 }

@@ -12,6 +12,8 @@
 // entry beyond the LDS table) are single-column "long" tiles: their descriptors follow the window tiles (after one all-zero
 // descriptor) and are walked by process_long_tile in separate loops ahead of the hot one: by one wavefront each, or -- the
 // very long ones, listed last -- by a whole workgroup.
+#include <atomic>
+
 #include "fused_common.h"
 #include "simplex4.h"
 
@@ -258,10 +260,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 template <class T, class RowT, bool LAM, bool GRAD, bool HOT, bool FAIR = false>
 static int launch_fused4_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
     auto kern = matching_fused_kernel4<T, RowT, LAM, GRAD, HOT, FAIR>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};  // per instantiation, one bit per device (the opt-in to > 64 KB of LDS is per device)
+    const uint64_t bit = 1ull << (h->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
         DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(h->n_wg), dim3(kFusedThreads), h->lds_bytes, st, args);
     DL_HIP(hipGetLastError());

@@ -352,53 +352,91 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
     """Column-sharded objective: one process per GPU, each holding a contiguous block of entities.
 
     Same constructor as the reference (matching.py:218-225).  ``calculate`` runs the local fused pass, sum-all-reduces
-    the packed [A x | c.x | sum x^2] buffer once over the default process group (RCCL on ROCm) and finishes the
-    objective on every rank, so all ranks can apply the identical dual update without a broadcast.
-    ``local_objective`` may be injected (tests drive the exchange logic on CPU/gloo with an oracle-backed local part).
+    the packed [A x | c.x | sum x^2] buffer once and finishes the objective on every rank, so all ranks can apply the
+    identical dual update without a broadcast.  On the GPU the exchange is the C library's (``dl_comm``: a one-shot P2P
+    exchange over hipIpc-mapped mailboxes, or RCCL -- dualip_amd/utils/comm.py); ``torch.distributed`` of the given
+    ``process_group`` is the side channel that sets it up, and the exchange itself only for CPU tensors (tests drive the
+    exchange logic on CPU/gloo with an oracle-backed ``local_objective``).
+
+    ``local_matching_input_args`` may be a list of MatchingInputArgs: the rank's shard split into blocks of columns, each
+    with its own kernel handle, run back to back per iteration (with RCCL the collective of every block but the last
+    overlaps the next block's fused pass -- see dl_agd_run_matching_sharded).
     """
 
     _dualip_native = True
 
     def __init__(
         self,
-        local_matching_input_args: MatchingInputArgs,
+        local_matching_input_args,
         b_vec: torch.Tensor,
         gamma: float,
         host_device=None,
         batching: bool = True,
         local_objective=None,
         process_group=None,
+        comm_backend: Optional[str] = None,
     ):
         self.gamma = gamma
         self.host_device = host_device
-        self.equality_mask = local_matching_input_args.equality_mask if local_matching_input_args is not None else None
+        blocks_args = list(local_matching_input_args) if isinstance(local_matching_input_args, (list, tuple)) else [local_matching_input_args]
+        first = blocks_args[0]
+        self.equality_mask = first.equality_mask if first is not None else None
         self.process_group = process_group
+        self.comm_backend = comm_backend
+        self._comm = None
+        self.more_blocks = []
         if local_objective is None:
-            if local_matching_input_args.b_vec is not None:
-                raise ValueError("local partitions must be built with b_vec=None (b_vec is shared by all ranks)")
-            local_objective = MatchingSolverDualObjectiveFunction(local_matching_input_args, gamma, batching)
+            for args in blocks_args:
+                if args.b_vec is not None:
+                    raise ValueError("local partitions must be built with b_vec=None (b_vec is shared by all ranks)")
+            local_objective = MatchingSolverDualObjectiveFunction(first, gamma, batching)
+            self.more_blocks = [MatchingSolverDualObjectiveFunction(args, gamma, batching) for args in blocks_args[1:]]
+            if len(self.more_blocks) > 3:
+                raise ValueError("a shard can be split into at most 4 blocks")
         self.local_objective = local_objective
-        self._needs_dual_tensor = bool(getattr(local_objective, "_needs_dual_tensor", False))
+        self._needs_dual_tensor = any(bool(getattr(o, "_needs_dual_tensor", False)) for o in [local_objective] + self.more_blocks)
         self.device = local_objective.device
         self.dtype = local_objective.dtype
         self.m = local_objective.m
         # every rank finishes the objective on its own device (the reference moves b to host_device = cuda:0)
         self.b_vec = b_vec.to(device=self.device, dtype=self.dtype)
 
+    # ---- the exchange ---------------------------------------------------------------------------------------
+    def communicator(self):
+        """The C library's communicator for this objective's device (created on first use: a collective call)."""
+        if self._comm is None:
+            from dualip_amd.utils.comm import Communicator
+
+            self._comm = Communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
+        return self._comm
+
+    def block_handles(self):
+        """ctypes array of the kernel handles of this rank's blocks (for dl_agd_run_matching_sharded)."""
+        objs = [self.local_objective] + self.more_blocks
+        return (ctypes.c_void_p * len(objs))(*[o._handle for o in objs]), len(objs)
+
     def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
+        if packed.is_cuda and hasattr(self.local_objective, "_handle"):
+            return self.communicator().all_reduce_(packed)  # the ONE collective of an iteration
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)  # the ONE collective of an iteration
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)
         return packed
 
     def calculate_packed(self, dual_val: torch.Tensor, gamma: float = None, x_out=None) -> torch.Tensor:
         if gamma is not None and gamma != self.gamma:
             self.gamma = gamma
-        return self._exchange(self.local_objective.calculate_packed(dual_val, self.gamma, x_out))
+        packed = self.local_objective.calculate_packed(dual_val, self.gamma, x_out)
+        for blk in self.more_blocks:
+            packed += blk.calculate_packed(dual_val, self.gamma)
+        return self._exchange(packed)
 
     def calculate_packed_ptr(self, lambda_ptr: int, gamma: float = None) -> torch.Tensor:
         if gamma is not None and gamma != self.gamma:
             self.gamma = gamma
-        return self._exchange(self.local_objective.calculate_packed_ptr(lambda_ptr, self.gamma))
+        packed = self.local_objective.calculate_packed_ptr(lambda_ptr, self.gamma)
+        for blk in self.more_blocks:
+            packed += blk.calculate_packed_ptr(lambda_ptr, self.gamma)
+        return self._exchange(packed)
 
     def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, rank: int = 0, **kwargs) -> ObjectiveResult:
         if save_primal:

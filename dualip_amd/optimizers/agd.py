@@ -17,6 +17,7 @@ synchronisation per iteration on routes 1/2), False = silent.
 """
 import ctypes
 import math
+import os
 from typing import Callable, Optional
 
 import numpy as np
@@ -187,7 +188,8 @@ class AcceleratedGradientDescent:
                     for k in range(n if (per_iteration or self._user_callback is None) else 0):
                         it = first + k + 1
                         if per_iteration:
-                            self.iteration_callback(it, run.result_from_row(rows[k], with_grad=True))
+                            if rank == 0:  # (the reference calls back on rank 0 only, agd.py:166-168)
+                                self.iteration_callback(it, run.result_from_row(rows[k], with_grad=True))
                         elif rank == 0:
                             print(_summary_from_log(it, rows[k]))
             return run.finish()
@@ -214,6 +216,13 @@ class DeviceRun:
         # (after its all-reduce) and the generic-LP objective; the single-device matching objective runs wholly inside C
         self.packed_route = self.sharded or bool(getattr(f, "_dualip_packed", False))
         self.local = f.local_objective if self.sharded else f
+        # the column-sharded matching objective on the GPU: the whole loop, exchange included, runs inside the C library
+        # (dl_agd_run_matching_sharded); objectives that need the duals as a tensor every iteration (user-defined projection
+        # operators, injected local objectives) keep the per-iteration route below
+        self.native_sharded = (
+            self.sharded and hasattr(f, "block_handles") and hasattr(self.local, "_handle") and not getattr(f, "_needs_dual_tensor", False)
+            and self.local.device.type == "cuda" and os.environ.get("DUALIP_SHARDED_LOOP", "c") != "python"
+        )
         if not self.sharded and f.b_vec is None:
             raise ValueError("a matching objective built with b_vec=None only provides local partial sums; wrap it in the distributed objective")
         self.device, self.dtype, self.m = self.local.device, self.local.dtype, self.local.m
@@ -270,6 +279,14 @@ class DeviceRun:
                         self.decay_factor, _hip.ptr(self.primal) if (last and self.primal is not None) else None, stream,
                     )
                 )
+            elif self.native_sharded:
+                handles, n_blocks = self.f.block_handles()
+                _hip.check(
+                    lib.dl_agd_run_matching_sharded(
+                        self.state, handles, n_blocks, self.f.communicator().handle, _hip.ptr(self.b_vec), self.done + 1, n, ctypes.byref(self.gamma),
+                        self.decay_steps, self.decay_factor, stream,
+                    )
+                )
             else:
                 by_address = hasattr(self.f, "calculate_packed_ptr") and not getattr(self.f, "_needs_dual_tensor", False)
                 for it in range(self.done + 1, self.done + n + 1):
@@ -304,6 +321,8 @@ class DeviceRun:
 
     def finish(self) -> SolverResult:
         solver = self.solver
+        if self.native_sharded:
+            self.f.communicator().check()  # a P2P wait that timed out invalidates the run: raise instead of returning numbers
         rows = self.read_log(0, self.done)
         mx = ctypes.c_double(0.0)
         with torch.cuda.device(self.device):

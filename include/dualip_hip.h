@@ -176,6 +176,59 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
                         double* gamma_io_host, int64_t gamma_decay_steps, double decay_factor, void* x_out,
                         dl_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The exchange of the column-sharded objective -- MatchingSolverDualObjectiveFunctionDistributed.calculate's
+ * three dist.reduce calls (src/dualip/objectives/matching.py:272-277) and maximize()'s barrier + two broadcasts
+ * (src/dualip/optimizers/agd.py:204-206; driver benchmark/run_matching_benchmark_dist.py:136-149) become ONE
+ * sum-all-reduce of double[m + 2] = [A x | c.x | sum x^2] per iteration; every rank then applies the identical update.
+ * One process per GPU.  Two back-ends:
+ *   DL_COMM_RCCL  ncclAllReduce over xGMI (librccl.so.1 is opened at run time, the copy PyTorch-ROCm loaded if present);
+ *   DL_COMM_P2P   one-shot all-to-all over hipIpc-mapped fine-grained mailboxes, fused into the slab-reduction and step
+ *                 kernels (no collective launch; every rank adds the W partial vectors in rank order, so all ranks hold
+ *                 bit-identical sums).  Up to 16 ranks of one node; ranks may share a device.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct dl_comm dl_comm;
+enum { DL_COMM_RCCL = 1, DL_COMM_P2P = 2 };
+#define DL_RCCL_ID_BYTES 128   /* ncclUniqueId */
+#define DL_IPC_HANDLE_BYTES 64 /* hipIpcMemHandle_t */
+
+/* RCCL: rank 0 calls dl_comm_rccl_unique_id and hands the 128 bytes to every rank (any side channel: the reference's
+ * torch.distributed store, MPI, a file); then every rank calls dl_comm_create_rccl (collective: ncclCommInitRank) with the
+ * device it computes on current.  max_count: largest all-reduce in doubles (m + 2). */
+int dl_comm_rccl_unique_id(void* id_out_host);
+int dl_comm_create_rccl(dl_comm** out, int32_t world, int32_t rank, const void* unique_id_host, int64_t max_count);
+/* RCCL: wrap a communicator the caller already owns (ncclComm_t); it is not destroyed with the handle. */
+int dl_comm_adopt_rccl(dl_comm** out, void* nccl_comm, int64_t max_count);
+/* P2P, two steps around one all-gather on the caller's side channel: _begin allocates this rank's mailbox and returns its
+ * hipIpcMemHandle (DL_IPC_HANDLE_BYTES); _connect takes all ranks' handles in rank order (world x DL_IPC_HANDLE_BYTES) and maps
+ * them.  The caller must make sure every rank has connected before the first exchange (a barrier on the side channel). */
+int dl_comm_p2p_begin(dl_comm** out, int32_t world, int32_t rank, int64_t max_count, void* ipc_handle_out_host);
+int dl_comm_p2p_connect(dl_comm* c, const void* all_handles_host);
+int dl_comm_destroy(dl_comm* c);
+/* what = 0 back-end (DL_COMM_*), 1 world size, 2 rank, 3 exchanges issued so far, 4 capacity in doubles. */
+int64_t dl_comm_info(const dl_comm* c, int what);
+/* In-place sum over the ranks of buf[0..count) (double, device), enqueued on `stream`; count <= max_count.  Every rank must
+ * issue the same sequence of exchanges on a communicator. */
+int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream);
+/* Synchronises `stream` and reports whether a P2P exchange ever timed out waiting for a rank (DL_E_STATE; waits are bounded --
+ * 5 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device). */
+int dl_comm_check(dl_comm* c, dl_stream_t stream);
+/* Developer aid: multiply every exchanged sum by `scale` (one rank standing in for W equal shards). */
+int dl_comm_set_emulation(dl_comm* c, double scale);
+/* Measurement hook: HIP events from the end of the last fused pass of an iteration to the end of the step's first kernel
+ * (slab reduction + exchange + gradient statistics) inside dl_agd_run_matching_sharded. */
+int dl_comm_profile(dl_comm* c, int enable);
+int dl_comm_profile_read(dl_comm* c, double* total_ms_host, int64_t* exchanges_host);
+
+/* dl_agd_run_matching for a column shard: this rank's columns as n_blocks (1..4) matching handles created with the same m
+ * and dtype, the exchange inside the loop, nothing returns to the host between iterations.  All ranks must call it with the
+ * same iteration range.  With n_blocks > 1 and RCCL the collectives run on a communicator-owned side stream, those of all
+ * but the last block overlapping the next block's fused pass.  save_primal is not offered (the reference raises
+ * NotImplementedError for it in distributed mode, matching.py:255-256). */
+int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n_blocks, dl_comm* comm, const void* b,
+                                int64_t first_iter, int64_t n_iters, double* gamma_io_host, int64_t gamma_decay_steps,
+                                double decay_factor, dl_stream_t stream);
+
 /* Copy logs to the host (synchronises the stream).  rows [first, first+count) of the per-iteration log; each row
  * is 8 doubles: dual_objective, step_size, reg_penalty, dual_val_times_grad, max_pos_slack, sum_pos_slack,
  * ||grad||_2, primal_objective (c.x). */

@@ -1,0 +1,200 @@
+"""The exchange of the column-sharded iteration (``dl_comm``, ``dl_allreduce_sum``, ``dl_agd_run_matching_sharded``) on the GPU.
+
+One-GPU box: several processes share cuda:0.  RCCL refuses that, the P2P back-end (hipIpc-mapped fine-grained mailboxes)
+does not -- every word of its protocol runs: remote-process stores into a mailbox, system-scope release, flags, local
+polling, acquire, rank-ordered sums.  Checked here:
+  * stand-alone all-reduce, 2 and 4 processes, exact sums over many rounds with UNEVEN load between the ranks (a rank that
+    arrives early must wait; a rank two exchanges ahead must not overwrite a slot still being read);
+  * the C loop against the reference's 2- and 4-rank golden traces (g3_syn2000.npz), ranks bit-identical;
+  * the C loop with one rank (P2P and RCCL back-ends, split shard) bit-identical to the single-device loop.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _allreduce_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.utils.comm import Communicator
+
+        n = 10_002
+        comm = Communicator(n, "cuda:0", backend="p2p")
+        assert comm.backend == "p2p" and comm.info()["world"] == world
+        g = torch.Generator(device="cuda:0").manual_seed(1234)  # the same stream of values on every rank
+        bad = 0
+        burn = torch.empty(1 << 24, device="cuda:0")
+        for rnd in range(200):
+            parts = torch.randint(-1000, 1000, (world, n), generator=g, device="cuda:0").double()  # integers: every order of summation is exact
+            want = parts.sum(0)
+            if (rnd + rank) % 3 == 0:  # uneven load: this rank reaches the exchange late
+                for _ in range(1 + (rnd % 4)):
+                    burn.normal_()
+            v = parts[rank].clone()
+            comm.all_reduce_(v)
+            bad += int((v != want).sum())
+        comm.check()
+        q.put((rank, bad, comm.exchanges))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_allreduce_is_exact_under_uneven_load(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get() for _ in procs]
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for rank, bad, exchanges in got:
+        assert bad == 0, f"rank {rank}: {bad} wrong words"
+        assert exchanges >= 200
+
+
+def _loop_worker(rank, world, port, kind, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunctionDistributed
+        from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+        from dualip_amd.projections import create_projection_map
+        from dualip_amd.utils.dist_utils import balanced_block_ranges, global_to_local_projection_map
+        from tests.helpers import load, problem, sub_problem, torch_args
+
+        z = load("g3_syn2000.npz")
+        p = problem(z)
+        gamma, iters, s0, s1 = z["params"]
+        n = p["n"]
+        if kind == "mixed":
+            half = int(z["mixed_boundary"])
+            pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)), **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n))}
+            ranges = balanced_block_ranges([(0, half), (half, n)], world, rank)
+        else:
+            pm = create_projection_map("simplex", {"z": 1.0}, n)
+            ranges = balanced_block_ranges([(0, n)], world, rank)
+        parts = [sub_problem(p, lo, hi) for lo, hi in ranges]
+        colptr = [np.zeros(1, dtype=np.int64)]
+        for q_ in parts:
+            colptr.append(q_["colptr"][1:] + colptr[-1][-1])
+        local = dict(m=p["m"], n=sum(q_["n"] for q_ in parts), colptr=np.concatenate(colptr), rowidx=np.concatenate([q_["rowidx"] for q_ in parts]),
+                     a=np.concatenate([q_["a"] for q_ in parts]), c=np.concatenate([q_["c"] for q_ in parts]), b=p["b"])
+        cols = [c for lo, hi in ranges for c in range(lo, hi)]
+        args = torch_args(local, "f64", global_to_local_projection_map(pm, cols), "cuda:0", with_b=False)
+        f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0", comm_backend="p2p")
+        solver = AcceleratedGradientDescent(max_iter=int(iters), gamma=float(gamma), initial_step_size=float(s0), max_step_size=float(s1), iteration_callback=False)
+        run = solver.start_device_run(f, torch.zeros(p["m"], dtype=torch.float64, device="cuda:0"), rank=rank)
+        assert run.native_sharded  # the loop, exchange included, runs inside the C library
+        run.advance(int(iters) // 2)
+        run.advance(int(iters))
+        res = run.finish()
+        run.close()
+        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), f.communicator().backend, f.communicator().exchanges))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4)])
+def test_sharded_c_loop_matches_reference_goldens(kind, world):
+    from tests.helpers import load, relerr
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, log, dual, backend, exchanges = q.get()
+        out[rank] = (log, dual, backend, exchanges)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    z = load("g3_syn2000.npz")
+    key = f"simplex1|w{world}|f64" if kind == "simplex" else "mixed|w2|f64"
+    want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
+    for r in range(world):
+        assert out[r][2] == "p2p" and out[r][3] >= len(want_log)
+        assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][0], out[r][0])  # identical update on every rank, no broadcast
+    assert relerr(out[0][0][:40], want_log[:40]) < 1e-9
+    assert relerr(out[0][0], want_log) < 1e-6
+    assert relerr(out[0][1], want_dual) < 1e-5
+
+
+@pytest.mark.parametrize("backend,blocks", [("p2p", 1), ("p2p", 2), ("rccl", 1), ("rccl", 2)])
+def test_one_rank_sharded_loop_equals_single_device_loop(backend, blocks):
+    """World of one: the sharded C loop (slab reduction -> exchange -> step from the exchanged sums) must reproduce the
+    single-device loop bit for bit with one block (the same sums take another road), and to rounding with a split shard."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction, MatchingSolverDualObjectiveFunctionDistributed
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import load, problem, sub_problem, torch_args
+
+    z = load("g1_syn2000.npz")
+    p = problem(z)
+    n, m = p["n"], p["m"]
+    pm = create_projection_map("simplex", {"z": 1.0}, n)
+    f1 = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, "cuda:0"), 0.02)
+    kw = dict(max_iter=50, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
+    lam0 = torch.zeros(m, dtype=torch.float32, device="cuda:0")
+    r1 = AcceleratedGradientDescent(**kw).maximize(f1, lam0)
+    cut = [0, n] if blocks == 1 else [0, n // 3, n]
+    largs = []
+    for lo, hi in zip(cut[:-1], cut[1:]):
+        sub = sub_problem(p, lo, hi)
+        largs.append(torch_args(sub, "f32", create_projection_map("simplex", {"z": 1.0}, sub["n"]), "cuda:0", with_b=False))
+    fd = MatchingSolverDualObjectiveFunctionDistributed(largs if blocks > 1 else largs[0], torch.from_numpy(p["b"]), 0.02, host_device="cuda:0", comm_backend=backend)
+    solver = AcceleratedGradientDescent(**kw)
+    run = solver.start_device_run(fd, lam0)
+    assert run.native_sharded
+    run.advance(50)
+    r2 = run.finish()
+    run.close()
+    assert fd.communicator().backend == backend
+    if blocks == 1:
+        assert np.array_equal(np.array(r1.dual_objective_log), np.array(r2.dual_objective_log))
+        assert torch.equal(r1.dual_val, r2.dual_val)
+    else:
+        from tests.helpers import relerr
+
+        assert relerr(np.array(r2.dual_objective_log)[:15], np.array(r1.dual_objective_log)[:15]) < 1e-4
+    # the stand-alone calculate() of the distributed objective goes through the same communicator
+    lam = torch.from_numpy(z["lam_small"]).float().to("cuda:0")
+    g1 = f1.calculate(lam, gamma=0.02).dual_gradient
+    g2 = fd.calculate(lam, gamma=0.02).dual_gradient
+    assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-6)
