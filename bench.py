@@ -168,13 +168,16 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
     }
 
 
-def timed_window(run, local, comm, n_iters, fence, elapsed_max):
+def timed_window(run, local, comm, n_iters, fence, elapsed_max, stride=1):
     """Time `n_iters` iterations of a device run between two fences; returns (seconds [max over ranks], fused launches,
     fused-kernel ms, exchange brackets, exchange ms)."""
     fence()
-    local.profile(True)
+    # every launch pair of event records costs ~5 us of stream time (measured: 9.5 us per iteration with two pairs): bracket
+    # every launch when an iteration is milliseconds long, every 8th when it is a fraction of one
+    events = 0 if os.environ.get("DUALIP_BENCH_NO_EVENTS") == "1" else stride
+    local.profile(events)
     if comm is not None:
-        comm.profile(True)
+        comm.profile(events)
     gc.disable()
     t0 = time.perf_counter()
     run.advance(n_iters)
@@ -426,7 +429,8 @@ def main():
     solver = AcceleratedGradientDescent(max_iter=total_iters, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
     run = solver.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
     run.advance(args.warmup)
-    elapsed, launches, kernel_ms, xn, xms = timed_window(run, local, comm, args.steps, fence, elapsed_max)
+    stride = 1 if nnz_first > 400_000_000 else 8
+    elapsed, launches, kernel_ms, xn, xms = timed_window(run, local, comm, args.steps, fence, elapsed_max, stride)
     result = run.finish()
     run.close()
     avg_kernel_s, achieved = roof(kernel_ms, launches)
@@ -438,9 +442,9 @@ def main():
         w0, w1 = int(S * 0.8), int(S * 0.9)
         solver2 = AcceleratedGradientDescent(max_iter=S, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
         run2 = solver2.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
-        tA, *_ = timed_window(run2, local, comm, w0, fence, elapsed_max)
-        tB, lB, kB, xnB, xmsB = timed_window(run2, local, comm, w1 - w0, fence, elapsed_max)
-        tC, *_ = timed_window(run2, local, comm, S - w1, fence, elapsed_max)
+        tA, *_ = timed_window(run2, local, comm, w0, fence, elapsed_max, 64)
+        tB, lB, kB, xnB, xmsB = timed_window(run2, local, comm, w1 - w0, fence, elapsed_max, stride)
+        tC, *_ = timed_window(run2, local, comm, S - w1, fence, elapsed_max, 64)
         res2 = run2.finish()
         run2.close()
         lam_late = res2.dual_val
@@ -505,6 +509,7 @@ def main():
                 "kernel": "matching_fused_kernel4" if lay["layout"] == 4 else "matching_fused_kernel",
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "kernel_launches": launches,
+                "event_stride": stride,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "physical_bytes_per_launch": phys_bytes,
                 "physical_frac": phys_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else None,

@@ -686,6 +686,8 @@ int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, doub
 int dl_matching_profile(dl_matching* h, int enable) {
     if (!h) return fail(DL_E_ARG, "null handle");
     h->prof_on = enable != 0;
+    h->prof_stride = enable > 1 ? enable : 1;
+    h->prof_seen = 0;
     h->prof_used = 0;
     return 0;
 }
@@ -923,7 +925,7 @@ int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n
             int rc = 0;
             if (!empty) rc = matching_launch_fused(f, s->x, gamma, nullptr, st, 0);
             if (rc) return rc;
-            if (last && comm->prof_on) {  // measurement: from the end of the last fused pass to the end of the step's first kernel
+            if (last && comm->prof_on && (comm->prof_seen++ % (uint64_t)comm->prof_stride) == 0) {  // measurement: end of the last fused pass -> end of the step's first kernel
                 if (comm->prof_used == comm->prof_start.size() && comm->prof_start.size() < 16384) {
                     hipEvent_t e0, e1;
                     DL_HIP(hipEventCreate(&e0));

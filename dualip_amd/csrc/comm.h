@@ -41,22 +41,29 @@ struct MailArgs {
     unsigned long long timeout_ticks;     // 100 MHz wall clock
 };
 
+// Memory-ordering rules of the exchange (no fence anywhere -- a system-scope release would write back every dirty L2 line
+// of the device and an acquire would invalidate the caches, once per workgroup: measured 61 us per exchange against 19 us
+// for a one-rank RCCL call):
+//   * the mailbox is UNCACHED fine-grained memory, and every access to it is a system-scope (sc0 sc1) store or load, i.e.
+//     written through to / fetched from memory: nothing about it ever sits dirty or stale in an L1 or L2;
+//   * a store is complete -- visible to every agent -- when the issuing wavefront's vmcnt has counted it down, so
+//     "s_waitcnt vmcnt(0)" after the data stores orders them before everything the wavefront does next;
+//   * workgroups of the pushing launch count their arrival with a device-scope atomic only AFTER that wait; the one that
+//     arrives last therefore knows all data of the launch is in place when it writes the flags;
+//   * the reader polls its flags and then issues its data loads (program order + a workgroup barrier in between).
 __device__ __forceinline__ void push_value(const PushArgs& p, int64_t i, double v) {
     for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.dst[r] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Called by EVERY thread of EVERY block of the pushing launch after its push_value calls: the block that arrives last
-// raises the flags.  Stores of a block are complete (acknowledged) before its arrival is counted; the last arriver's flag
-// stores are therefore ordered after all data stores of the launch.
+// Called by EVERY thread of EVERY block of the pushing launch after its push_value calls.
 __device__ __forceinline__ void push_finish(const PushArgs& p) {
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have landed
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == gridDim.x) {
+        const unsigned int old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == gridDim.x) {  // last arriver: every block's data is in place
             __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (stream ordered)
-            __threadfence_system();
-            for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -65,27 +72,37 @@ __device__ __forceinline__ void push_finish(const PushArgs& p) {
 __device__ __forceinline__ void mail_wait(const MailArgs& a) {
     if ((int)threadIdx.x < a.world) {
         if (__hip_atomic_load(a.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            const unsigned long long t0 = wall_clock64();
             const unsigned long long* f = a.flags + (size_t)threadIdx.x * kFlagStride;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-                __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > a.timeout_ticks) {
-                    __hip_atomic_store(a.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+                const unsigned long long t0 = wall_clock64();
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > a.timeout_ticks) {
+                        __hip_atomic_store(a.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope
-        __threadfence_system();
     }
     __syncthreads();
 }
 
-// Sum of element i over the ranks' slots, in rank order (identical on every rank).
+// Sum of element i over the ranks' slots, in rank order (identical on every rank).  All loads of a batch of eight ranks are
+// in flight before the first is added: the mailbox is uncached, every load is a memory round trip.
 __device__ __forceinline__ double mail_sum(const MailArgs& a, int64_t i) {
-    double v = 0.0;
-    for (int r = 0; r < a.world; ++r) v += __hip_atomic_load(a.slots + (int64_t)r * a.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return v;
+    double acc = 0.0;
+    for (int r0 = 0; r0 < a.world; r0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u < a.world ? r0 + u : a.world - 1;
+            v[u] = __hip_atomic_load(a.slots + (int64_t)r * a.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (r0 + u < a.world) ? v[u] : 0.0;
+    }
+    return acc;
 }
 
 }  // namespace dl
@@ -115,6 +132,8 @@ struct dl_comm {
     double* scratch = nullptr;                    // owned, double[stride]: result staging of the stand-alone all-reduce
     // measurement (dl_comm_profile): event pairs around the exchanges of dl_agd_run_matching_sharded
     bool prof_on = false;
+    int prof_stride = 1;
+    uint64_t prof_seen = 0;
     size_t prof_used = 0;
     std::vector<hipEvent_t> prof_start, prof_stop;
 };

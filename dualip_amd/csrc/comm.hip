@@ -340,6 +340,8 @@ int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream)
 int dl_comm_profile(dl_comm* c, int enable) {
     if (!c) return fail(DL_E_ARG, "null communicator");
     c->prof_on = enable != 0;
+    c->prof_stride = enable > 1 ? enable : 1;
+    c->prof_seen = 0;
     c->prof_used = 0;
     return 0;
 }

@@ -117,6 +117,8 @@ struct dl_matching {
     unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
     bool prof_on = false;
+    int prof_stride = 1;      // bracket every prof_stride-th launch (the event records cost ~5 us per launch pair)
+    uint64_t prof_seen = 0;
     size_t prof_used = 0;
     std::vector<hipEvent_t> prof_start, prof_stop;
 };

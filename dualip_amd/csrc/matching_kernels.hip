@@ -476,7 +476,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     }
     if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
     hipEvent_t ev_stop = nullptr;
-    if (h->prof_on) {
+    if (h->prof_on && (h->prof_seen++ % (uint64_t)h->prof_stride) == 0) {
         if (h->prof_used == h->prof_start.size() && h->prof_start.size() < 16384) {
             hipEvent_t e0, e1;
             DL_HIP(hipEventCreate(&e0));

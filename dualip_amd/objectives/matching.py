@@ -250,9 +250,10 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns"]
         return {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
 
-    def profile(self, enable: bool) -> None:
-        """Bracket every fused-pass launch with HIP events on the launch stream (measurement hook)."""
-        _hip.check(self._lib.dl_matching_profile(self._handle, int(bool(enable))))
+    def profile(self, enable) -> None:
+        """Bracket fused-pass launches with HIP events on the launch stream (measurement hook): True = every launch, an
+        integer N > 1 = every N-th launch, False = off."""
+        _hip.check(self._lib.dl_matching_profile(self._handle, int(enable)))
 
     def profile_read(self):
         """(launches, total milliseconds) of the fused pass since ``profile(True)``; waits for the last launch."""

@@ -150,8 +150,8 @@ class Communicator:
     def set_emulation(self, scale: float) -> None:
         _hip.check(self.lib.dl_comm_set_emulation(self.handle, float(scale)))
 
-    def profile(self, enable: bool) -> None:
-        _hip.check(self.lib.dl_comm_profile(self.handle, int(bool(enable))))
+    def profile(self, enable) -> None:
+        _hip.check(self.lib.dl_comm_profile(self.handle, int(enable)))
 
     def profile_read(self):
         ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)

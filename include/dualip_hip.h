@@ -102,7 +102,8 @@ int dl_matching_calculate(dl_matching* h, const void* lambda, double gamma, doub
 
 /* Measurement hook: while enabled, every fused-pass launch of this handle is bracketed by HIP events recorded on
  * the launch stream (bench.py's roofline leg).  dl_matching_profile_read waits for the last recorded launch and
- * returns the number of launches and their summed duration in milliseconds since the hook was (re-)enabled. */
+ * returns the number of bracketed launches and their summed duration in milliseconds since the hook was (re-)enabled.
+ * enable = N > 1 brackets every N-th launch only (a pair of event records costs about as much as a small kernel launch). */
 int dl_matching_profile(dl_matching* h, int enable);
 int dl_matching_profile_read(dl_matching* h, double* total_ms_host, int64_t* launches_host);
 /* Fairness pair -- the extension the reference documents in docs/demo/matching_complex.rst:8-168 (two extra constraint
@@ -217,7 +218,7 @@ int dl_comm_check(dl_comm* c, dl_stream_t stream);
 int dl_comm_set_emulation(dl_comm* c, double scale);
 /* Measurement hook: HIP events from the end of the last fused pass of an iteration to the end of the step's first kernel
  * (slab reduction + exchange + gradient statistics) inside dl_agd_run_matching_sharded. */
-int dl_comm_profile(dl_comm* c, int enable);
+int dl_comm_profile(dl_comm* c, int enable);  /* enable = N > 1: every N-th exchange */
 int dl_comm_profile_read(dl_comm* c, double* total_ms_host, int64_t* exchanges_host);
 
 /* dl_agd_run_matching for a column shard: this rank's columns as n_blocks (1..4) matching handles created with the same m
