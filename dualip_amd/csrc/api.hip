@@ -47,6 +47,13 @@ int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, vo
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
+int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const dl_proj_desc* projs, int32_t n_proj, double min_share,
+                 std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, hipStream_t st);  // sell_build.hip
+int sell_finish(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const std::vector<uint8_t>& pid_sell, const std::vector<uint32_t>& desc,
+                hipStream_t st);
+int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
+int sell_refill_costs(dl_matching* h, hipStream_t st);
+constexpr int kSellMaxLen = 24;  // sell.h: kSellMaxH
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
 template <class SrcT, class DstT>
@@ -108,6 +115,8 @@ static void matching_free(dl_matching* h) {
     if (h->dense_ax) (void)hipFree(h->dense_ax);
     if (h->lam_perm) (void)hipFree(h->lam_perm);
     if (h->cold_grad) (void)hipFree(h->cold_grad);
+    for (void* p : {(void*)h->sell_desc, (void*)h->sell_len, (void*)h->sell_colstart, h->sell_a, h->sell_c, h->sell_r, h->sell_f})
+        if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_stop) (void)hipEventDestroy(e);
     delete h;
@@ -222,8 +231,11 @@ static void schedule_tiles4(std::vector<uint32_t>& words, std::vector<uint32_t>&
 }
 
 // Layout 4: 16-byte-aligned 256-element windows of whole columns; 12 dwords per tile (see matching_kernels4.hip).
+// pid_sell[q] != 0: the columns of entry q with <= kSellMaxLen non-zeros live in column-per-lane slices (sell.h) and are skipped
+// here; the entry's longer columns become single-column tiles (windows over such leftovers would stream mostly skipped data).
 static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs,
-                       std::vector<uint32_t>& words, std::vector<uint64_t>& cost_prefix, std::vector<uint32_t>& tile_pid, int64_t* n_long) {
+                       std::vector<uint32_t>& words, std::vector<uint64_t>& cost_prefix, std::vector<uint32_t>& tile_pid, int64_t* n_long,
+                       const std::vector<uint8_t>& pid_sell) {
     auto weight = [&](uint32_t pj) -> uint64_t {
         if (pj == kNoProj || (int32_t)pj >= n_proj) return 10;
         const int k = projs[pj].kind;
@@ -270,8 +282,13 @@ static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int3
         int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
         if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
+        const bool sliced = pj != kNoProj && pj < pid_sell.size() && pid_sell[pj];
+        if (sliced && len <= kSellMaxLen) {
+            flush();  // (a window holds consecutive columns only)
+            continue;
+        }
         const bool tail_quad = (uint64_t)k1 > nnz_al4;  // touches the array's last partial quad: no vector loads there
-        if (len > 253 || tail_quad || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
+        if (len > 253 || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
             flush();
             const uint64_t h4[4] = {(uint64_t)len, 0, 0, 0};
             emit((uint64_t)k0 | (1ull << 51), h4, pj);
@@ -385,8 +402,18 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const bool want4 = !(lay_env && lay_env[0] == '1');
     const bool aligned = (((uintptr_t)a | (uintptr_t)c) & 15u) == 0;
     h->layout = (want4 && aligned && nnz >= 1024) ? 4 : 1;
+    // column-per-lane slices for the short columns of simplex entries (sell.h): decided before the windows are packed.
+    // DUALIP_HIP_SELL=0 switches them off; DUALIP_HIP_SELL_MIN_SHARE = least share of an entry's non-zeros in short columns.
+    std::vector<uint8_t> pid_sell;
+    std::vector<uint32_t> sell_desc_h;
     if (h->layout == 4) {
-        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long));
+        const char* se = getenv("DUALIP_HIP_SELL");
+        double min_share = 0.9;
+        if (const char* ms = getenv("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
+        if (!(se && se[0] == '0')) CK(sell_prepare(h, colptr, idx_dtype, col_proj, projs_host, n_proj, min_share, pid_sell, sell_desc_h, st));
+    }
+    if (h->layout == 4) {
+        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell));
         h->n_tiles = (int64_t)(words4.size() / 12);
     } else {
         CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
@@ -404,9 +431,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* wg_env = getenv("DUALIP_HIP_NUM_WG");
     if (wg_env && atoi(wg_env) > 0) n_cu = atoi(wg_env);
-    int64_t want = (h->n_tiles + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
+    int64_t want = (h->n_tiles + h->n_sell + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
     h->n_wg = (int)(want < n_cu ? want : n_cu);
-    if (h->n_wg < 1) h->n_wg = h->n_tiles > 0 ? 1 : 0;
+    if (h->n_wg < 1) h->n_wg = (h->n_tiles + h->n_sell) > 0 ? 1 : 0;
     if (h->layout == 4) {
         // descriptor array = [window tiles in schedule order | one all-zero descriptor (what slots past the end read) |
         // single-column tiles]: the single-column walker runs in its own loop, outside the hot one
@@ -618,6 +645,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         for (int64_t pnew = 0; pnew < h->m_hot; ++pnew) hot_nnz += row_count_h[(size_t)inv[(size_t)pnew]];
         h->hot_fraction = nnz > 0 ? (double)hot_nnz / (double)nnz : 1.0;
     }
+    if (h->n_sell > 0) CK(sell_finish(h, colptr, idx_dtype, col_proj, pid_sell, sell_desc_h, st));
     // |x| bounds per projection kind: box -> max(|lower|, |upper|); simplex -> z (+ slack); cone / identity -> via |v| per launch
     bool used_none = false;
     std::vector<char> used((size_t)(n_proj > 0 ? n_proj : 1), 0);
@@ -630,6 +658,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (pid == kNoProj) used_none = true;
         else used[pid] = 1;
     }
+    for (size_t q = 0; q < pid_sell.size() && q < used.size(); ++q)
+        if (pid_sell[q]) used[q] = 1;
     h->has_unbounded = used_none;
     for (int32_t q = 0; q < n_proj; ++q) {
         if (!used[(size_t)q]) continue;
@@ -673,6 +703,9 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 9: return h->m_hot;
         case 10: return (int64_t)(h->hot_fraction * 1e6);
         case 11: return h->n_xlong;
+        case 12: return h->n_sell;
+        case 13: return h->n_sell_cols;
+        case 14: return h->n_sell_elems;
         default: return -1;
     }
 }
@@ -699,7 +732,7 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
         return 0;
     }
     if (h->m < 2) return fail(DL_E_ARG, "the fairness pair needs at least its own two rows");
-    if (h->n_tiles > 0 && (h->layout != 4 || !h->lam_lds || !h->grad_lds))
+    if ((h->n_tiles > 0 || h->n_sell > 0) && (h->layout != 4 || !h->lam_lds || !h->grad_lds))
         return fail(DL_E_STATE, "the fairness pair needs the 256-wide tile layout with the dual vector and the gradient in LDS (16-byte aligned values, nnz >= 1024)");
     if ((reinterpret_cast<uintptr_t>(f_values) & 15u) != 0) return fail(DL_E_ARG, "fairness values must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -721,9 +754,31 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
         if (e != hipSuccess) return hip_fail(e, "fairness values");
         memcpy(&h->fair_max, &bits, sizeof(double));
     }
+    {
+        int rc = sell_fill_fair(h, f_values, st);  // the slices read their own copy, in slice order
+        if (rc) return rc;
+    }
     h->fair = f_values;
     h->hot_ready = false;
     return 0;
+}
+
+int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->has_unbounded && h->nnz > 0) {  // max |c| bounds |v| (hence |x|) for projections that do not bound x themselves
+        unsigned long long* mx_dev = nullptr;
+        unsigned long long bits = 0;
+        DL_HIP(hipMalloc((void**)&mx_dev, sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(mx_dev, 0, sizeof(unsigned long long), st);
+        if (e == hipSuccess && launch_absmax(h->val_dtype, h->nnz, h->c, mx_dev, st)) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bits, mx_dev, sizeof(bits), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(mx_dev);
+        if (e != hipSuccess) return hip_fail(e, "cost update");
+        memcpy(&h->cmax, &bits, sizeof(double));
+    }
+    return sell_refill_costs(h, st);
 }
 
 int dl_matching_set_eq_padding(dl_matching* h, const int32_t* heights_host, int32_t n_rows, dl_stream_t stream) {
@@ -869,7 +924,7 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
     if (first_iter == 1 || f->hot_ready_owner != s->uid) f->hot_ready = false;  // a new run (or another optimiser) starts from its own dual vector
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
-        const bool empty = f->n_tiles == 0 || f->n_wg == 0;
+        const bool empty = (f->n_tiles == 0 && f->n_sell == 0) || f->n_wg == 0;
         int rc = empty ? matching_calculate(f, s->x, gamma, s->packed, xo, st) : matching_launch_fused(f, s->x, gamma, xo, st, s->uid);
         if (rc) return rc;
         const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
@@ -920,7 +975,7 @@ int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n
         for (int k = 0; k < n_blocks; ++k) {
             dl_matching* f = blocks[k];
             const bool last = k == n_blocks - 1;
-            const bool empty = f->n_tiles == 0 || f->n_wg == 0;
+            const bool empty = (f->n_tiles == 0 && f->n_sell == 0) || f->n_wg == 0;
             double* pk = k == 0 ? s->packed : s->packed_blk[k - 1];
             int rc = 0;
             if (!empty) rc = matching_launch_fused(f, s->x, gamma, nullptr, st, 0);

@@ -113,6 +113,16 @@ struct dl_matching {
     double* dense_ax = nullptr;       // owned, [2]: (A x) of the two rows, written after every fused launch
     void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
     long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
+    // column-per-lane slices (sell.h): short columns of simplex entries, sorted by length, 64 per slice, transposed copies of
+    // their values and row indices owned by the handle
+    int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0;
+    uint32_t* sell_desc = nullptr;    // owned, 4 dwords per slice
+    uint8_t* sell_len = nullptr;      // owned, [n_sell_cols]
+    uint64_t* sell_colstart = nullptr;  // owned, [n_sell_cols]: the column's first non-zero in the caller's arrays (primal output)
+    void* sell_a = nullptr;           // owned, val[n_sell_elems]
+    void* sell_c = nullptr;
+    void* sell_r = nullptr;           // owned, row indices (row_bytes wide)
+    void* sell_f = nullptr;           // owned: fairness values in slice order (dl_matching_set_fairness)
     int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)
     unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches

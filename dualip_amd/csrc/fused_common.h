@@ -44,7 +44,27 @@ struct FusedArgs {
     const T* lambda_orig;          // the caller's dual vector (g.lambda is the renumbered copy under the hot-rows plan)
     double* partial_fair;          // [n_wg]: sum f_k x_k of the workgroup
     double fair_max;               // max |f| (0 without the pair): enters the |v| bound of unbounded projections
+    // column-per-lane slices (sell.h)
+    const uint32_t* __restrict__ sell_desc;
+    const uint8_t* __restrict__ sell_len;
+    const uint64_t* __restrict__ sell_colstart;
+    const T* __restrict__ sell_a;
+    const T* __restrict__ sell_c;
+    const void* __restrict__ sell_r;
+    const T* __restrict__ sell_f;
+    uint32_t n_sell;
 };
+
+// The cold paths re-read the kernel arguments from the kernarg segment (they sit at offset 0) instead of keeping a dozen
+// pointers alive in SGPRs across the hot loop.
+template <class T>
+__device__ __forceinline__ const FusedArgs<T>& kernarg_args(const FusedArgs<T>& fallback) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const FusedArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return fallback;
+#endif
+}
 
 // a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
 // float : 1.5 * 2^52 trick -- for |ax * 2^shift| < 2^51 the integer sits in the mantissa of the fma result (3 VALU);

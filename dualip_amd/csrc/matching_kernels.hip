@@ -463,6 +463,14 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.lambda_orig = static_cast<const T*>(lambda);
     args.partial_fair = h->partial_fair;
     args.fair_max = h->fair ? h->fair_max : 0.0;
+    args.sell_desc = h->sell_desc;
+    args.sell_len = h->sell_len;
+    args.sell_colstart = h->sell_colstart;
+    args.sell_a = static_cast<const T*>(h->sell_a);
+    args.sell_c = static_cast<const T*>(h->sell_c);
+    args.sell_r = h->sell_r;
+    args.sell_f = static_cast<const T*>(h->sell_f);
+    args.n_sell = (uint32_t)h->n_sell;
     if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
         // (the device-resident AGD loop leaves both prepared, common.h -- only honoured for the optimiser that prepared them)
         if (!(h->hot_ready && owner_uid != 0 && h->hot_ready_owner == owner_uid && h->hot_ready_lambda == lambda)) {
@@ -510,7 +518,7 @@ int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void
 
 template <class T>
 static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
-    if (h->n_tiles == 0 || h->n_wg == 0) {  // no non-zeros at all: A x = 0
+    if ((h->n_tiles == 0 && h->n_sell == 0) || h->n_wg == 0) {  // no non-zeros at all: A x = 0
         DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
         return 0;
     }

@@ -15,6 +15,7 @@
 #include <atomic>
 
 #include "fused_common.h"
+#include "sell.h"
 #include "simplex4.h"
 
 namespace dl {
@@ -29,17 +30,6 @@ template <class RowT>
 struct alignas(sizeof(RowT) * 4) RowQuad {
     RowT v[4];
 };
-
-// The cold single-column path re-reads the kernel arguments from the kernarg segment (they sit at offset 0) instead of
-// keeping a dozen pointers alive in SGPRs across the hot loop.
-template <class T>
-__device__ __forceinline__ const FusedArgs<T>& kernarg_args(const FusedArgs<T>& fallback) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(const FusedArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    return fallback;
-#endif
-}
 
 template <class T>
 __device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, int k) {
@@ -246,6 +236,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         if (ti >= n_tiles) break;
         step(tB, tA);
     }
+    // ---- column-per-lane slices: the short columns of simplex entries (sell.h) ----
+    sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, obj, ssq, fair);
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 2);

@@ -247,8 +247,14 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
 
     def info(self) -> dict:
         """Kernel-side layout facts (tiles, workgroups, LDS plan) for benchmarks and tests."""
-        names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns"]
+        names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns", "slices", "slice_columns", "slice_elements"]
         return {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
+
+    def costs_changed(self) -> None:
+        """Tell the kernel handle that the values of ``c`` were rewritten in place (same pattern): it refreshes what it
+        derived from them.  ``A`` must stay as it was when the objective was built."""
+        with torch.cuda.device(self.device):
+            _hip.check(self._lib.dl_matching_update_costs(self._handle, _hip.stream_ptr(self.device)))
 
     def profile(self, enable) -> None:
         """Bracket fused-pass launches with HIP events on the launch stream (measurement hook): True = every launch, an

@@ -145,6 +145,7 @@ class MatchingFairnessDualObjectiveFunction(BaseObjective):
         lam = dual_val.contiguous()
         d = lam[k] - lam[k + 1]
         torch.addcmul(self._c0, self._f, d, out=self._c_eff)
+        self.inner.costs_changed()  # the handle keeps derived copies of the costs (include/dualip_hip.h: dl_matching_update_costs)
         x = self.inner._primal_buffer() if x_out is None else x_out
         inner = self.inner.calculate_packed_ptr(_hip.ptr(lam), self.gamma, x)
         fx = torch.dot(self._f, x).to(torch.float64)

@@ -83,11 +83,19 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
                        int32_t n_proj, const int32_t* col_proj, dl_stream_t stream);
 int dl_matching_destroy(dl_matching* h);
 
+/* The caller rewrote the values of c in place (same pattern): refresh what the handle derived from them -- the transposed copy
+ * the column-per-lane slices read, and max |c| when a projection in use does not bound x itself.  A stays read-only (the
+ * fixed-point scale of the gradient is taken from it).  Use: re-solving with new costs on the same graph; the folded form of
+ * the fairness objective (dualip_amd/objectives/matching_fairness.py) calls it every iteration. */
+int dl_matching_update_costs(dl_matching* h, dl_stream_t stream);
+
 /* Size/introspection: what = 0 number of wave tiles, 1 workgroups used, 2 LDS bytes per workgroup,
  * 3 lambda staged in LDS (0/1), 4 gradient privatised in LDS (0/1), 5 bytes of owned device memory,
  * 6 number of single-column ("long") tiles, 7 row-index width in bytes, 8 tile layout (non-zeros per lane: 4 or 1),
  * 9 rows kept in LDS by the hot-rows plan (0 = plan not in use: all rows or none are), 10 share of the non-zeros in those rows x 1e6,
- * 11 single-column tiles long enough (> 1024 non-zeros) to be walked by a whole workgroup instead of one wavefront. */
+ * 11 single-column tiles long enough (> 1024 non-zeros) to be walked by a whole workgroup instead of one wavefront,
+ * 12 column-per-lane slices (64 short columns of a simplex entry each, sorted by length; the handle owns a transposed copy of
+ * their values and row indices), 13 columns in slices, 14 slice elements including padding. */
 int64_t dl_matching_info(const dl_matching* h, int what);
 
 /* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays
