@@ -17,6 +17,7 @@ DL_F32, DL_F64 = 0, 1
 DL_I32, DL_I64 = 0, 1
 PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLEX_EQ = range(6)
 LOG_COLS = 8
+PROJ_FLAG_BISECTION = 1
 
 _c_i64 = ctypes.c_int64
 _c_vp = ctypes.c_void_p
@@ -70,6 +71,11 @@ _SIGNATURES = {
     "dl_agd_read_log": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "dl_agd_read_max_step": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), _c_vp]),
     "dl_project_dense": (_c_int, [_c_i64, _c_i64, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_vp]),
+    "dl_csc_scale_rows": (_c_int, [_c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
+    "dl_csc_scale_cols": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
+    "dl_csc_elementwise": (_c_int, [_c_i64, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    "dl_csc_row_sums": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_int, _c_vp]),
+    "dl_csc_project_columns": (_c_int, [_c_i64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_int, _c_vp]),
     "dl_jacobi_precondition": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "dl_lp_create": (_c_int, [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int]),
     "dl_lp_destroy": (_c_int, [_c_vp]),

@@ -470,6 +470,67 @@ __global__ void project_dense_kernel(int64_t L, int64_t K, const T* __restrict__
     }
 }
 
+// The reference's OTHER simplex method (method="bisection_search", simplex.py:6-123), restated step by step -- it is not
+// the Euclidean projection in every case, and callers that select it get its behaviour, not a substitute:
+//   * "simplex" only: a column with sum(x) <= z + 1e-6 and every x >= -1e-6 is returned AS IS (small negatives included);
+//   * L > 1: if the two largest entries of x / z differ by more than 1, the result is z at the argmax, 0 elsewhere;
+//   * otherwise nu is bisected on [-1, 0] for sum(max(x - max(x / z) - nu, 0)) = 1 (the shift uses the maximum of the
+//     NORMALISED column, as the reference does) by 19 halvings, nu* = bracket midpoint,
+//     w = max(x - max(x / z) - nu*, 0) * z.
+template <class T>
+__global__ void project_dense_bisect_kernel(int64_t L, int64_t K, const T* __restrict__ in, T* __restrict__ out, int kind, T z) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const T tol = (T)1e-6;
+    if (kind == DL_PROJ_SIMPLEX) {
+        T sum = (T)0;
+        bool nonneg = true;
+        for (int64_t i = 0; i < L; ++i) {
+            const T x = in[i * K + k];
+            sum = (T)(sum + x);
+            nonneg = nonneg && x >= -tol;
+        }
+        if (sum <= (T)(z + tol) && nonneg) {
+            for (int64_t i = 0; i < L; ++i) out[i * K + k] = in[i * K + k];
+            return;
+        }
+    }
+    T m1 = (T)(-INFINITY), m2 = (T)(-INFINITY);  // two largest entries of x / z
+    int64_t arg = 0;
+    for (int64_t i = 0; i < L; ++i) {
+        const T xn = (T)(in[i * K + k] / z);
+        if (xn > m1) {
+            m2 = m1;
+            m1 = xn;
+            arg = i;
+        } else if (xn > m2) {
+            m2 = xn;
+        }
+    }
+    if (L > 1 && (T)(m1 - m2) > (T)1) {
+        for (int64_t i = 0; i < L; ++i) out[i * K + k] = i == arg ? z : (T)0;
+        return;
+    }
+    // 19 halvings: the reference stops the whole batch when consecutive midpoints differ by less than 1e-6, i.e. at the start of
+    // its 20th pass (brackets are 2^-k wide for every column, so that test is the same for all of them)
+    T lo = (T)(-1), hi = (T)0;
+    for (int it = 0; it < 19; ++it) {
+        const T mid = (T)((T)(lo + hi) / (T)2);
+        T S = (T)0;
+        for (int64_t i = 0; i < L; ++i) {
+            const T d = (T)((T)(in[i * K + k] - m1) - mid);
+            S = (T)(S + (d > (T)0 ? d : (T)0));
+        }
+        if (S > (T)1) lo = mid;
+        else hi = mid;
+    }
+    const T nu = (T)((T)(lo + hi) / (T)2);
+    for (int64_t i = 0; i < L; ++i) {
+        const T d = (T)((T)(in[i * K + k] - m1) - nu);
+        out[i * K + k] = (T)((d > (T)0 ? d : (T)0) * z);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Jacobi row scaling (preprocessing/precondition.py:8-28, sparse_utils.py:429-450)
 // ---------------------------------------------------------------------------------------------------------
@@ -622,6 +683,12 @@ int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, vo
     if (K <= 0 || L <= 0) return 0;
     const int threads = 256;
     const int blocks = (int)((K + threads - 1) / threads);
+    if ((p->flags & DL_PROJ_FLAG_BISECTION) && (p->kind == DL_PROJ_SIMPLEX || p->kind == DL_PROJ_SIMPLEX_EQ)) {
+        if (val_dtype == DL_F32) hipLaunchKernelGGL(project_dense_bisect_kernel<float>, dim3(blocks), dim3(threads), 0, st, L, K, (const float*)in, (float*)out, p->kind, (float)p->p0);
+        else hipLaunchKernelGGL(project_dense_bisect_kernel<double>, dim3(blocks), dim3(threads), 0, st, L, K, (const double*)in, (double*)out, p->kind, p->p0);
+        DL_HIP(hipGetLastError());
+        return 0;
+    }
     if (val_dtype == DL_F32)
         hipLaunchKernelGGL(project_dense_kernel<float>, dim3(blocks), dim3(threads), 0, st, L, K, (const float*)in, (float*)out, p->kind, (float)p->p0,
                            (float)p->p1, (float)(p->p0 + 1e-6));

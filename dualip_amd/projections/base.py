@@ -52,7 +52,7 @@ def _apply_dense(op: "ProjectionOperator", x: torch.Tensor, force_2d: bool = Fal
         raise ValueError("projection operators take a vector [L] or a block [L, K] with one vector per column")
     src = x2.contiguous()
     out = torch.empty_like(src)
-    desc = op.descriptor()
+    desc = op.dense_descriptor() if hasattr(op, "dense_descriptor") else op.descriptor()
     with torch.cuda.device(x.device):
         rc = lib.dl_project_dense(
             src.shape[0], src.shape[1], _hip.dtype_code(src.dtype), _hip.ptr(src), _hip.ptr(out), desc, _hip.stream_ptr(x.device)

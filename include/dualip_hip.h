@@ -53,10 +53,15 @@ enum {
 /* One ProjectionEntry's operator (src/dualip/projections/base.py:8-12) without its index list. */
 typedef struct {
     int32_t kind;   /* DL_PROJ_* */
-    int32_t flags;  /* reserved, 0 */
+    int32_t flags;  /* DL_PROJ_FLAG_*; 0 for the matching handle */
     double p0;      /* box: lower | cone: the bound | simplex: z */
     double p1;      /* box: upper */
 } dl_proj_desc;
+
+/* dl_project_dense only: the reference's method="bisection_search" for the simplex kinds (simplex.py:6-123: nu bisected to
+ * 1e-6 after its feasibility and top-2 shortcuts) instead of the exact threshold.  A matching handle rejects it: inside the
+ * objective such entries take the dense-block route of user-defined operators (objectives/matching.py:_CustomBlocks). */
+enum { DL_PROJ_FLAG_BISECTION = 1 };
 
 typedef struct dl_matching dl_matching; /* opaque: one matching objective (A, c) on one device */
 typedef struct dl_agd dl_agd;           /* opaque: device-resident state of one maximize() run */
@@ -253,6 +258,28 @@ int dl_agd_read_max_step(dl_agd* s, double* out_host, dl_stream_t stream);
  * (src/dualip/projections/base.py:15-36; box.py, cone.py, simplex.py).  out may alias in. */
 int dl_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* proj_host,
                      dl_stream_t stream);
+
+/* The stand-alone CSC primitives of the reference (src/dualip/utils/sparse_utils.py).  Inside a solve their work is fused into
+ * dl_matching_calculate; these serve callers that use them on their own.  Value arrays follow the CSC order of the pattern
+ * arrays given; out may alias in.
+ *   dl_csc_scale_rows      left_multiply_sparse  (:54-85):   out[k] = in[k] * v[row_k]
+ *   dl_csc_scale_cols      right_multiply_sparse (:88-130):  out[k] = in[k] * v[col_k]
+ *   dl_csc_elementwise     elementwise_csc       (:26-51):   out[k] = a[k] op b[k], op = DL_OP_*
+ *   dl_csc_row_sums        row_sums_csc          (:223-243): out[i] = sum of the values stored in row i (double accumulation;
+ *                          synchronises the stream)
+ *   dl_csc_project_columns apply_F_to_columns    (:133-220) for an operator with a kernel form: every selected column
+ *                          (cols: int64[n_sel] device, NULL = columns 0 .. n_sel-1) is replaced by its projection; other columns'
+ *                          entries of vals_out are not touched. */
+enum { DL_OP_ADD = 0, DL_OP_SUB = 1, DL_OP_MUL = 2, DL_OP_DIV = 3 };
+int dl_csc_scale_rows(int64_t nnz, const void* rowidx, int idx_dtype, const void* vals_in, const void* v, void* vals_out, int val_dtype,
+                      dl_stream_t stream);
+int dl_csc_scale_cols(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const void* vals_in, const void* v, void* vals_out,
+                      int val_dtype, dl_stream_t stream);
+int dl_csc_elementwise(int64_t nnz, const void* a, const void* b, void* out, int op, int val_dtype, dl_stream_t stream);
+int dl_csc_row_sums(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, const void* vals, void* out, int val_dtype,
+                    dl_stream_t stream);
+int dl_csc_project_columns(int64_t n_sel, const int64_t* cols, const void* colptr, int idx_dtype, const void* vals_in, void* vals_out,
+                           const dl_proj_desc* proj_host, int val_dtype, dl_stream_t stream);
 
 /* jacobi_precondition (src/dualip/preprocessing/precondition.py:8-28): row_norms_out[m] = ||A_i||_2,
  * then a[k] *= 1/row_norms[row_k] and b *= 1/row_norms in place.  rowidx in idx_dtype. */

@@ -191,12 +191,11 @@ def test_projection_operators_match_reference_golden():
                 got = y.cpu().numpy()
                 tol = 1e-12 if dn == "f64" else 2e-6
                 if "bisect" in on:
-                    # the reference's bisection variant is accurate to its own 1e-6 search tolerance, and for columns
-                    # that are infeasible only through negative entries it lands on sum == z instead of the Euclidean
-                    # projection (simplex.py:42-48 skips the clamp): compare where the reference's two methods agree.
-                    agree = np.all(np.abs(want - z[f"out|{bn}|simplex_z1|{dn}"]) < 1e-5, axis=0)
-                    assert agree.sum() > 0 or bn == "neg"
-                    got, want, tol = got[:, agree], want[:, agree], 1e-5
+                    # the reference's bisection variant is its own map (feasible columns returned unclamped, nu bisected to
+                    # ~2e-6): restated as a kernel of its own and compared on EVERY column.  A halving decided by a sum within
+                    # rounding of 1 may fall the other way (different summation order): the result then moves by less than
+                    # the final bracket.
+                    tol = 1e-9 if dn == "f64" else 5e-6
                 assert np.allclose(got, want, rtol=0, atol=tol), (bn, on, dn, np.abs(got - want).max())
     # reference tests/projections/test_simplex.py:270-284 (exact expected vector) and a 1-D input
     x = torch.tensor([[-0.0133, -0.0133, 0.0006, -0.0133, -0.0133], [0.0006, 0.0007, -0.0133, 0.0006, 0.0009]], device=DEV)

@@ -163,3 +163,30 @@ def test_cost_update_refreshes_the_slices():
     p2 = dict(p, c=p["c"] * 1.7)
     _, _, _, xo = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], p["a"], p2["c"], lam.cpu().numpy(), 0.05, [("simplex", {"z": 1.0})])
     assert relerr(f.calculate(lam, 0.05, save_primal=True).primal_var.cpu().numpy(), xo) < 1e-9
+
+
+def test_bisection_entries_take_the_dense_block_route():
+    """method="bisection_search" inside a matching objective: not substituted by the exact projection -- its columns go through
+    the operator itself (dense blocks), so x equals what the reference's operator returns for them."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map, project
+
+    p = _ragged(23, n=800, m=60, lens=np.random.default_rng(1).integers(1, 9, 800))
+    n, m = p["n"], p["m"]
+    pm = create_projection_map("simplex", {"z": 1.0, "method": "bisection_search"}, n)
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, DEV), 0.05, batching=False)
+    assert f._custom is not None and f.info()["slices"] == 0
+    lam = torch.full((m,), 0.02, dtype=torch.float64, device=DEV)
+    x = f.calculate(lam, 0.05, save_primal=True).primal_var.cpu().numpy()
+    # the same columns as one zero-padded block through the operator
+    lens = np.diff(p["colptr"])
+    L = int(lens.max())
+    v = p["a"] * (-1.0 / 0.05 * 0.02) + (-1.0 / 0.05) * p["c"]
+    block = np.zeros((L, n))
+    cols = np.repeat(np.arange(n), lens)
+    offs = np.arange(len(v)) - np.repeat(p["colptr"][:-1], lens)
+    block[offs, cols] = v
+    want = project("simplex", z=1.0, method="bisection_search")(torch.from_numpy(block).to(DEV)).cpu().numpy()[offs, cols]
+    assert relerr(x, want) < 1e-12
+    exact = project("simplex", z=1.0)(torch.from_numpy(block).to(DEV)).cpu().numpy()[offs, cols]
+    assert np.abs(want - exact).max() > 1e-8  # the two methods do differ (bracket width) -- so the route matters
