@@ -134,7 +134,8 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
 
     _dualip_native = True
 
-    def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True, simplex_eq_padding: str = "exact"):
+    def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True, simplex_eq_padding: str = "exact",
+                 use_jacobi_precondition: bool = False, row_norms: Optional[torch.Tensor] = None):
         A, c = matching_input_args.A, matching_input_args.c
         if A.layout != torch.sparse_csc or c.layout != torch.sparse_csc:
             raise ValueError("Both A and c must be CSC-format sparse tensors")
@@ -142,9 +143,29 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
             raise ValueError("A and c must share the same sparsity pattern")
         _hip.require_device(A.values(), "A")
         _hip.require_device(c.values(), "c")
+        b_in = matching_input_args.b_vec
+        # Jacobi pre-conditioning (run_solver.py:136-144 expects the objective to carry ``use_jacobi_precondition`` and
+        # ``invert_jacobi_precondition``; preprocessing/precondition.py:8-28): rows of A and b scaled by 1 / ||A_i||_2 -- on
+        # COPIES, the caller's tensors stay as they are.  ``row_norms`` given = the norms of the WHOLE matrix when this
+        # objective holds only a column shard of it (the distributed objective all-reduces the squares).
+        self.use_jacobi_precondition = bool(use_jacobi_precondition)
+        self.row_norms = None
+        if self.use_jacobi_precondition:
+            from dualip_amd.preprocessing.precondition import jacobi_precondition
+            from dualip_amd.utils.sparse_utils import left_multiply_sparse
+
+            A = torch.sparse_csc_tensor(A.ccol_indices(), A.row_indices(), A.values().clone(), size=A.shape)
+            if row_norms is None:
+                b_scaled = b_in.clone() if b_in is not None else torch.ones(A.shape[0], dtype=A.values().dtype, device=A.values().device)
+                self.row_norms = jacobi_precondition(A, b_scaled)
+                b_in = b_scaled if b_in is not None else None
+            else:
+                self.row_norms = row_norms.to(device=A.values().device, dtype=A.values().dtype)
+                left_multiply_sparse(1 / self.row_norms, A, A)
+                b_in = b_in / self.row_norms if b_in is not None else None
         self.A, self.c = A, c
         self.gamma = gamma
-        self.b_vec = matching_input_args.b_vec
+        self.b_vec = b_in
         self.projection_map = matching_input_args.projection_map
         self.is_distributed = self.b_vec is None
         self.equality_mask = matching_input_args.equality_mask
@@ -249,6 +270,13 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         """Kernel-side layout facts (tiles, workgroups, LDS plan) for benchmarks and tests."""
         names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns", "slices", "slice_columns", "slice_elements"]
         return {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
+
+    def invert_jacobi_precondition(self, dual_val: torch.Tensor, dual_grad: torch.Tensor):
+        """Duals / gradient of the ORIGINAL rows from those of the row-normalised problem (run_solver.py:136-144):
+        lambda = lambda~ / ||A_i||,  (A x - b) = g~ * ||A_i||."""
+        if self.row_norms is None:
+            return dual_val, dual_grad
+        return dual_val / self.row_norms, dual_grad * self.row_norms
 
     def costs_changed(self) -> None:
         """Tell the kernel handle that the values of ``c`` were rewritten in place (same pattern): it refreshes what it
@@ -382,8 +410,11 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
         local_objective=None,
         process_group=None,
         comm_backend: Optional[str] = None,
+        use_jacobi_precondition: bool = False,
     ):
         self.gamma = gamma
+        self.use_jacobi_precondition = bool(use_jacobi_precondition) and local_objective is None
+        self.row_norms = None
         self.host_device = host_device
         blocks_args = list(local_matching_input_args) if isinstance(local_matching_input_args, (list, tuple)) else [local_matching_input_args]
         first = blocks_args[0]
@@ -396,8 +427,17 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
             for args in blocks_args:
                 if args.b_vec is not None:
                     raise ValueError("local partitions must be built with b_vec=None (b_vec is shared by all ranks)")
-            local_objective = MatchingSolverDualObjectiveFunction(first, gamma, batching)
-            self.more_blocks = [MatchingSolverDualObjectiveFunction(args, gamma, batching) for args in blocks_args[1:]]
+            kw = {}
+            if self.use_jacobi_precondition:  # ||A_i||^2 summed over every rank's (and block's) columns
+                from dualip_amd.utils.sparse_utils import row_norms_csc
+
+                sq = sum(row_norms_csc(a.A).double() ** 2 for a in blocks_args)
+                if dist.is_available() and dist.is_initialized():
+                    dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=process_group)
+                self.row_norms = sq.sqrt().to(first.A.values().dtype)
+                kw = dict(use_jacobi_precondition=True, row_norms=self.row_norms)
+            local_objective = MatchingSolverDualObjectiveFunction(first, gamma, batching, **kw)
+            self.more_blocks = [MatchingSolverDualObjectiveFunction(args, gamma, batching, **kw) for args in blocks_args[1:]]
             if len(self.more_blocks) > 3:
                 raise ValueError("a shard can be split into at most 4 blocks")
         self.local_objective = local_objective
@@ -407,6 +447,13 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
         self.m = local_objective.m
         # every rank finishes the objective on its own device (the reference moves b to host_device = cuda:0)
         self.b_vec = b_vec.to(device=self.device, dtype=self.dtype)
+        if self.row_norms is not None:
+            self.b_vec = self.b_vec / self.row_norms
+
+    def invert_jacobi_precondition(self, dual_val: torch.Tensor, dual_grad: torch.Tensor):
+        if self.row_norms is None:
+            return dual_val, dual_grad
+        return dual_val / self.row_norms, dual_grad * self.row_norms
 
     # ---- the exchange ---------------------------------------------------------------------------------------
     def communicator(self):

@@ -23,7 +23,7 @@ from dualip_amd.objectives.matching import (
 from dualip_amd.optimizers.agd import AcceleratedGradientDescent
 from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs, SolverResult
 from dualip_amd.utils.mlflow_utils import MLflowConfig, log_hyperparameters, mlflow_run_context
-from dualip_amd.utils.dist_utils import global_to_local_projection_map, split_tensors_to_devices
+from dualip_amd.utils.dist_utils import balanced_split_sizes, global_to_local_projection_map
 
 
 def transfer_tensors_to_device(input_args: BaseInputArgs, device: str):
@@ -32,11 +32,22 @@ def transfer_tensors_to_device(input_args: BaseInputArgs, device: str):
 
 
 def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device) -> MatchingInputArgs:
-    a_blocks, c_blocks, index_map = split_tensors_to_devices(input_args.A, input_args.c, [input_args.A.device] * world)
+    """This rank's contiguous column block of the global problem (sizes as dist_utils.split_tensors_to_devices: n // W, +1 for
+    the first n % W ranks).  Only this block is sliced and moved -- cutting all W blocks on every rank would hold the whole
+    problem twice per rank before the solve starts."""
+    A, c = input_args.A, input_args.c
+    n = int(A.size(1))
+    sizes = balanced_split_sizes(n, world)
+    lo = sum(sizes[:rank])
+    hi = lo + sizes[rank]
+    colptr = A.ccol_indices()
+    k0, k1 = (int(v) for v in colptr[torch.tensor([lo, hi], device=colptr.device)].tolist())
+    sub_ptr = (colptr[lo : hi + 1] - k0).to(device)
+    rows = A.row_indices()[k0:k1].to(device)
     return MatchingInputArgs(
-        A=a_blocks[rank].to(device),
-        c=c_blocks[rank].to(device),
-        projection_map=global_to_local_projection_map(input_args.projection_map, index_map[rank]),
+        A=torch.sparse_csc_tensor(sub_ptr, rows, A.values()[k0:k1].to(device), size=(A.size(0), hi - lo)),
+        c=torch.sparse_csc_tensor(sub_ptr, rows, c.values()[k0:k1].to(device), size=(A.size(0), hi - lo)),
+        projection_map=global_to_local_projection_map(input_args.projection_map, range(lo, hi)),
         b_vec=None,
         equality_mask=input_args.equality_mask,
     )
@@ -45,8 +56,9 @@ def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device) -
 def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_args: ComputeArgs, objective_args: ObjectiveArgs):
     kind = objective_args.objective_type
     if kind == "matching":
+        jac = bool(objective_args.use_jacobi_precondition)
         if compute_args.compute_device_num == 1:
-            return MatchingSolverDualObjectiveFunction(matching_input_args=input_args, gamma=solver_args.gamma)
+            return MatchingSolverDualObjectiveFunction(matching_input_args=input_args, gamma=solver_args.gamma, use_jacobi_precondition=jac)
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("compute_device_num > 1 needs an initialised torch.distributed group (one process per GPU)")
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -55,7 +67,7 @@ def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_
         device = torch.device("cuda", torch.cuda.current_device())
         local = _local_shard(input_args, rank, world, device)
         return MatchingSolverDualObjectiveFunctionDistributed(
-            local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device
+            local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device, use_jacobi_precondition=jac
         )
     if kind == "miplib2017":
         kwargs = dict(objective_args.objective_kwargs or {})
