@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-cols", type=int, default=4_000_000)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
+    ap.add_argument("--cpu-ref-cols", type=int, default=10_000_000, help="entities of the sample the reference-path CPU leg runs on")
+    ap.add_argument("--cpu-ref-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-late", action="store_true", help="skip the whole-solve leg (the reference's 1000-iteration configuration: aux.whole_solve / aux.late)")
     ap.add_argument("--no-verify", action="store_true", help="skip the correctness leg at the benchmark size (aux.verified)")
@@ -104,16 +106,12 @@ def copy_ceiling_gbps(device, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def cpu_baseline(args, inp, pm_local, total_nnz):
-    """Oracle (kind 'port') on a bounded sample of the local columns, all host cores.  The sample takes an equal share of
-    columns from the head of EVERY projection entry (so a mixed map is sampled with its operator mix)."""
-    import oracle
-    from oracle import agd_oracle
-
+def _cpu_sample(args, inp, pm_local, n_cols):
+    """The first n_cols / #entries columns of EVERY projection entry, on the host (so a mixed map is sampled with its mix)."""
     A = inp.A
     n_local = A.shape[1]
     entries = list(pm_local.items())
-    per = max(1, min(args.cpu_sample_cols, n_local) // max(len(entries), 1))
+    per = max(1, min(n_cols, n_local) // max(len(entries), 1))
     colptr_dev = A.ccol_indices()
     parts, projs, col_proj_parts = [], [], []
     for q, (_, e) in enumerate(entries):
@@ -137,35 +135,74 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
         rowidx_l.append(A.row_indices()[k0:k1p].cpu().numpy().astype(np.int64))
         a_l.append(A.values()[k0:k1p].cpu().numpy())
         c_l.append(inp.c.values()[k0:k1p].cpu().numpy())
-    k1 = off
-    rowidx, a, c = np.concatenate(rowidx_l), np.concatenate(a_l), np.concatenate(c_l)
-    col_proj = np.concatenate(col_proj_parts)
-    b = inp.b_vec.cpu().numpy()
-    m = A.shape[0]
+    return dict(ncols=ncols, nnz=off, per=per, colptr=colptr, rowidx=np.concatenate(rowidx_l), a=np.concatenate(a_l), c=np.concatenate(c_l),
+                col_proj=np.concatenate(col_proj_parts), projs=projs, b=inp.b_vec.cpu().numpy(), m=A.shape[0], n_entries=len(entries))
+
+
+def cpu_baseline(args, inp, pm_local, total_nnz):
+    """Two CPU legs on bounded samples of the same problem, all host cores, outside every timed region (reported baseline only):
+      value   -- the reference's OP SEQUENCE restated in torch-on-CPU (oracle/torch_path.py: padded dense blocks per nnz bucket,
+                 sort + cumsum simplex -- what device="cpu" executes in the reference; pinned to its goldens), >= 10M entities;
+      c_port  -- the C oracle (oracle/matching_oracle.c, OpenMP), a per-column loop: much faster than the reference's path.
+    Both are scaled by nnz to whole-problem iterations/s and labelled extrapolated."""
+    import oracle
+    from oracle import agd_oracle
+
     npdt = np.float32 if args.dtype == "f32" else np.float64
     threads = oracle.max_threads()
+    out = {"unit": "iterations/s", "cores": threads, "kind": "port", "extrapolated": True}
+    # ---- C port -------------------------------------------------------------------------------------------------
+    smp = _cpu_sample(args, inp, pm_local, args.cpu_sample_cols)
+    m = smp["m"]
     lam = np.zeros(m, dtype=npdt)
     sizer = agd_oracle.StepSizer(npdt)
     times = []
     for it in range(args.cpu_sample_iters + 1):
         t0 = time.perf_counter()
-        ax, obj0, ssq, _ = oracle.matching_calculate(m, ncols, colptr, rowidx, a, c, lam, args.gamma, projs, col_proj=col_proj, dtype=npdt, want_x=False, threads=threads)
-        grad, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, b, args.gamma, npdt)
+        ax, obj0, ssq, _ = oracle.matching_calculate(m, smp["ncols"], smp["colptr"], smp["rowidx"], smp["a"], smp["c"], lam, args.gamma, smp["projs"], col_proj=smp["col_proj"],
+                                                     dtype=npdt, want_x=False, threads=threads)
+        grad, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, smp["b"], args.gamma, npdt)
         step = sizer(grad, lam, 1e-3, 1e-1)
         lam = np.maximum(lam + grad * npdt(step), 0).astype(npdt)
         times.append(time.perf_counter() - t0)
     per_iter = float(np.mean(times[1:]))
-    sample_its = 1.0 / per_iter
-    return {
-        "value": sample_its * (k1 / max(total_nnz, 1)),
-        "unit": "iterations/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"oracle/ (C, OpenMP {threads} threads) on {ncols} entities of the same problem ({k1} non-zeros; the first {per} of each of the "
-        f"{len(entries)} projection blocks), {args.cpu_sample_iters} iterations at {per_iter * 1e3:.1f} ms = {args.cpu_sample_iters * per_iter * threads:.0f} core-seconds; "
-        f"value = sample it/s x sample_nnz/total_nnz",
+    out["c_port"] = {
+        "value": (1.0 / per_iter) * (smp["nnz"] / max(total_nnz, 1)),
+        "sample": f"oracle/matching_oracle.c (OpenMP {threads} threads) on {smp['ncols']} entities ({smp['nnz']} non-zeros; the first {smp['per']} of each of the "
+        f"{smp['n_entries']} projection blocks), {args.cpu_sample_iters} iterations at {per_iter * 1e3:.1f} ms = {args.cpu_sample_iters * per_iter * threads:.0f} core-seconds",
         "sample_ms_per_iteration": per_iter * 1e3,
     }
+    # ---- the reference's op sequence (torch on CPU) --------------------------------------------------------------------
+    import torch as _t
+
+    from oracle.torch_path import ReferencePathObjective
+
+    if args.cpu_ref_cols > args.cpu_sample_cols:
+        del smp
+        smp = _cpu_sample(args, inp, pm_local, args.cpu_ref_cols)
+    old_threads = _t.get_num_threads()
+    _t.set_num_threads(os.cpu_count() or old_threads)
+    try:
+        bounds = np.cumsum([0] + [int((smp["col_proj"] == q).sum()) for q in range(smp["n_entries"])])
+        entries = [(pt, pp, np.arange(bounds[q], bounds[q + 1])) for q, (pt, pp) in enumerate(smp["projs"])]
+        ref = ReferencePathObjective(m, smp["ncols"], smp["colptr"], smp["rowidx"], smp["a"], smp["c"], entries, args.gamma, dtype=_t.float32 if args.dtype == "f32" else _t.float64)
+        lam_t = _t.zeros(m, dtype=_t.float32 if args.dtype == "f32" else _t.float64)
+        b_t = _t.as_tensor(smp["b"]).to(lam_t.dtype)
+        times = []
+        for it in range(args.cpu_ref_iters + 1):
+            t0 = time.perf_counter()
+            ax, obj0, ssq, _ = ref.calculate(lam_t)
+            lam_t = (lam_t + (ax - b_t) * 1e-3).clamp(min=0)  # (a plain projected ascent step: the m-sized side is negligible here)
+            times.append(time.perf_counter() - t0)
+        per_ref = float(np.mean(times[1:]))
+        out["value"] = (1.0 / per_ref) * (smp["nnz"] / max(total_nnz, 1))
+        out["sample"] = (f"oracle/torch_path.py -- the reference's calculate() op sequence in torch on CPU, {_t.get_num_threads()} threads -- on {smp['ncols']} entities "
+                         f"({smp['nnz']} non-zeros; the first {smp['per']} of each of the {smp['n_entries']} projection blocks), {args.cpu_ref_iters} iterations at {per_ref * 1e3:.0f} ms; "
+                         f"value = sample it/s x sample_nnz / total_nnz (extrapolated to the whole problem)")
+        out["sample_ms_per_iteration"] = per_ref * 1e3
+    finally:
+        _t.set_num_threads(old_threads)
+    return out
 
 
 def timed_window(run, local, comm, n_iters, fence, elapsed_max, stride=1):
