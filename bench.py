@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     ap.add_argument("--cpu-ref-cols", type=int, default=10_000_000, help="entities of the sample the reference-path CPU leg runs on")
     ap.add_argument("--cpu-ref-iters", type=int, default=3)
+    ap.add_argument("--cpu-ref-threads", type=int, default=32, help="torch threads of the reference-path CPU leg (its measured optimum on the GPU box's host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-late", action="store_true", help="skip the whole-solve leg (the reference's 1000-iteration configuration: aux.whole_solve / aux.late)")
     ap.add_argument("--no-verify", action="store_true", help="skip the correctness leg at the benchmark size (aux.verified)")
@@ -180,8 +181,12 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
     if args.cpu_ref_cols > args.cpu_sample_cols:
         del smp
         smp = _cpu_sample(args, inp, pm_local, args.cpu_ref_cols)
+    # thread count: measured on the 256-thread host of the GPU box (tools/cpu_path_threads.py, 2M entities): 8 threads 469 ms,
+    # 32 -> 373 ms, 64 -> 749 ms, 128 -> 1592 ms, 256 -> 41 s per iteration -- the op sequence is made of many small
+    # memory-bound tensor ops that stop scaling early.  The leg runs at its best setting and says so in `cores`.
     old_threads = _t.get_num_threads()
-    _t.set_num_threads(os.cpu_count() or old_threads)
+    ref_threads = max(1, min(args.cpu_ref_threads, os.cpu_count() or 1))
+    _t.set_num_threads(ref_threads)
     try:
         bounds = np.cumsum([0] + [int((smp["col_proj"] == q).sum()) for q in range(smp["n_entries"])])
         entries = [(pt, pp, np.arange(bounds[q], bounds[q + 1])) for q, (pt, pp) in enumerate(smp["projs"])]
@@ -200,6 +205,8 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
                          f"({smp['nnz']} non-zeros; the first {smp['per']} of each of the {smp['n_entries']} projection blocks), {args.cpu_ref_iters} iterations at {per_ref * 1e3:.0f} ms; "
                          f"value = sample it/s x sample_nnz / total_nnz (extrapolated to the whole problem)")
         out["sample_ms_per_iteration"] = per_ref * 1e3
+        out["cores"] = ref_threads
+        out["c_port"]["cores"] = threads
     finally:
         _t.set_num_threads(old_threads)
     return out
