@@ -10,6 +10,7 @@
 #include <vector>
 
 #include <atomic>
+#include <chrono>
 
 #include "comm.h"
 
@@ -51,6 +52,8 @@ int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_
                  std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, hipStream_t st);  // sell_build.hip
 int sell_finish(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const std::vector<uint8_t>& pid_sell, const std::vector<uint32_t>& desc,
                 hipStream_t st);
+int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell,
+                uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st);  // pack_build.hip
 int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
 constexpr int kSellMaxLen = 24;  // sell.h: kSellMaxH
@@ -372,32 +375,17 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         }                                           \
     } while (0)
 
-    // ---- column pointers and per-column projection ids to the host (one-off) ----
-    std::vector<int64_t> colptr_h((size_t)n + 1);
-    if (idx_dtype == DL_I64) {
-        CKH(hipMemcpyAsync(colptr_h.data(), colptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
-        CKH(hipStreamSynchronize(st));
-    } else {
-        std::vector<int32_t> tmp((size_t)n + 1);
-        CKH(hipMemcpyAsync(tmp.data(), colptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
-        CKH(hipStreamSynchronize(st));
-        for (size_t i = 0; i <= (size_t)n; ++i) colptr_h[i] = tmp[i];
-    }
-    if (colptr_h[0] != 0 || colptr_h[(size_t)n] != nnz) {
-        matching_free(h);
-        return fail(DL_E_LAYOUT, "ccol_indices[0] must be 0 and ccol_indices[n] must equal nnz");
-    }
-    std::vector<int32_t> col_proj_h;
-    if (col_proj) {
-        col_proj_h.resize((size_t)n);
-        CKH(hipMemcpyAsync(col_proj_h.data(), col_proj, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-        CKH(hipStreamSynchronize(st));
-    }
-
-    // ---- tiles ----
-    std::vector<TileDesc> tiles;
-    std::vector<uint32_t> words4, tile_pid4;
-    std::vector<uint64_t> prefix;
+    // developer aid: DUALIP_HIP_TIMING=1 prints the wall time of every set-up phase to stderr
+    const bool timing = getenv("DUALIP_HIP_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_phase = now();
+    auto phase = [&](const char* name) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now();
+        fprintf(stderr, "[dl_matching_create] %-28s %.1f ms\n", name, (t - t_phase) * 1e3);
+        t_phase = t;
+    };
     // layout 4 (16-byte loads) needs 16-byte aligned value arrays and at least one full quad; DUALIP_HIP_LAYOUT=1 forces layout 1
     const char* lay_env = getenv("DUALIP_HIP_LAYOUT");
     const bool want4 = !(lay_env && lay_env[0] == '1');
@@ -413,7 +401,80 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (const char* ms = getenv("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
         if (!(se && se[0] == '0')) CK(sell_prepare(h, colptr, idx_dtype, col_proj, projs_host, n_proj, min_share, pid_sell, sell_desc_h, st));
     }
-    if (h->layout == 4) {
+    phase("slice plan");
+    // Window tiles are packed on the device (pack_build.hip) unless the map has BOTH instruction-bound window tiles (a simplex
+    // entry that is not sliced) and memory-bound ones -- those want the host's interleaved schedule (schedule_tiles4) -- or
+    // DUALIP_HIP_HOST_PACK=1 asks for the host path (kept as the independent implementation for cross-checks).
+    bool dev_pack = h->layout == 4 && !getenv("DUALIP_HIP_HOST_PACK") && n < (1ll << 31);
+    for (int32_t q = 0; q < n_proj && dev_pack; ++q) {
+        const int k = projs_host[q].kind;
+        if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q]) && n_proj > 1) dev_pack = false;
+    }
+    // ---- column pointers and per-column projection ids to the host (one-off; host packing only) ----
+    std::vector<int64_t> colptr_h;
+    std::vector<int32_t> col_proj_h;
+    if (!dev_pack) {
+        colptr_h.resize((size_t)n + 1);
+        if (idx_dtype == DL_I64) {
+            CKH(hipMemcpyAsync(colptr_h.data(), colptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
+            CKH(hipStreamSynchronize(st));
+        } else {
+            std::vector<int32_t> tmp((size_t)n + 1);
+            CKH(hipMemcpyAsync(tmp.data(), colptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
+            CKH(hipStreamSynchronize(st));
+            for (size_t i = 0; i <= (size_t)n; ++i) colptr_h[i] = tmp[i];
+        }
+        if (colptr_h[0] != 0 || colptr_h[(size_t)n] != nnz) {
+            matching_free(h);
+            return fail(DL_E_LAYOUT, "ccol_indices[0] must be 0 and ccol_indices[n] must equal nnz");
+        }
+        if (col_proj) {
+            col_proj_h.resize((size_t)n);
+            CKH(hipMemcpyAsync(col_proj_h.data(), col_proj, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+            CKH(hipStreamSynchronize(st));
+        }
+    } else {  // the two ends of the column pointers
+        int64_t ends[2] = {0, 0};
+        const size_t isz = idx_dtype == DL_I64 ? 8 : 4;
+        int32_t e32[2] = {0, 0};
+        void* dst0 = idx_dtype == DL_I64 ? (void*)&ends[0] : (void*)&e32[0];
+        void* dst1 = idx_dtype == DL_I64 ? (void*)&ends[1] : (void*)&e32[1];
+        CKH(hipMemcpyAsync(dst0, colptr, isz, hipMemcpyDeviceToHost, st));
+        CKH(hipMemcpyAsync(dst1, (const char*)colptr + isz * (size_t)n, isz, hipMemcpyDeviceToHost, st));
+        CKH(hipStreamSynchronize(st));
+        if (idx_dtype != DL_I64) {
+            ends[0] = e32[0];
+            ends[1] = e32[1];
+        }
+        if (ends[0] != 0 || ends[1] != nnz) {
+            matching_free(h);
+            return fail(DL_E_LAYOUT, "ccol_indices[0] must be 0 and ccol_indices[n] must equal nnz");
+        }
+    }
+
+    phase("colptr / col_proj to host");
+    // ---- tiles ----
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> words4, tile_pid4;
+    std::vector<uint64_t> prefix;
+    uint32_t* win_dev = nullptr;  // device path: window descriptors in memory order
+    int64_t n_win_dev = 0;
+    std::vector<uint8_t> used_dev;
+    struct WinGuard {
+        uint32_t*& p;
+        ~WinGuard() {
+            if (p) (void)hipFree(p);
+        }
+    } win_guard{win_dev};
+    if (dev_pack) {
+        std::vector<uint32_t> long_list;
+        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, &win_dev, &n_win_dev, long_list, used_dev, st));
+        words4 = long_list;  // single-column tiles only; split / ordered below
+        for (size_t t = 0; t < long_list.size() / 12; ++t) tile_pid4.push_back(long_list[t * 12 + 10] == 0xFFFFFFFFu ? kNoProj : long_list[t * 12 + 10]);
+        h->n_long = (int64_t)(long_list.size() / 12);
+        h->n_tiles = n_win_dev + h->n_long;
+        prefix.assign(1, 0);
+    } else if (h->layout == 4) {
         CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell));
         h->n_tiles = (int64_t)(words4.size() / 12);
     } else {
@@ -425,6 +486,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         return fail(DL_E_ARG, "too many tiles");
     }
 
+    phase(dev_pack ? "window packing (device)" : "window packing (host)");
     // ---- workgroups: one per CU.  Layout 1: contiguous tile ranges of equal cost (wg_tile_begin); layout 4: descriptors in
     //      schedule order, dealt cyclically to the wavefronts (schedule_tiles4) ----
     hipDeviceProp_t prop;
@@ -476,9 +538,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         h->n_xlong = (int64_t)xlong_pid.size();
         long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
         long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
-        if (!getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
-        h->n_short = (int64_t)short_pid.size();
-        words4 = short_words;
+        if (!dev_pack && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
+        h->n_short = dev_pack ? n_win_dev : (int64_t)short_pid.size();
+        words4 = short_words;  // (device path: empty -- the window descriptors are already on the device)
         words4.resize(words4.size() + 12, 0u);
         words4.insert(words4.end(), long_words.begin(), long_words.end());
         tile_pid4 = short_pid;
@@ -488,7 +550,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     {
         const uint64_t total = prefix.back();
         size_t t = 0;
-        const size_t n_t = (size_t)h->n_tiles;
+        const size_t n_t = dev_pack ? 0 : (size_t)h->n_tiles;  // (the 256-wide layout deals tiles cyclically: the table is unused there)
         for (int w = 0; w <= h->n_wg; ++w) {
             const uint64_t target = h->n_wg ? (total * (uint64_t)w) / (uint64_t)h->n_wg : 0;
             while (t < n_t && prefix[t] < target) ++t;
@@ -497,6 +559,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (h->n_wg) wg_begin[(size_t)h->n_wg] = (uint32_t)n_t;
     }
 
+    phase("schedule (host)");
     // ---- LDS plan ----
     auto lds_need = [&](bool lam, bool grad) { return fused_lds_bytes(m, val_dtype, lam, grad); };
     const char* mode_env = getenv("DUALIP_HIP_LDS_MODE");  // "both" | "grad" | "none": force a smaller plan (testing)
@@ -548,7 +611,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const char* row_env = getenv("DUALIP_HIP_ROW32");
     if (row_env && row_env[0] == '1') h->row_bytes = 4;
     CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
-    const size_t tile_bytes = h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size();
+    const size_t win_bytes = dev_pack ? sizeof(uint32_t) * 12 * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
+    const size_t tile_bytes = win_bytes + (h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size());
     CK(owned_malloc(h, (void**)&h->tiles, tile_bytes));
     CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));
     CK(owned_malloc(h, (void**)&h->projs, sizeof(ProjDev) * (size_t)(n_proj > 0 ? n_proj : 1)));
@@ -568,8 +632,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
-    if (e == hipSuccess && tile_bytes > 0)
-        e = hipMemcpyAsync(h->tiles, h->layout == 4 ? (const void*)words4.data() : (const void*)tiles.data(), tile_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && win_bytes > 0) e = hipMemcpyAsync(h->tiles, win_dev, win_bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && tile_bytes > win_bytes)
+        e = hipMemcpyAsync((char*)h->tiles + win_bytes, h->layout == 4 ? (const void*)words4.data() : (const void*)tiles.data(), tile_bytes - win_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h->wg_tile_begin, wg_begin.data(), sizeof(uint32_t) * wg_begin.size(), hipMemcpyHostToDevice, st);
     std::vector<ProjDev> pd((size_t)(n_proj > 0 ? n_proj : 1));
     for (int32_t q = 0; q < n_proj; ++q) pd[(size_t)q] = ProjDev{projs_host[q].kind, 0, projs_host[q].p0, projs_host[q].p1};
@@ -646,7 +711,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         for (int64_t pnew = 0; pnew < h->m_hot; ++pnew) hot_nnz += row_count_h[(size_t)inv[(size_t)pnew]];
         h->hot_fraction = nnz > 0 ? (double)hot_nnz / (double)nnz : 1.0;
     }
+    phase("uploads, row re-encoding, maxima");
     if (h->n_sell > 0) CK(sell_finish(h, colptr, idx_dtype, col_proj, pid_sell, sell_desc_h, st));
+    phase("slice sort + transpose");
     // |x| bounds per projection kind: box -> max(|lower|, |upper|); simplex -> z (+ slack); cone / identity -> via |v| per launch
     bool used_none = false;
     std::vector<char> used((size_t)(n_proj > 0 ? n_proj : 1), 0);
@@ -661,6 +728,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     }
     for (size_t q = 0; q < pid_sell.size() && q < used.size(); ++q)
         if (pid_sell[q]) used[q] = 1;
+    for (size_t q = 0; q < used_dev.size(); ++q) {  // device-packed tiles
+        if (!used_dev[q]) continue;
+        if ((int32_t)q == n_proj) used_none = true;
+        else if (q < used.size()) used[q] = 1;
+    }
     h->has_unbounded = used_none;
     for (int32_t q = 0; q < n_proj; ++q) {
         if (!used[(size_t)q]) continue;

@@ -190,3 +190,30 @@ def test_bisection_entries_take_the_dense_block_route():
     assert relerr(x, want) < 1e-12
     exact = project("simplex", z=1.0)(torch.from_numpy(block).to(DEV)).cpu().numpy()[offs, cols]
     assert np.abs(want - exact).max() > 1e-8  # the two methods do differ (bracket width) -- so the route matters
+
+
+@pytest.mark.parametrize("kind", ["box", "mixed", "simplex"])
+def test_device_packed_windows_equal_host_packed(kind):
+    """Window tiles packed on the device (chunks of 8192 columns, one thread each) against the host's greedy packing of the same
+    columns: the exact integer gradient is bit-identical, the primal identical, the tile count within a chunk-boundary's worth."""
+    from dualip_amd.projections import create_projection_map
+
+    rng = np.random.default_rng(9)
+    n, m = 40_000, 500
+    lens = rng.poisson(9, n)
+    lens[rng.integers(0, n, 40)] = rng.integers(260, 400, 40)  # single-column tiles
+    lens[::333] = 0
+    p = _ragged(9, n=n, m=m, lens=lens)
+    if kind == "mixed":
+        pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(n // 2)), **create_projection_map("simplex", {"z": 1.0}, n, indices=range(n // 2, n))}
+    else:
+        pm = create_projection_map(kind, {"z": 1.0} if kind == "simplex" else {"lower": 0.0, "upper": 1.0}, n)
+    fd = _objective(p, "f64", pm, 0.05, DUALIP_HIP_SELL_MIN_SHARE=0.5)
+    fh = _objective(p, "f64", pm, 0.05, DUALIP_HIP_SELL_MIN_SHARE=0.5, DUALIP_HIP_HOST_PACK=1)
+    a, b = fd.info(), fh.info()
+    assert a["slices"] == b["slices"] and a["long_columns"] == b["long_columns"]
+    assert b["tiles"] <= a["tiles"] <= b["tiles"] + n // 8192 + 2
+    lam = torch.from_numpy(rng.uniform(0, 0.2, m)).to(DEV)
+    ra, rb = fd.calculate(lam, 0.05, save_primal=True), fh.calculate(lam, 0.05, save_primal=True)
+    assert torch.equal(ra.dual_gradient, rb.dual_gradient) and torch.equal(ra.primal_var, rb.primal_var)
+    assert abs(float(ra.dual_objective) - float(rb.dual_objective)) < 1e-9 * max(1.0, abs(float(rb.dual_objective)))
