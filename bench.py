@@ -461,7 +461,11 @@ def main():
     lay = local.info()
     # what the launch physically moves through HBM: the two value arrays, the re-encoded row indices, the 48-byte window
     # descriptors, and the per-workgroup gradient slabs it writes (lambda and the projection table are L2-served re-reads)
-    phys_bytes = nnz_first * (2 * vs + lay["row_index_bytes"]) + lay["tiles"] * (48 if lay["layout"] == 4 else 16) + lay["workgroups"] * (m * 8 + 16)
+    # -- plus, for columns held in column-per-lane slices, the padding of their transposed copy, 16 bytes per slice, one length
+    # byte per column
+    per_nnz = 2 * vs + lay["row_index_bytes"]
+    phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + lay["tiles"] * (48 if lay["layout"] == 4 else 16) \
+        + lay.get("slices", 0) * 16 + lay.get("slice_columns", 0) + lay["workgroups"] * (m * 8 + 16)
 
     def roof(kernel_ms, launches):
         avg_s = (kernel_ms / max(launches, 1)) * 1e-3

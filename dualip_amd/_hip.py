@@ -17,6 +17,7 @@ DL_F32, DL_F64 = 0, 1
 DL_I32, DL_I64 = 0, 1
 PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLEX_EQ = range(6)
 LOG_COLS = 8
+ABI_VERSION = 200  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
 PROJ_FLAG_BISECTION = 1
 
 _c_i64 = ctypes.c_int64
@@ -100,21 +101,35 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    stale = None
     try:
         path = _build.build()
     except Exception as exc:  # no silent fallback: the HIP path is the product
         if os.path.exists(_build.LIB_PATH):
-            path = _build.LIB_PATH  # stale but present (e.g. hipcc unavailable on this box): use the shipped binary
+            path, stale = _build.LIB_PATH, exc  # present but not rebuilt (e.g. hipcc unavailable on this box)
         else:
             raise HipLibraryError(f"libdualip_hip.so is not built and could not be built: {exc}") from exc
     try:
         handle = ctypes.CDLL(path)
     except OSError as exc:
         raise HipLibraryError(f"cannot load {path}: {exc}") from exc
+    if stale is not None:
+        # a binary whose sources have changed since it was built may not have the ABI _SIGNATURES describes: only accept it
+        # when it reports the ABI version these bindings were written for and exports every entry point, and say so
+        import warnings
+
+        missing = [n for n in _SIGNATURES if not hasattr(handle, n)]
+        handle.dl_version.restype = _c_int
+        if missing or int(handle.dl_version()) != ABI_VERSION:
+            raise HipLibraryError(f"{path} is stale (rebuild failed: {stale}) and does not match these bindings "
+                                  f"(ABI {int(handle.dl_version())} vs {ABI_VERSION}; missing {missing[:5]})") from stale
+        warnings.warn(f"libdualip_hip.so could not be rebuilt ({stale}); using the existing binary, whose ABI version matches", RuntimeWarning)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args
+    if int(handle.dl_version()) != ABI_VERSION:
+        raise HipLibraryError(f"{path} reports ABI version {int(handle.dl_version())}, these bindings expect {ABI_VERSION}")
     _lib = handle
     return _lib
 

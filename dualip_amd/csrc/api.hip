@@ -322,7 +322,7 @@ using namespace dl;
 extern "C" {
 
 const char* dl_last_error_string(void) { return g_err; }
-int dl_version(void) { return 100; }
+int dl_version(void) { return 200; }  // ABI version: _hip.py ABI_VERSION must agree
 
 int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx, int idx_dtype,
                        const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj, const int32_t* col_proj,
@@ -779,6 +779,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 12: return h->n_sell;
         case 13: return h->n_sell_cols;
         case 14: return h->n_sell_elems;
+        case 15: return h->n_sell_nnz;
         default: return -1;
     }
 }

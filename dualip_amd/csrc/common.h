@@ -115,7 +115,7 @@ struct dl_matching {
     long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
     // column-per-lane slices (sell.h): short columns of simplex entries, sorted by length, 64 per slice, transposed copies of
     // their values and row indices owned by the handle
-    int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0;
+    int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0, n_sell_nnz = 0;  // slices, their columns, slots (with padding), non-zeros
     uint32_t* sell_desc = nullptr;    // owned, 4 dwords per slice
     uint8_t* sell_len = nullptr;      // owned, [n_sell_cols]
     uint64_t* sell_colstart = nullptr;  // owned, [n_sell_cols]: the column's first non-zero in the caller's arrays (primal output)

@@ -237,7 +237,12 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         step(tB, tA);
     }
     // ---- column-per-lane slices: the short columns of simplex entries (sell.h) ----
-    sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, obj, ssq, fair);
+    // the cyclic deal continues where the window tiles stopped: wavefronts that had one window tile fewer take the first slices
+    {
+        const uint32_t me = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;
+        const uint32_t q0 = (g.ablate & 16) ? me : (me + S - n_tiles % S) % S;  // (DUALIP_HIP_ABLATE=16: every wavefront starts the slices at its own index)
+        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, q0, S, lane, sd, obj, ssq, fair);
+    }
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 2);

@@ -2,6 +2,7 @@
 // stable radix sort of the eligible columns by (entry, length), slice table, transposed copies of the value / row arrays.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,12 +40,12 @@ __global__ __launch_bounds__(256) void sell_hist_kernel(int64_t n, const IdxT* _
 
 template <class IdxT>
 __global__ __launch_bounds__(256) void sell_keys_kernel(int64_t n, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj,
-                                                        const uint8_t* __restrict__ pid_sell, uint16_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+                                                        const uint8_t* __restrict__ pid_sell, uint16_t* __restrict__ keys, uint32_t* __restrict__ ids, int desc) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t len = (int64_t)colptr[j + 1] - (int64_t)colptr[j];
         const int32_t pid = col_proj ? col_proj[j] : 0;
         const bool ok = pid >= 0 && pid < kSellPidSlots - 1 && pid_sell[pid] && len >= 1 && len <= kSellMaxH;
-        keys[j] = ok ? (uint16_t)(((uint32_t)pid << 6) | (uint32_t)len) : (uint16_t)0xFFFF;
+        keys[j] = ok ? (uint16_t)(((uint32_t)pid << 6) | (uint32_t)(desc ? 63 - len : len)) : (uint16_t)0xFFFF;  // (desc: longest first inside an entry)
         ids[j] = (uint32_t)j;
     }
 }
@@ -86,12 +87,21 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(uint32_t n_slices, const
 // Decide which projection entries get slices and lay the slices out.  hist / nnz are host copies of sell_hist_kernel's output.
 // An entry qualifies when it is a simplex kind and at least `min_share` of its non-zeros sit in columns of <= kSellMaxH
 // non-zeros (the rest of such an entry goes to single-column tiles: windows over the leftovers would stream mostly skipped data).
+// Slices run in ASCENDING length order.  Longest first (so that the last, partly filled round of the kernel's cyclic deal holds
+// the cheapest slices) was measured on one box, three repetitions each (tools/ab_sell.sh): 100M mixed 1.677-1.685 ms against
+// 1.654-1.660 ms ascending, 12.5M 0.224-0.230 against 0.221-0.224 -- slower.  DUALIP_HIP_SELL_ORDER=desc keeps it reachable.
+static bool sell_descending() {
+    const char* e = getenv("DUALIP_HIP_SELL_ORDER");
+    return e && e[0] == 'd';
+}
+
 static void sell_plan(const unsigned long long* hist, const unsigned long long* nnz, const dl_proj_desc* projs, int32_t n_proj, bool single_entry, double min_share,
-                      std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems) {
+                      std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems, uint64_t* n_nnz) {
     pid_sell.assign(kSellPidSlots, 0);
     desc.clear();
     *n_cols = 0;
     *n_elems = 0;
+    *n_nnz = 0;
     if (n_proj <= 0 || !projs) return;
     uint64_t dense = 0, base = 0;
     for (int pid = 0; pid < kSellPidSlots - 1 && pid < (single_entry ? 1 : n_proj); ++pid) {
@@ -105,26 +115,29 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
         for (int l = 1; l <= kSellMaxH; ++l) cnt += hist[(size_t)pid * kSellBins + l];
         if (cnt == 0) continue;
         pid_sell[pid] = 1;
-        // columns of this entry in sorted order: hist[l] columns of every length l = 1 .. 32
-        int l_lo = 1;            // length of the column at position `pos`
-        uint64_t left_lo = hist[(size_t)pid * kSellBins + 1];
+        *n_nnz += (uint64_t)sh;
+        // columns of this entry in sorted order: hist[l] columns of every length l, shortest first (see sell_descending)
+        const bool down = sell_descending();
+        const int l_first = down ? kSellMaxH : 1, l_last = down ? 1 : kSellMaxH, dl = down ? -1 : 1;
+        int l_lo = l_first;    // length of the column at the current position
+        uint64_t left_lo = hist[(size_t)pid * kSellBins + l_first];
         auto advance = [&](int& l, uint64_t& left, uint64_t by) {  // move `by` columns forward
             while (by > 0) {
-                while (left == 0 && l < kSellMaxH) left = hist[(size_t)pid * kSellBins + (++l)];
+                while (left == 0 && l != l_last) left = hist[(size_t)pid * kSellBins + (l += dl)];
                 const uint64_t step = by < left ? by : left;
                 left -= step;
                 by -= step;
+                if (step == 0) break;
             }
-            while (left == 0 && l < kSellMaxH) left = hist[(size_t)pid * kSellBins + (++l)];
+            while (left == 0 && l != l_last) left = hist[(size_t)pid * kSellBins + (l += dl)];
         };
         advance(l_lo, left_lo, 0);
         for (uint64_t pos = 0; pos < cnt; pos += 64) {
             const uint32_t ncols = (uint32_t)(cnt - pos < 64 ? cnt - pos : 64);
-            const int hmin = l_lo;
             int l_hi = l_lo;
             uint64_t left_hi = left_lo;
             advance(l_hi, left_hi, ncols - 1);  // the slice's last column
-            const int H = l_hi;
+            const int H = down ? l_lo : l_hi, hmin = down ? l_hi : l_lo;
             desc.push_back((uint32_t)base);
             desc.push_back((uint32_t)(base >> 32) | ((uint32_t)H << 8) | ((uint32_t)hmin << 16) | ((ncols - 1u) << 24));
             desc.push_back((uint32_t)pid);
@@ -158,8 +171,8 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(stats);
     if (e != hipSuccess) return hip_fail(e, "slice statistics");
-    uint64_t n_cols = 0, n_elems = 0;
-    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, pid_sell_out, desc, &n_cols, &n_elems);
+    uint64_t n_cols = 0, n_elems = 0, n_nnz = 0;
+    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, pid_sell_out, desc, &n_cols, &n_elems, &n_nnz);
     if (n_cols == 0 || n_cols >= (1ull << 32) || desc.size() / kSellDescWords >= (1ull << 31)) {
         pid_sell_out.assign(kSellPidSlots, 0);
         desc.clear();
@@ -168,6 +181,7 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     h->n_sell = (int64_t)(desc.size() / kSellDescWords);
     h->n_sell_cols = (int64_t)n_cols;
     h->n_sell_elems = (int64_t)n_elems;
+    h->n_sell_nnz = (int64_t)n_nnz;
     return 0;
 }
 
@@ -196,7 +210,7 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
     if (e == hipSuccess) e = hipMalloc((void**)&flags, kSellPidSlots);
     if (e == hipSuccess) e = hipMemcpyAsync(flags, pid_sell.data(), kSellPidSlots, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(sell_keys_kernel<IdxT>, dim3(blocks), dim3(256), 0, st, h->n, colptr, col_proj, flags, keys, ids);
+        hipLaunchKernelGGL(sell_keys_kernel<IdxT>, dim3(blocks), dim3(256), 0, st, h->n, colptr, col_proj, flags, keys, ids, sell_descending() ? 1 : 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, ids, ids2, (int)n, 0, 16, st);

@@ -390,3 +390,22 @@ def test_hot_rows_state_survives_outside_calls_between_iterations(monkeypatch):
     warm = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, other)
     ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), DEV), gamma=0.05)
     assert AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(ref, other).dual_objective_log == warm.dual_objective_log
+
+
+def test_handles_on_two_devices_in_one_process():
+    """The opt-in to more than 64 KB of LDS is a per-device function attribute: a process that builds handles on two devices (the
+    reference's split_tensors_to_devices idiom) must get it on both (a per-process flag gave it to the first only)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import load, problem, torch_args
+
+    z = load("g1_syn2000.npz")
+    p = problem(z)
+    pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
+    out = []
+    for dev in ("cuda:0", "cuda:1"):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, dev), 0.02)
+        out.append(f.calculate(torch.from_numpy(z["lam_small"]).to(dev), 0.02).dual_gradient.cpu())
+    assert torch.equal(out[0], out[1])
