@@ -100,24 +100,34 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         }
     }
     // ---- projection: per-lane recurrences ----
-    T mx = (T)0;  // (padding slots hold a = c = 0, so u = 0 there: harmless for the maximum)
+    T mx = (T)0, sall = (T)0;  // (padding slots hold a = c = 0, so u = 0 there: harmless for the maximum and the sum)
 #pragma unroll
-    for (int t = 0; t < HM; ++t) mx = max_nonneg(mx, u[t]);
+    for (int t = 0; t < HM; ++t) {
+        mx = max_nonneg(mx, u[t]);
+        sall = (T)(sall + u[t]);
+    }
     // slots past a column's own length (the slice's padding; none below Hmin) must not count as members
 #pragma unroll
     for (int t = 0; t < HM; ++t)
         if (t >= Hmin) u[t] = t < len ? u[t] : NEG;
+    // first support {u > theta_0}, theta_0 = the larger of two lower bounds of the threshold: max - z (the reference's top-2
+    // shortcut: only the maximum above it <=> vertex) and (sum of all - z) / length (Michelot's start).  Late in a solve, when
+    // most of a column is in its support, the second one is close to the answer and saves a pass or two; a single member can
+    // only happen with theta_0 = max - z (the threshold of a one-element support IS max - z, and theta_0 never exceeds the
+    // threshold), so the vertex test is unchanged.
     const T th0 = (T)(mx - pj.z);
+    T theta0 = th0;
+    if (!(g.ablate & 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
     T sum = (T)0, cnt = (T)0;
 #pragma unroll
     for (int t = 0; t < HM; ++t) {
-        const bool in = u[t] > th0;
+        const bool in = u[t] > theta0;
         sum = in ? (T)(sum + u[t]) : sum;
         cnt = in ? (T)(cnt + (T)1) : cnt;
     }
     // column state: theta (0 = keep the clamped values), vertex flag
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
-    const bool keep = ineq && !(sum > pj.ztol);
+    const bool keep = ineq && !(sall > pj.ztol);  // feasible after the clamp (simplex.py:153-158: the sum of the whole column)
     bool vertex = !keep && cnt == (T)1;
     T theta = (T)0;
     bool act = false;
@@ -126,15 +136,15 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         act = cnt > (T)2;  // a support of two is final: the runner-up stays above (sum - z)/2 exactly when it is above max - z
     }
     if (eq_row) {  // simplex_eq reference-compatibility mode (cold): a deficit is spread over the padded block height
-        if (pj.kind == DL_PROJ_SIMPLEX_EQ && sum < pj.z) {
+        if (pj.kind == DL_PROJ_SIMPLEX_EQ && sall < pj.z) {
             const T L = (T)eq_row[eq_bucket(len > 0 ? len : 1)];
-            theta = (T)((T)(sum - pj.z) / L);
+            theta = (T)((T)(sall - pj.z) / L);
             vertex = L == (T)1;
             act = false;
         }
     }
-    theta = tmax(theta, keep ? (T)0 : th0);  // (sum - z)/cnt > max - z in exact arithmetic: keep it so under rounding (nested supports)
-    theta = vertex ? th0 : theta;
+    theta = tmax(theta, keep ? (T)0 : theta0);  // (sum - z)/cnt >= theta_0 in exact arithmetic: keep it so under rounding (nested supports)
+    theta = vertex ? theta0 : theta;  // (the threshold the single member was counted at)
     T cprev = cnt;
     for (int it = 0; it < kSellMaxH + 2 && __any(act); ++it) {
         T s2 = (T)0, c2 = (T)0;
@@ -154,7 +164,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     T o32 = (T)0, q32 = (T)0, f32 = (T)0;
     auto finish = [&](int t, T at, T ct, uint32_t rt, T ft) {
         const T xg = relu((T)(u[t] - theta));
-        const T xv = (u[t] > th0) ? pj.z : (T)0;  // vertex: exact z at the maximum, as the reference
+        const T xv = (u[t] > theta) ? pj.z : (T)0;  // vertex: exact z at the maximum, as the reference
         const T x = vertex ? xv : xg;
         const T ax = (T)(at * x);
         if (ax != (T)0) {
