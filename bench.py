@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-ref-iters", type=int, default=3)
     ap.add_argument("--cpu-ref-threads", type=int, default=32, help="torch threads of the reference-path CPU leg (its measured optimum on the GPU box's host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gamma-decay", action="store_true", help="BASELINE config 3: gamma continuation in the whole-solve leg (35 steps / factor 0.7, initial gamma = "
+                    "gamma / 0.7^(iters // 35), benchmark/run_matching_benchmark.py:29-38); the timed window keeps the fixed gamma")
     ap.add_argument("--no-late", action="store_true", help="skip the whole-solve leg (the reference's 1000-iteration configuration: aux.whole_solve / aux.late)")
     ap.add_argument("--no-verify", action="store_true", help="skip the correctness leg at the benchmark size (aux.verified)")
     ap.add_argument("--solve-iters", type=int, default=1000, help="iterations of the whole-solve leg (benchmark/config.py:16-18: 1000)")
@@ -488,7 +490,12 @@ def main():
     if not args.no_late and args.solve_iters >= 200:
         S = args.solve_iters
         w0, w1 = int(S * 0.8), int(S * 0.9)
-        solver2 = AcceleratedGradientDescent(max_iter=S, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
+        decay_kw = {}
+        gamma0 = args.gamma
+        if args.gamma_decay:
+            gamma0 = args.gamma / (0.7 ** (S // 35))
+            decay_kw = dict(gamma_decay_type="step", gamma_decay_params={"decay_steps": 35, "decay_factor": 0.7})
+        solver2 = AcceleratedGradientDescent(max_iter=S, gamma=gamma0, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False, **decay_kw)
         run2 = solver2.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
         tA, *_ = timed_window(run2, local, comm, w0, fence, elapsed_max, 64)
         tB, lB, kB, xnB, xmsB = timed_window(run2, local, comm, w1 - w0, fence, elapsed_max, stride)
@@ -501,12 +508,15 @@ def main():
                 "physical_frac": phys_bytes / avgB / 1e9 / HBM_PEAK_GBS if avgB > 0 else None}
         if xnB:
             late["exchange_us"] = xmsB / xnB * 1e3
-        whole = {"iterations": S, "seconds": tA + tB + tC, "iterations_per_s": S / (tA + tB + tC), "final_dual_objective": res2.dual_objective,
+        gamma_end = float(solver2.gamma)
+        whole = {"iterations": S, "gamma_continuation": bool(args.gamma_decay), "gamma_first": gamma0, "gamma_last": gamma_end, "seconds": tA + tB + tC, "iterations_per_s": S / (tA + tB + tC), "final_dual_objective": res2.dual_objective,
                  "algorithmic_GBps": alg_bytes * S / (tA + tB + tC) / 1e9, "frac": alg_bytes * S / (tA + tB + tC) / 1e9 / HBM_PEAK_GBS}
 
     verified = None
     if not args.no_verify:
         try:
+            if whole is not None and args.gamma_decay:
+                args.gamma = whole["gamma_last"]  # (the verification leg evaluates the objective at the solve's final gamma)
             verified = verify_at_size(args, inp, pm_local, f, local, lam_late, rank, world, sharded, device)
         except Exception as exc:  # a failed check must show in the line, not kill the measurement
             verified = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
