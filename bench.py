@@ -142,6 +142,20 @@ def _cpu_sample(args, inp, pm_local, n_cols):
                 col_proj=np.concatenate(col_proj_parts), projs=projs, b=inp.b_vec.cpu().numpy(), m=A.shape[0], n_entries=len(entries))
 
 
+def read_ceiling_gbps(device, nbytes=4 << 30, reps=5):
+    """Streaming READ rate of this box (16-byte non-temporal loads, the fused kernel's access): what `physical_frac` should be
+    held against besides the 8 TB/s of the data sheet (the fused kernel is read dominated; torch's copy reads AND writes)."""
+    import ctypes
+
+    from dualip_amd import _hip
+
+    buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+    out = ctypes.c_double(0.0)
+    with torch.cuda.device(device):
+        _hip.check(_hip.load().dl_measure_read_bandwidth(_hip.ptr(buf), nbytes, reps, ctypes.byref(out), _hip.stream_ptr(device)))
+    return float(out.value)
+
+
 def cpu_baseline(args, inp, pm_local, total_nnz):
     """Two CPU legs on bounded samples of the same problem, all host cores, outside every timed region (reported baseline only):
       value   -- the reference's OP SEQUENCE restated in torch-on-CPU (oracle/torch_path.py: padded dense blocks per nnz bucket,
@@ -218,8 +232,8 @@ def timed_window(run, local, comm, n_iters, fence, elapsed_max, stride=1):
     """Time `n_iters` iterations of a device run between two fences; returns (seconds [max over ranks], fused launches,
     fused-kernel ms, exchange brackets, exchange ms)."""
     fence()
-    # every launch pair of event records costs ~5 us of stream time (measured: 9.5 us per iteration with two pairs): bracket
-    # every launch when an iteration is milliseconds long, every 8th when it is a fraction of one
+    # every pair of event records costs ~5 us of stream time (measured: 9.5 us per iteration with two pairs, 0.6 % of a 100M
+    # iteration and 4 % of a 12.5M one): the hooks bracket every `stride`-th launch
     events = 0 if os.environ.get("DUALIP_BENCH_NO_EVENTS") == "1" else stride
     local.profile(events)
     if comm is not None:
@@ -479,7 +493,7 @@ def main():
     solver = AcceleratedGradientDescent(max_iter=total_iters, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
     run = solver.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
     run.advance(args.warmup)
-    stride = 1 if nnz_first > 400_000_000 else 8
+    stride = 4 if nnz_first > 400_000_000 else 8  # (bracket every 4th / 8th fused launch: see timed_window)
     elapsed, launches, kernel_ms, xn, xms = timed_window(run, local, comm, args.steps, fence, elapsed_max, stride)
     result = run.finish()
     run.close()
@@ -571,6 +585,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "physical_bytes_per_launch": phys_bytes,
                 "physical_frac": phys_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else None,
+                "physical_GBps": phys_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None,
                 "window": [args.warmup + 1, args.warmup + args.steps],
             },
             "aux": {
@@ -585,6 +600,7 @@ def main():
                 "verified": verified,
                 "collective": None,
                 "copy_ceiling_GBps": copy_ceiling_gbps(device),
+                "read_ceiling_GBps": read_ceiling_gbps(device),
             },
         }
         if comm is not None:

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "dl_agd_read_log": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),
     "dl_agd_read_max_step": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), _c_vp]),
     "dl_project_dense": (_c_int, [_c_i64, _c_i64, _c_int, _c_vp, _c_vp, ctypes.POINTER(ProjDesc), _c_vp]),
+    "dl_measure_read_bandwidth": (_c_int, [_c_vp, _c_i64, ctypes.c_int32, ctypes.POINTER(_c_dbl), _c_vp]),
     "dl_csc_scale_rows": (_c_int, [_c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "dl_csc_scale_cols": (_c_int, [_c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "dl_csc_elementwise": (_c_int, [_c_i64, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),

@@ -281,6 +281,11 @@ int dl_csc_row_sums(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, c
 int dl_csc_project_columns(int64_t n_sel, const int64_t* cols, const void* colptr, int idx_dtype, const void* vals_in, void* vals_out,
                            const dl_proj_desc* proj_host, int val_dtype, dl_stream_t stream);
 
+/* Measurement hook (bench.py: aux.read_ceiling_GBps): best of `reps` streaming passes over buf[0..bytes) (16-byte aligned,
+ * >= 1 MiB) with 16-byte non-temporal loads, 256 workgroups x 1024 threads -- the read bandwidth this device reaches, in GB/s.
+ * Synchronises the stream. */
+int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, double* gbps_out_host, dl_stream_t stream);
+
 /* jacobi_precondition (src/dualip/preprocessing/precondition.py:8-28): row_norms_out[m] = ||A_i||_2,
  * then a[k] *= 1/row_norms[row_k] and b *= 1/row_norms in place.  rowidx in idx_dtype. */
 int dl_jacobi_precondition(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b,
