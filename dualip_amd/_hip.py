@@ -19,6 +19,7 @@ PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLE
 LOG_COLS = 8
 ABI_VERSION = 200  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
 PROJ_FLAG_BISECTION = 1
+PROJ_FLAG_NO_SLICES = 2
 
 _c_i64 = ctypes.c_int64
 _c_vp = ctypes.c_void_p

@@ -340,7 +340,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (k < DL_PROJ_NONE || k > DL_PROJ_SIMPLEX_EQ) return fail(DL_E_PROJ, "Unknown projection operator kind %d", k);
         if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !(projs_host[q].p0 > 0.0))
             return fail(DL_E_PROJ, "Simplex radius z must be positive.");
-        if (projs_host[q].flags != 0) return fail(DL_E_PROJ, "projection flags %d are not available inside the fused pass (entry %d)", (int)projs_host[q].flags, (int)q);
+        if (projs_host[q].flags & ~DL_PROJ_FLAG_NO_SLICES)
+            return fail(DL_E_PROJ, "projection flags %d are not available inside the fused pass (entry %d)", (int)projs_host[q].flags, (int)q);
     }
     hipStream_t st = (hipStream_t)stream;
     dl_matching* h = new (std::nothrow) dl_matching();

@@ -107,6 +107,7 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
     for (int pid = 0; pid < kSellPidSlots - 1 && pid < (single_entry ? 1 : n_proj); ++pid) {
         const int kind = projs[pid].kind;
         if (kind != DL_PROJ_SIMPLEX && kind != DL_PROJ_SIMPLEX_EQ) continue;
+        if (projs[pid].flags & DL_PROJ_FLAG_NO_SLICES) continue;
         double sh = 0.0;
         for (int l = 1; l <= kSellMaxH; ++l) sh += (double)l * (double)hist[(size_t)pid * kSellBins + l];
         const double lg = (double)nnz[pid * 2 + 1];

@@ -135,7 +135,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
     _dualip_native = True
 
     def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, batching: bool = True, simplex_eq_padding: str = "exact",
-                 use_jacobi_precondition: bool = False, row_norms: Optional[torch.Tensor] = None):
+                 use_jacobi_precondition: bool = False, row_norms: Optional[torch.Tensor] = None, column_slices: bool = True):
         A, c = matching_input_args.A, matching_input_args.c
         if A.layout != torch.sparse_csc or c.layout != torch.sparse_csc:
             raise ValueError("Both A and c must be CSC-format sparse tensors")
@@ -189,6 +189,8 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         colptr = A.ccol_indices().contiguous()
         rowidx = A.row_indices().contiguous()
         descs, col_proj = _column_projection_table(self.projection_map, self.n, self.device)
+        if not column_slices:  # keep every entry in window tiles (include/dualip_hip.h: DL_PROJ_FLAG_NO_SLICES)
+            descs = [_hip.ProjDesc(d.kind, d.flags | _hip.PROJ_FLAG_NO_SLICES, d.p0, d.p1) for d in descs]
         self._descs = (_hip.ProjDesc * max(len(descs), 1))(*descs)
 
         lib = _hip.load()

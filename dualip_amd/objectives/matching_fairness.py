@@ -100,7 +100,7 @@ class MatchingFairnessDualObjectiveFunction(BaseObjective):
         if c_eff.values().data_ptr() != self._c_eff.data_ptr():  # the kernel must see the buffer this class rewrites
             self._c_eff = c_eff.values()
         inner_args = MatchingInputArgs(A=A, c=c_eff, projection_map=matching_input_args.projection_map, b_vec=None, equality_mask=None)
-        self.inner = MatchingSolverDualObjectiveFunction(matching_input_args=inner_args, gamma=gamma, batching=batching)
+        self.inner = MatchingSolverDualObjectiveFunction(matching_input_args=inner_args, gamma=gamma, batching=batching, column_slices=False)
         self.gamma = gamma
         self.b_vec = b
         self.equality_mask = matching_input_args.equality_mask
@@ -117,7 +117,8 @@ class MatchingFairnessDualObjectiveFunction(BaseObjective):
             return False
         wide = lambda t: torch.sparse_csc_tensor(t.ccol_indices(), t.row_indices(), t.values(), size=(self.m, n))  # noqa: E731
         inner_args = MatchingInputArgs(A=wide(A), c=wide(c), projection_map=args.projection_map, b_vec=args.b_vec, equality_mask=args.equality_mask)
-        inner = MatchingSolverDualObjectiveFunction(matching_input_args=inner_args, gamma=gamma, batching=batching)
+        # window tiles only: with a fourth streamed array the sliced kernel spills registers and is slower than the window one
+        inner = MatchingSolverDualObjectiveFunction(matching_input_args=inner_args, gamma=gamma, batching=batching, column_slices=False)
         with torch.cuda.device(inner.device):
             rc = self._lib.dl_matching_set_fairness(inner._handle, _hip.ptr(self._f), _hip.stream_ptr(inner.device))
         if rc != 0:

@@ -62,6 +62,10 @@ typedef struct {
  * 1e-6 after its feasibility and top-2 shortcuts) instead of the exact threshold.  A matching handle rejects it: inside the
  * objective such entries take the dense-block route of user-defined operators (objectives/matching.py:_CustomBlocks). */
 enum { DL_PROJ_FLAG_BISECTION = 1 };
+/* dl_matching_create only: keep this entry's columns in window tiles (no column-per-lane slices).  The fairness objective sets
+ * it: the sliced kernel with a fourth streamed array spills registers (10M entities, all-simplex: 0.36 ms per iteration sliced
+ * against 0.32 ms in window tiles), and its folded fallback rewrites c every iteration. */
+enum { DL_PROJ_FLAG_NO_SLICES = 2 };
 
 typedef struct dl_matching dl_matching; /* opaque: one matching objective (A, c) on one device */
 typedef struct dl_agd dl_agd;           /* opaque: device-resident state of one maximize() run */

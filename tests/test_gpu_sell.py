@@ -217,3 +217,31 @@ def test_device_packed_windows_equal_host_packed(kind):
     ra, rb = fd.calculate(lam, 0.05, save_primal=True), fh.calculate(lam, 0.05, save_primal=True)
     assert torch.equal(ra.dual_gradient, rb.dual_gradient) and torch.equal(ra.primal_var, rb.primal_var)
     assert abs(float(ra.dual_objective) - float(rb.dual_objective)) < 1e-9 * max(1.0, abs(float(rb.dual_objective)))
+
+
+def test_fairness_stream_on_sliced_handle_equals_window_handle():
+    """dl_matching_set_fairness on a handle WITH slices (the C path keeps a transposed copy of f) against the same handle kept on
+    window tiles (what objectives/matching_fairness.py builds): same gradient (exact integers), same primal."""
+    from dualip_amd import _hip
+    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = _ragged(31, n=5000, m=120, lens=np.random.default_rng(2).integers(1, 20, 5000))
+    n, K = p["n"], p["m"]
+    m = K + 2
+    rng = np.random.default_rng(4)
+    f_vals = torch.from_numpy(rng.uniform(-0.3, 0.3, len(p["a"]))).to(DEV)
+    out = []
+    for slices in (True, False):
+        base = torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, n), DEV)
+        wide = lambda t: torch.sparse_csc_tensor(t.ccol_indices(), t.row_indices(), t.values(), size=(m, n))  # noqa: E731
+        b = torch.cat([base.b_vec, torch.tensor([0.05, 0.05], dtype=torch.float64, device=DEV)])
+        obj = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=wide(base.A), c=wide(base.c), projection_map=base.projection_map, b_vec=b), 0.05, column_slices=slices)
+        assert (obj.info()["slices"] > 0) == slices
+        with torch.cuda.device(obj.device):
+            _hip.check(_hip.load().dl_matching_set_fairness(obj._handle, _hip.ptr(f_vals), _hip.stream_ptr(obj.device)))
+        lam = torch.from_numpy(rng.uniform(0, 0.1, m)).to(DEV) if not out else out[0][2]
+        r = obj.calculate(lam, 0.05, save_primal=True)
+        out.append((r.dual_gradient.clone(), r.primal_var.clone(), lam))
+    assert relerr(out[0][1].cpu().numpy(), out[1][1].cpu().numpy()) < 1e-12
+    assert relerr(out[0][0].cpu().numpy(), out[1][0].cpu().numpy()) < 1e-12
