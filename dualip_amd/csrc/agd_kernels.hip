@@ -1,6 +1,7 @@
 // agd_kernels.hip -- the m-sized side of the dual ascent on gfx950: dual epilogue, accelerated-gradient step with the
 // Lipschitz-history step size (device resident, no host round trip), dense-block projection operator and
 // Jacobi row scaling.
+#include "agd_step.h"
 #include "comm.h"
 #include <algorithm>
 #include <cstring>
@@ -9,17 +10,6 @@
 namespace dl {
 
 constexpr int kAgdThreads = 1024;
-constexpr int kLipsMax = 14;  // max_history_length - 1 (optimizers/agd_utils.py:69)
-
-struct AgdDevState {
-    double max_step;
-    double initial_step;
-    double last_step;
-    int32_t n_lips;  // valid entries in the ring, oldest first starting at head
-    int32_t head;
-    int64_t steps_done;
-    double lips[kLipsMax];  // values rounded to the working precision
-};
 
 template <class T>
 __device__ __forceinline__ T rnd(double v) { return (T)v; }
@@ -89,7 +79,6 @@ __global__ __launch_bounds__(kAgdThreads) void dual_epilogue_kernel(int64_t m, c
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kStatRows = 64;      // rows per stats workgroup
 constexpr int kStatSlices = 16;    // slab slices per stats workgroup (1024 threads)
-constexpr int kStatCols = 6;       // dvtg, gmax, spos, g2, dg2, dy2
 
 template <class T>
 struct StatsArgs {
@@ -255,145 +244,17 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
 
 // ---- finalize + update in one launch ----
 // Every workgroup derives the SAME scalars (objective pieces, Lipschitz estimate, step) from the stats partials, in the
-// same order, then updates its own 1024 rows.  (Letting every workgroup recompute the statistics from the reduced A x
-// instead -- no stats launch on the sharded route -- measured 22 us against 4.3 + 7.5 us for the two launches.)  The optimizer state is double buffered: all workgroups read st_in,
-// workgroup 0 writes st_out.
-constexpr int kApplyThreads = 1024;
-
-template <class T>
-struct ApplyArgs {
-    int64_t m;
-    const double* __restrict__ partial_stats;  // [n_blocks][kStatCols], from the stats launch
-    int n_blocks;
-    const T* __restrict__ g_new;               // gradient written by the stats launch
-    const double* __restrict__ scal;           // c.x, sum x^2
-    const AgdDevState* st_in;
-    AgdDevState* st_out;
-    double* __restrict__ log_row;
-    double gamma;
-    int decay_now;
-    double decay_factor;
-    // update
-    const T* __restrict__ x;
-    T* __restrict__ x_next;
-    const T* __restrict__ y;
-    T* __restrict__ y_new;
-    const uint8_t* __restrict__ eq_mask;
-    const float* __restrict__ beta;
-    int64_t iter;
-    T* __restrict__ x_perm;              // or null
-    const int32_t* __restrict__ perm;    // caller's row -> renumbered row
-};
-
+// same order, then updates its own 1024 rows (agd_step.h holds the arithmetic: the fused pass of the NEXT iteration can run it in
+// its prologue instead, saving this launch).  The optimizer state is double buffered: all workgroups read st_in, workgroup 0
+// writes st_out.
 template <class T>
 __global__ __launch_bounds__(kApplyThreads) void agd_apply_kernel(ApplyArgs<T> p) {
     const int tid = threadIdx.x;
-    const AgdDevState& si = *p.st_in;
-    const bool has_prev = si.steps_done > 0;
-    const double ring = si.lips[(tid & 63) < kLipsMax ? (tid & 63) : kLipsMax - 1];  // Lipschitz history, one entry per lane
-    double dvtg = 0.0, gmax = -INFINITY, spos = 0.0, g2 = 0.0, dg2 = 0.0, dy2 = 0.0;
-    T g_mine = (T)0;  // gradient of this thread's own row
+    const double step = agd_step_scalars(p, tid & 63, blockIdx.x == 0, tid);
     const int64_t mine = (int64_t)blockIdx.x * kApplyThreads + tid;
-    {
-        // every wavefront sums the partials in the same fixed order (no LDS, no barrier); four rows per lane are loaded
-        // before the first is used -- the launch is latency bound
-        constexpr int kU = 4;
-        for (int k0 = tid & 63; k0 < p.n_blocks; k0 += 64 * kU) {
-            double o[kU][kStatCols];
-            bool in[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int k = k0 + 64 * u;
-                in[u] = k < p.n_blocks;
-                const double* src = p.partial_stats + (int64_t)(in[u] ? k : p.n_blocks - 1) * kStatCols;
-#pragma unroll
-                for (int c = 0; c < kStatCols; ++c) o[u][c] = src[c];
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                dvtg += in[u] ? o[u][0] : 0.0;
-                gmax = (in[u] && o[u][1] > gmax) ? o[u][1] : gmax;
-                spos += in[u] ? o[u][2] : 0.0;
-                g2 += in[u] ? o[u][3] : 0.0;
-                dg2 += in[u] ? o[u][4] : 0.0;
-                dy2 += in[u] ? o[u][5] : 0.0;
-            }
-        }
-        dvtg = wave_allreduce(dvtg, OpAdd());
-        gmax = wave_allreduce(gmax, OpMax());
-        spos = wave_allreduce(spos, OpAdd());
-        g2 = wave_allreduce(g2, OpAdd());
-        dg2 = wave_allreduce(dg2, OpAdd());
-        dy2 = wave_allreduce(dy2, OpAdd());
-        if (mine < p.m) g_mine = p.g_new[mine];  // written by the stats launch
-    }
-    // ---- calculate_step_size (agd_utils.py:65-89) ----
-    // The Lipschitz ring lives one entry per lane (loaded at the top of the kernel): no serial walk over global memory.
-    int n_lips = si.n_lips, head = si.head, slot = -1;
-    double L = 0.0;
-    if (has_prev) {
-        const T num = (T)sqrt(dg2), den = (T)sqrt(dy2);
-        L = (double)(T)(num / den);  // estimate_lipschitz_constant; x/0 -> inf, 0/0 -> nan as in torch
-        if (n_lips == kLipsMax) {
-            slot = head;  // overwrite the oldest
-            head = (head + 1) % kLipsMax;
-        } else {
-            slot = (head + n_lips) % kLipsMax;
-            n_lips += 1;
-        }
-    }
-    const int lane = tid & 63;
-    const double ring_new = lane == slot ? L : ring;  // lanes >= kLipsMax carry padding
-    double step;
-    if (n_lips < kLipsMax) {
-        step = si.initial_step;  // incomplete history (agd_utils.py:57-58)
-    } else {
-        // builtins.max over the list, oldest first: NaN if the oldest entry is NaN, else the maximum of the non-NaN entries
-        const double first = bperm(head, ring_new);
-        const double cand_l = (lane < kLipsMax && !isnan(ring_new)) ? ring_new : -INFINITY;
-        const double mx = wave_allreduce(cand_l, OpMax());
-        const double lmax = isnan(first) ? first : mx;
-        if (isnan(lmax) || isinf(lmax)) step = si.initial_step;
-        else {
-            const double cand = lmax != 0.0 ? 1.0 / lmax : si.max_step;
-            step = cand < si.max_step ? cand : si.max_step;
-        }
-    }
-    if (blockIdx.x == 0 && tid < kLipsMax) p.st_out->lips[tid] = ring_new;
-    if (blockIdx.x == 0 && tid == 0) {
-        AgdDevState& so = *p.st_out;
-        so.initial_step = si.initial_step;
-        so.max_step = p.decay_now ? step * p.decay_factor : si.max_step;  // agd.py:106-107
-        so.last_step = step;
-        so.n_lips = n_lips;
-        so.head = head;
-        so.steps_done = si.steps_done + 1;
-        if (p.log_row) {
-            const T nrm = (T)sqrt(p.scal[1]);
-            const T reg = (T)((T)(p.gamma / 2.0) * (T)(nrm * nrm));  // (gamma/2) * norm(x)**2, matching.py:157
-            const T obj0 = (T)p.scal[0];
-            const T dv = (T)dvtg;
-            const T obj = (T)((T)(obj0 + reg) + dv);                 // matching.py:33
-            p.log_row[0] = (double)obj;
-            p.log_row[1] = step;
-            p.log_row[2] = (double)reg;
-            p.log_row[3] = (double)dv;
-            p.log_row[4] = (p.m > 0 && gmax > 0.0) ? (double)(T)gmax : 0.0;  // builtins.max(max(grad), 0), matching.py:168
-            p.log_row[5] = (double)(T)spos;
-            p.log_row[6] = (double)(T)sqrt(g2);
-            p.log_row[7] = (double)obj0;
-        }
-    }
-    // ---- projected ascent step + momentum (agd.py:181-184) ----
     if (mine < p.m) {
-        const T stp = (T)step;
-        const float bt = p.beta[p.iter - 1];
-        const T bb = (T)bt;
-        const T omb = (T)(float)(1.0f - bt);  // 1.0 - fp32 0-dim tensor stays fp32 (agd.py:184)
-        T yn = (T)(p.x[mine] + (T)(g_mine * stp));                  // agd.py:181
-        const bool eq = p.eq_mask && p.eq_mask[mine];
-        if (!eq) yn = yn > (T)0 ? yn : (T)0;                         // project_on_nn_cone, agd.py:13-21
-        const T xn = (T)((T)(yn * omb) + (T)(p.y[mine] * bb));       // agd.py:184
+        T yn, xn;
+        agd_update_row(p, step, mine, yn, xn);
         p.y_new[mine] = yn;
         p.x_next[mine] = xn;
         if (p.x_perm) p.x_perm[p.perm[mine]] = xn;  // hot-rows plan of the matching handle: next launch's dual vector, renumbered
@@ -594,13 +455,11 @@ int agd_state_read_max_step(void* dev_state, int cur, double* out, hipStream_t s
 }
 
 template <class T>
-static int agd_step_typed(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st) {
+static int agd_stats_typed(dl_agd* s, const StepSource& src, const void* b, hipStream_t st) {
     const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
     AgdDevState* states = (AgdDevState*)s->state;
     const AgdDevState* st_in = states + s->state_cur;
-    AgdDevState* st_out = states + (s->state_cur ^ 1);
     dl_matching* f = src.slabs;
-    dl_matching* hot = (src.hot && src.hot->m_hot > 0) ? src.hot : nullptr;
     if (n_blocks > 0) {
         StatsArgs<T> sa;
         memset(&sa, 0, sizeof(sa));
@@ -632,36 +491,22 @@ static int agd_step_typed(dl_agd* s, const StepSource& src, const void* b, doubl
         if (f) hipLaunchKernelGGL((agd_stats_kernel<T, 1>), dim3(n_blocks + 1), dim3(kStatRows * kStatSlices), 0, st, sa);  // + the scalar-sum block
         else if (src.mail) hipLaunchKernelGGL((agd_stats_kernel<T, 2>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
         else hipLaunchKernelGGL((agd_stats_kernel<T, 0>), dim3(n_blocks), dim3(kStatRows * kStatSlices), 0, st, sa);
+        DL_HIP(hipGetLastError());
     }
-    ApplyArgs<T> aa;
-    aa.m = s->m;
-    aa.partial_stats = s->partial_stats;
-    aa.n_blocks = n_blocks;
-    aa.g_new = (const T*)s->g_old;
-    aa.scal = (n_blocks > 0 || !src.n_packed) ? s->packed + s->m : src.packed[0] + s->m;  // (the stats launch leaves the scalars it used in s->packed)
-    aa.st_in = st_in;
-    aa.st_out = st_out;
-    aa.log_row = (iter >= 1 && iter <= s->max_iter) ? s->log + (iter - 1) * kLogCols : nullptr;
-    aa.gamma = gamma;
-    aa.decay_now = decay_now;
-    aa.decay_factor = decay_factor;
-    aa.x = (const T*)s->x;
-    aa.x_next = (T*)s->x_alt;
-    aa.y = (const T*)s->y;
-    aa.y_new = (T*)s->y_old;
-    aa.eq_mask = s->eq_mask;
-    aa.beta = s->beta;
-    aa.iter = iter;
+    return 0;
+}
+
+template <class T>
+static int agd_apply_typed(dl_agd* s, const StepSource& src, const PendingStep& ps, hipStream_t st) {
+    dl_matching* f = src.slabs;
+    dl_matching* hot = (src.hot && src.hot->m_hot > 0) ? src.hot : nullptr;
+    ApplyArgs<T> aa = make_apply_args<T>(s, ps);
     aa.x_perm = hot ? (T*)hot->lam_perm : nullptr;
     aa.perm = hot ? hot->row_perm : nullptr;
     const unsigned grid = (unsigned)std::max<int64_t>(1, (s->m + kApplyThreads - 1) / kApplyThreads);
     hipLaunchKernelGGL(agd_apply_kernel<T>, dim3(grid), dim3(kApplyThreads), 0, st, aa);
     DL_HIP(hipGetLastError());
-    // rotate: the buffer that received y_i becomes y; the old y becomes the "previous history dual"; likewise x, g, state
-    std::swap(s->y, s->y_old);
-    std::swap(s->g, s->g_old);
-    std::swap(s->x, s->x_alt);
-    s->state_cur ^= 1;
+    agd_rotate(s);
     if (hot && f == hot) {  // (the slab route also re-zeroed the cold accumulators: the next fused launch needs no preparation at all)
         hot->hot_ready = true;
         hot->hot_ready_lambda = s->x;
@@ -670,11 +515,36 @@ static int agd_step_typed(dl_agd* s, const StepSource& src, const void* b, doubl
     return 0;
 }
 
-// Where A x comes from: the matching handle's integer slabs (single-device loop, no separate slab reduction), reduced
-// packed buffers (all-reduced when sharded over RCCL; one per block of a split shard), or the P2P mailbox.
+// The first half of a step: g = A x - b and the per-workgroup statistics.  Where A x comes from: the matching handle's integer
+// slabs (single-device loop, no separate slab reduction), reduced packed buffers (all-reduced when sharded over RCCL; one per
+// block of a split shard), or the P2P mailbox.
+int launch_agd_stats(dl_agd* s, const StepSource& src, const void* b, hipStream_t st) {
+    if (s->val_dtype == DL_F32) return agd_stats_typed<float>(s, src, b, st);
+    return agd_stats_typed<double>(s, src, b, st);
+}
+// The second half as its own launch (step size, projected ascent, momentum, log row, next state) + buffer rotation.  The loops
+// of api.hip hand this half to the NEXT fused launch's prologue instead whenever they can (agd_step.h).
+int launch_agd_apply(dl_agd* s, const StepSource& src, const PendingStep& ps, hipStream_t st) {
+    if (s->val_dtype == DL_F32) return agd_apply_typed<float>(s, src, ps, st);
+    return agd_apply_typed<double>(s, src, ps, st);
+}
+// scalars (c.x, sum x^2) the step of `src` reads: the stats launch leaves them in s->packed
+const double* agd_step_scal(const dl_agd* s, const StepSource& src) {
+    const int n_blocks = (int)((s->m + kStatRows - 1) / kStatRows);
+    return (n_blocks > 0 || !src.n_packed) ? s->packed + s->m : src.packed[0] + s->m;
+}
+
 int launch_agd_step(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st) {
-    if (s->val_dtype == DL_F32) return agd_step_typed<float>(s, src, b, gamma, iter, decay_now, decay_factor, st);
-    return agd_step_typed<double>(s, src, b, gamma, iter, decay_now, decay_factor, st);
+    int rc = launch_agd_stats(s, src, b, st);
+    if (rc) return rc;
+    PendingStep ps;
+    ps.valid = true;
+    ps.gamma = gamma;
+    ps.iter = iter;
+    ps.decay_now = decay_now;
+    ps.decay_factor = decay_factor;
+    ps.scal = agd_step_scal(s, src);
+    return launch_agd_apply(s, src, ps, st);
 }
 
 size_t agd_partial_stats_bytes(int64_t m) { return sizeof(double) * kStatCols * (size_t)((m + kStatRows - 1) / kStatRows + 1); }

@@ -997,10 +997,25 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
     hipStream_t st = (hipStream_t)stream;
     double gamma = *gamma_io_host;
     if (first_iter == 1 || f->hot_ready_owner != s->uid) f->hot_ready = false;  // a new run (or another optimiser) starts from its own dual vector
+    // An iteration is: fused pass at x -> stats (g, partial reductions) -> apply (step, new x and y).  With DUALIP_HIP_FUSE_APPLY=1
+    // (and a handle that allows it) the apply of iteration i rides the fused launch of iteration i + 1 (agd_step.h): two launches
+    // per iteration instead of three; the last iteration of the call is applied by its own launch, so the state is complete when
+    // the call returns.  Opt-in: measured neutral (fused_common.h: fused_prologue).
+    const bool can_fuse = matching_can_fuse_apply(f);
+    PendingStep pending;
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         void* xo = (it == first_iter + n_iters - 1) ? x_out : nullptr;
         const bool empty = (f->n_tiles == 0 && f->n_sell == 0) || f->n_wg == 0;
-        int rc = empty ? matching_calculate(f, s->x, gamma, s->packed, xo, st) : matching_launch_fused(f, s->x, gamma, xo, st, s->uid);
+        int rc = 0;
+        if (empty) {
+            rc = matching_calculate(f, s->x, gamma, s->packed, xo, st);
+        } else if (pending.valid) {
+            rc = matching_launch_fused(f, nullptr, gamma, xo, st, s->uid, s, &pending);  // applies iteration it - 1, then runs at the new x
+            if (!rc) agd_rotate(s);
+            pending.valid = false;
+        } else {
+            rc = matching_launch_fused(f, s->x, gamma, xo, st, s->uid);
+        }
         if (rc) return rc;
         const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
         StepSource src;
@@ -1011,8 +1026,19 @@ int dl_agd_run_matching(dl_agd* s, dl_matching* f, const void* b, int64_t first_
             src.slabs = f;
             src.hot = f;
         }
-        rc = launch_agd_step(s, src, b, gamma, it, decay_now, decay_factor, st);
+        rc = launch_agd_stats(s, src, b, st);
         if (rc) return rc;
+        pending.valid = true;
+        pending.gamma = gamma;
+        pending.iter = it;
+        pending.decay_now = decay_now;
+        pending.decay_factor = decay_factor;
+        pending.scal = agd_step_scal(s, src);
+        if (!can_fuse || empty || it == first_iter + n_iters - 1) {
+            rc = launch_agd_apply(s, src, pending, st);
+            if (rc) return rc;
+            pending.valid = false;
+        }
         if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
     }
     *gamma_io_host = gamma;
@@ -1042,6 +1068,10 @@ int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n
     for (int k = 1; k < n_blocks && comm->backend == DL_COMM_RCCL; ++k)
         if (!s->packed_blk[k - 1]) DL_HIP(hipMalloc((void**)&s->packed_blk[k - 1], pbytes));
     double gamma = *gamma_io_host;
+    // (as in dl_agd_run_matching: the apply of iteration i rides the first block's fused launch of iteration i + 1 when it can)
+    const bool first_empty = (blocks[0]->n_tiles == 0 && blocks[0]->n_sell == 0) || blocks[0]->n_wg == 0;
+    const bool can_fuse = !first_empty && matching_can_fuse_apply(blocks[0]);
+    PendingStep pending;
     for (int64_t it = first_iter; it < first_iter + n_iters; ++it) {
         StepSource src;
         src.scale = comm->emu_scale;
@@ -1053,7 +1083,13 @@ int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n
             const bool empty = (f->n_tiles == 0 && f->n_sell == 0) || f->n_wg == 0;
             double* pk = k == 0 ? s->packed : s->packed_blk[k - 1];
             int rc = 0;
-            if (!empty) rc = matching_launch_fused(f, s->x, gamma, nullptr, st, 0);
+            if (k == 0 && pending.valid) {
+                rc = matching_launch_fused(f, nullptr, gamma, nullptr, st, 0, s, &pending);  // applies iteration it - 1, then runs at the new x
+                if (!rc) agd_rotate(s);
+                pending.valid = false;
+            } else if (!empty) {
+                rc = matching_launch_fused(f, s->x, gamma, nullptr, st, 0);
+            }
             if (rc) return rc;
             if (last && comm->prof_on && (comm->prof_seen++ % (uint64_t)comm->prof_stride) == 0) {  // measurement: end of the last fused pass -> end of the step's first kernel
                 if (comm->prof_used == comm->prof_start.size() && comm->prof_start.size() < 16384) {
@@ -1105,9 +1141,20 @@ int dl_agd_run_matching_sharded(dl_agd* s, dl_matching* const* blocks, int32_t n
             }
         }
         const int decay_now = gamma_decay_steps > 0 && (it % gamma_decay_steps == 0);
-        int rc = launch_agd_step(s, src, b, gamma, it, decay_now, decay_factor, st);
+        int rc = launch_agd_stats(s, src, b, st);
         if (rc) return rc;
         if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
+        pending.valid = true;
+        pending.gamma = gamma;
+        pending.iter = it;
+        pending.decay_now = decay_now;
+        pending.decay_factor = decay_factor;
+        pending.scal = agd_step_scal(s, src);
+        if (!can_fuse || it == first_iter + n_iters - 1) {
+            rc = launch_agd_apply(s, src, pending, st);
+            if (rc) return rc;
+            pending.valid = false;
+        }
         if (decay_now) gamma = gamma * decay_factor;  // agd.py:105
     }
     *gamma_io_host = gamma;

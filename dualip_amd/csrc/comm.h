@@ -13,6 +13,7 @@
 //         memory), acquires, and adds the slots in rank order 0..W-1 -- so all ranks obtain bit-identical sums without a
 //         second hop, and an iteration costs no collective launch at all.
 #pragma once
+#include "agd_step.h"
 #include "common.h"
 
 namespace dl {
@@ -149,8 +150,15 @@ struct StepSource {
     dl_matching* hot = nullptr;      // handle under the hot-rows plan that wants the next dual vector in renumbered order, or null
 };
 int launch_agd_step(dl_agd* s, const StepSource& src, const void* b, double gamma, int64_t iter, int decay_now, double decay_factor, hipStream_t st);
+int launch_agd_stats(dl_agd* s, const StepSource& src, const void* b, hipStream_t st);
+int launch_agd_apply(dl_agd* s, const StepSource& src, const PendingStep& ps, hipStream_t st);
+const double* agd_step_scal(const dl_agd* s, const StepSource& src);
 int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* push, hipStream_t st, int push_accumulate);
-int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid);
+// pending != null && pending->valid: the launch's prologue applies that step first (the dual vector it stages is the NEW x; agd
+// must be the optimiser the step belongs to); the caller rotates the optimiser's buffers afterwards (agd_rotate)
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd = nullptr,
+                          const PendingStep* pending = nullptr);
+bool matching_can_fuse_apply(const dl_matching* h);
 PushArgs comm_push_args(dl_comm* c, unsigned long long seq);
 MailArgs comm_mail_args(dl_comm* c, unsigned long long seq);
 int comm_rccl_allreduce(dl_comm* c, double* buf, int64_t count, hipStream_t st);

@@ -2,6 +2,7 @@
 // lane, 64-wide tiles; matching_kernels4.hip: four per lane, 256-wide tiles): kernel arguments, the exact fixed-point
 // scatter, SGPR-base addressing and the single-column ("long tile") walker.
 #pragma once
+#include "agd_step.h"
 #include "common.h"
 #include "simplex.h"
 #include "wave.h"
@@ -53,6 +54,10 @@ struct FusedArgs {
     const void* __restrict__ sell_r;
     const T* __restrict__ sell_f;
     uint32_t n_sell;
+    // the previous iteration's optimiser step, applied in this launch's prologue (agd_step.h): do_apply != 0 => `lambda` is not read,
+    // every workgroup forms the new iterate from apply.{x, g_new, y} and stages THAT; workgroup 0 also stores it (and the state / log)
+    int do_apply;
+    ApplyArgs<T> apply;
 };
 
 // The cold paths re-read the kernel arguments from the kernarg segment (they sit at offset 0) instead of keeping a dozen
@@ -316,14 +321,55 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     w.red_s = reinterpret_cast<double*>(smem + off);
     w.s = (T)(-1.0 / g.gamma);
     double lmax = 0.0;
+    // The optimiser step of the previous iteration, if this launch carries it (agd_step.h; opt-in, DUALIP_HIP_FUSE_APPLY=1): every
+    // wavefront derives the same step and every workgroup forms the new iterate itself.  Measured on one box at the per-rank size
+    // of an 8-GPU run (12.5M entities): the launch grows by 7 us -- the stats partials, then the rows, are two dependent memory
+    // latencies at the head of a launch whose CUs have nothing else to do yet -- which is what the separate apply launch and its
+    // boundary cost: 0.2317 / 0.2333 / 0.2314 ms per iteration with it, 0.2323 / 0.2313 / 0.2302 without.  Requesting the rows
+    // before deriving the step (twelve per thread in registers) made the launch 12 us longer.  Kept as a tested route, not the default.
+    const bool applying = g.do_apply != 0;
+    T a_stp = (T)0, a_bb = (T)0, a_omb = (T)0;
+    if (applying) {
+        const ApplyArgs<T>& ap = kernarg_args(g).apply;
+        a_stp = (T)agd_step_scalars(ap, lane, wg == 0, tid);
+        const float bt = ap.beta[ap.iter - 1];
+        a_bb = (T)bt;
+        a_omb = (T)(float)(1.0f - bt);
+    }
     {   // latency bound (every workgroup pulls the whole dual vector from L2): four loads in flight per thread
         constexpr int kU = 4;
         for (int64_t i0 = tid; i0 < g.m; i0 += (int64_t)kU * kFusedThreads) {
             T l[kU];
+            if (!applying) {
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int64_t i = i0 + (int64_t)u * kFusedThreads;
-                l[u] = g.lambda[i < g.m ? i : g.m - 1];
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    l[u] = g.lambda[i < g.m ? i : g.m - 1];
+                }
+            } else {
+                const ApplyArgs<T>& ap = kernarg_args(g).apply;
+                T xx[kU], gg[kU], yy[kU];
+                bool eq[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    const int64_t ic = i < g.m ? i : g.m - 1;
+                    xx[u] = ap.x[ic];
+                    gg[u] = ap.g_new[ic];
+                    yy[u] = ap.y[ic];
+                    eq[u] = ap.eq_mask && ap.eq_mask[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    T yn, xn;
+                    agd_update_values(xx[u], gg[u], yy[u], eq[u], a_stp, a_bb, a_omb, yn, xn);
+                    l[u] = xn;
+                    if (wg == 0 && i < g.m) {  // one workgroup stores the new iterate for the launches that follow
+                        ap.y_new[i] = yn;
+                        ap.x_next[i] = xn;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {

@@ -426,8 +426,16 @@ __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restri
 }
 
 // the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
+// the step of the previous iteration CAN ride this handle's launches when every dual entry the kernel reads comes from the
+// workgroup's own LDS copy (256-wide layout, whole dual vector and gradient in LDS, no fairness stream)
+bool matching_can_fuse_apply(const dl_matching* h) {
+    const char* e = getenv("DUALIP_HIP_FUSE_APPLY");  // opt-in ("1"): measured neutral (fused_common.h), so every step is its own launch by default
+    const bool off = !(e && e[0] == '1');
+    return !off && h->layout == 4 && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
+}
+
 template <class T>
-static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid) {
+static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd, const PendingStep* pending) {
     FusedArgs<T> args;
     args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
     args.wg_tile_begin = h->wg_tile_begin;
@@ -471,6 +479,13 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.sell_r = h->sell_r;
     args.sell_f = static_cast<const T*>(h->sell_f);
     args.n_sell = (uint32_t)h->n_sell;
+    args.do_apply = 0;
+    args.apply = ApplyArgs<T>();
+    if (pending && pending->valid) {
+        if (!agd || !matching_can_fuse_apply(h) || agd->m != h->m || agd->val_dtype != h->val_dtype) return fail(DL_E_STATE, "this handle cannot apply an optimiser step in its prologue");
+        args.do_apply = 1;
+        args.apply = make_apply_args<T>(agd, *pending);
+    }
     if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
         // (the device-resident AGD loop leaves both prepared, common.h -- only honoured for the optimiser that prepared them)
         if (!(h->hot_ready && owner_uid != 0 && h->hot_ready_owner == owner_uid && h->hot_ready_lambda == lambda)) {
@@ -510,9 +525,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     return 0;
 }
 
-int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid) {
-    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st, owner_uid);
-    return fused_typed<double>(h, lambda, gamma, x_out, st, owner_uid);
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd, const PendingStep* pending) {
+    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st, owner_uid, agd, pending);
+    return fused_typed<double>(h, lambda, gamma, x_out, st, owner_uid, agd, pending);
 }
 
 
@@ -522,7 +537,7 @@ static int calculate_typed(dl_matching* h, const void* lambda, double gamma, dou
         DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
         return 0;
     }
-    int rc = fused_typed<T>(h, lambda, gamma, x_out, st, 0);
+    int rc = fused_typed<T>(h, lambda, gamma, x_out, st, 0, nullptr, nullptr);
     if (rc) return rc;
     return matching_reduce(h, packed_out, 0, nullptr, st, 0);
 }

@@ -198,3 +198,49 @@ def test_one_rank_sharded_loop_equals_single_device_loop(backend, blocks):
     g1 = f1.calculate(lam, gamma=0.02).dual_gradient
     g2 = fd.calculate(lam, gamma=0.02).dual_gradient
     assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dn", ["f32", "f64"])
+def test_step_applied_in_the_next_launch_prologue_is_bit_identical(dn):
+    """The optimiser step of iteration i rides the fused launch of iteration i + 1 (csrc/agd_step.h) unless
+    DUALIP_HIP_FUSE_APPLY=0 makes it its own launch: same arithmetic, so logs, duals, the primal, gamma continuation and calls in
+    chunks must agree bit for bit -- on the single-device loop and on the sharded one."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction, MatchingSolverDualObjectiveFunctionDistributed
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import load, problem, torch_args
+
+    z = load("g1_syn2000.npz")
+    p = problem(z)
+    n, m = p["n"], p["m"]
+    half = n // 2
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(half)), **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n))}
+    td = torch.float32 if dn == "f32" else torch.float64
+    mask = np.zeros(m, dtype=bool)
+    mask[::7] = True
+
+    def solve(fuse, sharded):
+        os.environ["DUALIP_HIP_FUSE_APPLY"] = "1" if fuse else "0"
+        try:
+            if sharded:
+                args = torch_args(p, dn, pm, "cuda:0", with_b=False, equality_mask=mask)
+                f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), 0.04, host_device="cuda:0", comm_backend="p2p")
+            else:
+                f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, pm, "cuda:0", equality_mask=mask), 0.04)
+            solver = AcceleratedGradientDescent(max_iter=45, gamma=0.04, initial_step_size=1e-3, max_step_size=0.1, gamma_decay_type="step",
+                                                gamma_decay_params={"decay_steps": 10, "decay_factor": 0.5}, save_primal=not sharded, iteration_callback=False)
+            run = solver.start_device_run(f, torch.zeros(m, dtype=td, device="cuda:0"))
+            for chunk in (1, 7, 20, 17):  # (a call ends with the step applied: chunked calls see a complete state)
+                run.advance(chunk)
+            res = run.finish()
+            run.close()
+            return res, solver.gamma
+        finally:
+            os.environ.pop("DUALIP_HIP_FUSE_APPLY", None)
+
+    for sharded in (False, True):
+        (ra, ga), (rb, gb) = solve(True, sharded), solve(False, sharded)
+        assert ra.dual_objective_log == rb.dual_objective_log and ra.step_size_log == rb.step_size_log and ga == gb
+        assert torch.equal(ra.dual_val, rb.dual_val) and torch.equal(ra.objective_result.dual_gradient, rb.objective_result.dual_gradient)
+        if not sharded:
+            assert torch.equal(ra.objective_result.primal_var, rb.objective_result.primal_var)
