@@ -327,19 +327,31 @@ class MIPLIB2017ObjectiveFunctionDistributed(BaseObjective):
 
     _dualip_native = True
 
-    def __init__(self, local_input_args: MIPLIBInputArgs, gamma: float, process_group=None):
+    def __init__(self, local_input_args: MIPLIBInputArgs, gamma: float, process_group=None, comm_backend=None):
         import torch.distributed as dist
 
         self._dist = dist
         self.local_objective = MIPLIB2017ObjectiveFunction(local_input_args, use_jacobi_precondition=False)
         self.gamma = gamma
         self.process_group = process_group
+        self.comm_backend = comm_backend
+        self._comm = None
         self.equality_mask = local_input_args.equality_mask
         self.device, self.dtype, self.m = self.local_objective.device, self.local_objective.dtype, self.local_objective.m
         self.b_vec = self.local_objective.b_vec.contiguous()
 
+    def communicator(self):
+        """The C library's communicator (dualip_amd/utils/comm.py: one-shot P2P exchange or RCCL), created on first use."""
+        if self._comm is None:
+            from dualip_amd.utils.comm import Communicator
+
+            self._comm = Communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
+        return self._comm
+
     def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
         if self._dist.is_available() and self._dist.is_initialized():
+            if packed.is_cuda:
+                return self.communicator().all_reduce_(packed)  # the ONE collective of an iteration, as for the matching objective
             self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self.process_group)
         return packed
 
