@@ -59,9 +59,18 @@ int sell_refill_costs(dl_matching* h, hipStream_t st);
 constexpr int kSellMaxLen = 24;  // sell.h: kSellMaxH
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
+constexpr int kReencLdsRows = 16384;  // rows whose histogram a workgroup keeps in LDS (64 KB)
 template <class SrcT, class DstT>
-__global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t m, int* __restrict__ bad,
-                                     unsigned int* __restrict__ row_count) {
+__global__ __launch_bounds__(256) void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, DstT* __restrict__ dst, int64_t m, int* __restrict__ bad,
+                                                            unsigned int* __restrict__ row_count) {
+    // one-off row histogram (bounds the fixed-point gradient accumulators): privatised per workgroup in LDS when the rows fit --
+    // 10^9 global atomics on 10^4 addresses made this kernel 67 ms of a 120 ms handle creation at 100M entities
+    __shared__ unsigned int sh[kReencLdsRows];
+    const bool in_lds = m <= kReencLdsRows;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < (int)m; i += blockDim.x) sh[i] = 0u;
+        __syncthreads();
+    }
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = (int64_t)src[k];
         if (r < 0 || r >= m) {
@@ -69,8 +78,14 @@ __global__ void reencode_rows_kernel(int64_t nnz, const SrcT* __restrict__ src, 
             dst[k] = 0;
         } else {
             dst[k] = (DstT)r;
-            atomicAdd(&row_count[r], 1u);  // one-off histogram: bounds the fixed-point gradient accumulators
+            if (in_lds) atomicAdd(&sh[r], 1u);
+            else atomicAdd(&row_count[r], 1u);
         }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)m; i += blockDim.x)
+            if (sh[i]) atomicAdd(&row_count[i], sh[i]);
     }
 }
 
