@@ -53,6 +53,7 @@ int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_
 int sell_finish(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const std::vector<uint8_t>& pid_sell, const std::vector<uint32_t>& desc,
                 hipStream_t st);
 int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell,
+                const std::vector<uint8_t>& pid_flat,
                 uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st);  // pack_build.hip
 int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
@@ -253,7 +254,7 @@ static void schedule_tiles4(std::vector<uint32_t>& words, std::vector<uint32_t>&
 // here; the entry's longer columns become single-column tiles (windows over such leftovers would stream mostly skipped data).
 static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs,
                        std::vector<uint32_t>& words, std::vector<uint64_t>& cost_prefix, std::vector<uint32_t>& tile_pid, int64_t* n_long,
-                       const std::vector<uint8_t>& pid_sell) {
+                       const std::vector<uint8_t>& pid_sell, const std::vector<uint8_t>& pid_flat) {
     auto weight = [&](uint32_t pj) -> uint64_t {
         if (pj == kNoProj || (int32_t)pj >= n_proj) return 10;
         const int k = projs[pj].kind;
@@ -306,13 +307,32 @@ static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int3
             continue;
         }
         const bool tail_quad = (uint64_t)k1 > nnz_al4;  // touches the array's last partial quad: no vector loads there
-        if (len > 253 || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
+        // point-wise entry (pid_flat; last element = columns with no entry): windows are cut every 256 non-zeros wherever they fall
+        const bool flat = !pid_flat.empty() && (pj == kNoProj ? pid_flat.back() != 0 : (pj < 254u && (size_t)pj + 1 < pid_flat.size() && pid_flat[pj]));
+        if ((len > 253 && !flat) || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
             flush();
             const uint64_t h4[4] = {(uint64_t)len, 0, 0, 0};
             emit((uint64_t)k0 | (1ull << 51), h4, pj);
             running += (uint64_t)len * weight(pj) * 3;
             cost_prefix.push_back(running);
             *n_long += 1;
+            continue;
+        }
+        if (flat) {
+            if (open && pj != cur_proj) flush();
+            uint64_t k = (uint64_t)k0;
+            while (k < (uint64_t)k1) {
+                if (!open) {
+                    open = true;
+                    W = k & ~3ull;
+                    lo = (uint32_t)(k - W);
+                    cur_proj = pj;
+                }
+                const uint64_t stop = (uint64_t)k1 < W + 256 ? (uint64_t)k1 : W + 256;
+                end = (uint32_t)(stop - W);
+                k = stop;
+                if (end == 256) flush();
+            }
             continue;
         }
         if (open && ((uint64_t)k1 > W + 256 || pj != cur_proj)) flush();
@@ -417,6 +437,17 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (const char* ms = getenv("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
         if (!(se && se[0] == '0')) CK(sell_prepare(h, colptr, idx_dtype, col_proj, projs_host, n_proj, min_share, pid_sell, sell_desc_h, st));
     }
+    // point-wise entries (box, cone, identity): their windows need not hold whole columns (pack_build.hip); DUALIP_HIP_FLAT=0 keeps
+    // whole-column windows.  Element n_proj: columns with no entry.
+    std::vector<uint8_t> pid_flat;
+    if (h->layout == 4 && !(getenv("DUALIP_HIP_FLAT") && getenv("DUALIP_HIP_FLAT")[0] == '0')) {
+        pid_flat.assign((size_t)n_proj + 1, 0);
+        for (int32_t q = 0; q < n_proj; ++q) {
+            const int k = projs_host[q].kind;
+            pid_flat[(size_t)q] = (k != DL_PROJ_SIMPLEX && k != DL_PROJ_SIMPLEX_EQ) ? 1 : 0;
+        }
+        pid_flat[(size_t)n_proj] = 1;
+    }
     phase("slice plan");
     // Window tiles are packed on the device (pack_build.hip) unless the map has BOTH instruction-bound window tiles (a simplex
     // entry that is not sliced) and memory-bound ones -- those want the host's interleaved schedule (schedule_tiles4) -- or
@@ -484,14 +515,14 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     } win_guard{win_dev};
     if (dev_pack) {
         std::vector<uint32_t> long_list;
-        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, &win_dev, &n_win_dev, long_list, used_dev, st));
+        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, pid_flat, &win_dev, &n_win_dev, long_list, used_dev, st));
         words4 = long_list;  // single-column tiles only; split / ordered below
         for (size_t t = 0; t < long_list.size() / 12; ++t) tile_pid4.push_back(long_list[t * 12 + 10] == 0xFFFFFFFFu ? kNoProj : long_list[t * 12 + 10]);
         h->n_long = (int64_t)(long_list.size() / 12);
         h->n_tiles = n_win_dev + h->n_long;
         prefix.assign(1, 0);
     } else if (h->layout == 4) {
-        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell));
+        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell, pid_flat));
         h->n_tiles = (int64_t)(words4.size() / 12);
     } else {
         CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));

@@ -129,7 +129,7 @@ struct dl_comm {
     unsigned long long seq = 0;                   // exchanges issued
     unsigned int* counter = nullptr;              // owned
     int* dead = nullptr;                          // owned
-    unsigned long long timeout_ticks = 500000000ull;  // 5 s at 100 MHz
+    unsigned long long timeout_ticks = 2000000000ull;  // 20 s at 100 MHz
     double* scratch = nullptr;                    // owned, double[stride]: result staging of the stand-alone all-reduce
     // measurement (dl_comm_profile): event pairs around the exchanges of dl_agd_run_matching_sharded
     bool prof_on = false;

@@ -2,7 +2,9 @@
 //
 // Same computation and LDS plan as matching_kernels.hip; what changes is the tile:
 //   * a tile is a 16-byte-aligned window of 256 non-zeros [W, W+256) holding whole consecutive columns in
-//     [W+lo, W+hi); lane L owns elements 4L..4L+3, fetched with ONE 16-byte load per array (a, c) and one 8-byte
+//     [W+lo, W+hi) -- or, for point-wise projection entries (box, cone, identity), simply the next <= 256 non-zeros of the
+//     entry's run of columns, cut wherever they fall (no window then re-reads the tail of its predecessor: -4 % HBM
+//     traffic and time on an all-box map); lane L owns elements 4L..4L+3, fetched with ONE 16-byte load per array (a, c) and one 8-byte
 //     load of four uint16 row indices -- a quarter of the load instructions and descriptor traffic per non-zero;
 //   * per-tile fixed costs (descriptor unpack, loop control) amortise over 4x the work, and the four slots of a lane
 //     are independent dependency chains for the element-wise part;

@@ -1,8 +1,9 @@
 // pack_build.hip -- the window tiles of the 256-wide layout packed ON THE DEVICE (dl_matching_create).
 //
 // The packing rule is the greedy one of api.hip:pack_tiles4 -- a 16-byte aligned window of <= 256 non-zeros holding whole
-// consecutive columns of one projection entry; columns that cannot sit in a window become single-column tiles; columns that
-// live in column-per-lane slices (sell.h) are skipped -- but the column range is cut into fixed chunks that are packed
+// consecutive columns of one projection entry (point-wise entries: simply the next 256 non-zeros of the entry's run of columns,
+// pid_flat); columns that cannot sit in a window become single-column tiles; columns that live in column-per-lane slices
+// (sell.h) are skipped -- but the column range is cut into fixed chunks that are packed
 // independently, one thread per chunk (a window never spans a chunk boundary: +0.5 % windows at the benchmark's shape).  Two
 // passes over the column pointers (count, exclusive scan, write) replace what used to be the dominant part of handle creation at
 // 100M entities: 0.8 GB of column pointers / projection ids copied to the host (340 ms) and a single-threaded host loop over
@@ -87,17 +88,38 @@ __device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, 
             continue;
         }
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
-        const bool sliced = pj != kNoProj && pj < 255u && pid_sell[pj];
+        const uint8_t fl = pid_sell[pj == kNoProj ? 255u : (pj < 255u ? pj : 254u)];  // bit 0: sliced entry, bit 1: point-wise entry (flat windows)
+        const bool sliced = pj != kNoProj && pj < 255u && (fl & 1u);
+        const bool flat = (pj == kNoProj || pj < 254u) && (fl & 2u);
         if (sliced && len <= kPackSellMaxLen) {
             flush();  // (a window holds consecutive columns only)
             continue;
         }
         if constexpr (!WRITE) used[pj == kNoProj ? (uint32_t)n_proj : pj] = 1;
         const bool tail_quad = (uint64_t)k1 > nnz_al4;  // touches the array's last partial quad: no vector loads there
-        if (len > 253 || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
+        if ((len > 253 && !flat) || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
             flush();
             if constexpr (WRITE) emit12(long_out + (size_t)n_long * 12, (uint64_t)kc | (1ull << 51), (uint64_t)len, 0, 0, 0, pj);
             n_long += 1;
+            continue;
+        }
+        if (flat) {
+            // point-wise entry: the projection does not see column boundaries, so windows are cut every 256 non-zeros wherever
+            // they fall -- no window re-reads the tail of its predecessor, and a long column is just more of the stream
+            if (open && pj != cur_proj) flush();
+            uint64_t k = (uint64_t)kc;
+            while (k < (uint64_t)k1) {
+                if (!open) {
+                    open = true;
+                    W = k & ~3ull;
+                    lo = (uint32_t)(k - W);
+                    cur_proj = pj;
+                }
+                const uint64_t stop = (uint64_t)k1 < W + 256 ? (uint64_t)k1 : W + 256;
+                end = (uint32_t)(stop - W);
+                k = stop;
+                if (end == 256) flush();
+            }
             continue;
         }
         if (open && ((uint64_t)k1 > W + 256 || pj != cur_proj)) flush();
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(64) void pack_write_kernel(int64_t n, int64_t nnz, 
 
 template <class IdxT>
 static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell_h,
-                             uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used_h, hipStream_t st) {
+                             const std::vector<uint8_t>& pid_flat_h, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used_h, hipStream_t st) {
     *win_dev_out = nullptr;
     *n_win_out = 0;
     long_words.clear();
@@ -159,7 +181,9 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
         if (!keep_win && win) (void)hipFree(win);
     };
     std::vector<uint8_t> flags_h(256, 0);
-    for (size_t q = 0; q < pid_sell_h.size() && q < 256; ++q) flags_h[q] = pid_sell_h[q];
+    for (size_t q = 0; q < pid_sell_h.size() && q < 255; ++q) flags_h[q] = pid_sell_h[q] ? 1 : 0;
+    for (size_t q = 0; q < pid_flat_h.size() && q < 254; ++q) flags_h[q] |= pid_flat_h[q] ? 2 : 0;
+    if (!pid_flat_h.empty() && pid_flat_h.back()) flags_h[255] = 2;  // last element: columns with no projection entry
     PackErr err_h = {0, 0, (long long)n};
     hipError_t e = hipMalloc((void**)&counts, sizeof(unsigned long long) * (size_t)(n_chunks + 1));
     if (e == hipSuccess) e = hipMalloc((void**)&offsets, sizeof(unsigned long long) * (size_t)(n_chunks + 1));
@@ -221,12 +245,13 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
 }
 
 // Window descriptors stay on the device (*win_dev_out, 12 dwords each, memory order; the caller frees it); the single-column
-// tiles come back to the host (they are few, and the caller orders them longest first).  used[q] != 0: entry q has a window or
+// tiles come back to the host (they are few, and the caller orders them longest first).  pid_flat[q] != 0: entry q is point-wise
+// (its last element, index n_proj: columns with no entry).  used[q] != 0: entry q has a window or
 // single-column tile (used[n_proj]: a column with no entry has one).
 int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell,
-                uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st) {
-    if (idx_dtype == DL_I64) return pack_device_typed<int64_t>(n, nnz, (const int64_t*)colptr, col_proj, n_proj, pid_sell, win_dev_out, n_win_out, long_words, used, st);
-    return pack_device_typed<int32_t>(n, nnz, (const int32_t*)colptr, col_proj, n_proj, pid_sell, win_dev_out, n_win_out, long_words, used, st);
+                const std::vector<uint8_t>& pid_flat, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st) {
+    if (idx_dtype == DL_I64) return pack_device_typed<int64_t>(n, nnz, (const int64_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, win_dev_out, n_win_out, long_words, used, st);
+    return pack_device_typed<int32_t>(n, nnz, (const int32_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, win_dev_out, n_win_out, long_words, used, st);
 }
 
 }  // namespace dl

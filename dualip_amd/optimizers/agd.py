@@ -252,6 +252,9 @@ class DeviceRun:
                 )
             )
 
+        if self.native_sharded:
+            f.communicator().rendezvous()  # the in-kernel waits of the exchange are bounded: start the ranks together
+
     def close(self):
         if self.state is not None and self.state.value:
             self.lib.dl_agd_destroy(self.state)

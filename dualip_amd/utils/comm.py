@@ -142,6 +142,12 @@ class Communicator:
             _hip.check(self.lib.dl_allreduce_sum(self.handle, _hip.ptr(buf), buf.numel(), _hip.stream_ptr(self.device)))
         return buf
 
+    def rendezvous(self) -> None:
+        """Host-side meeting of the ranks (through the process group, not the device): called once before a device-resident
+        solve so that the first in-kernel wait of the P2P exchange starts with the ranks milliseconds, not a handle creation,
+        apart -- the in-kernel waits are bounded (20 s, DUALIP_COMM_TIMEOUT_MS)."""
+        _gather(0, self.group, self.world)
+
     def check(self) -> None:
         """Synchronise and raise if a P2P wait ever timed out."""
         with torch.cuda.device(self.device):

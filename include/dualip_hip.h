@@ -229,7 +229,7 @@ int64_t dl_comm_info(const dl_comm* c, int what);
  * issue the same sequence of exchanges on a communicator. */
 int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream);
 /* Synchronises `stream` and reports whether a P2P exchange ever timed out waiting for a rank (DL_E_STATE; waits are bounded --
- * 5 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device). */
+ * 20 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device). */
 int dl_comm_check(dl_comm* c, dl_stream_t stream);
 /* Developer aid: multiply every exchanged sum by `scale` (one rank standing in for W equal shards). */
 int dl_comm_set_emulation(dl_comm* c, double scale);

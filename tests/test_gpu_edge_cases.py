@@ -151,7 +151,55 @@ def test_long_columns_empty_columns_and_nested_ranges():
     col_proj[0:1000], col_proj[1000:1800], col_proj[2500:4000] = 0, 1, 2
     for dn in ("f32", "f64"):
         f = _compare(p, pm, entries, col_proj, 0.03, dn, lam)
-        assert f.info()["long_columns"] >= 4
+        # (column 1999 is in no entry: point-wise columns of any length are part of the window stream, not single-column tiles)
+        assert f.info()["long_columns"] >= 3
+
+
+@pytest.mark.parametrize("host_pack", [False, True])
+def test_pointwise_windows_cut_through_columns(host_pack, monkeypatch):
+    """Box / cone / no-entry columns are streamed in windows of 256 non-zeros that ignore column boundaries (columns of 1 to 5000
+    non-zeros, entries changing mid-window, empty columns): same numbers as the oracle, and -- the gradient being summed in
+    integer fixed point -- the same BITS as a handle built with whole-column windows (DUALIP_HIP_FLAT=0)."""
+    import os
+
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
+        pytest.skip("the 64-wide layout has no windows")
+    if host_pack:
+        monkeypatch.setenv("DUALIP_HIP_HOST_PACK", "1")
+    m, n = 3_000, 5_000
+    p = _random_problem(m, n, 12, seed=77, long_cols=((0, 700), (3, 256), (4, 1), (900, 3000), (901, 2999), (2400, 255), (2401, 257), (4200, 1023), (4999, 300)),
+                        empty_every=9)
+    lam = np.random.default_rng(12).uniform(0, 0.02, m)
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.05, "upper": 0.6}, indices=list(range(0, 1500))),
+        "cone": ProjectionEntry("cone", {"lower": 0.1}, indices=list(range(1500, 2400))),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(2400, 3000))),
+        "box2": ProjectionEntry("box", {"lower": 0.0, "upper": 0.3}, indices=list(range(3000, 4000))),
+        # 4000..4999: in no entry
+    }
+    entries = [("box", {"lower": 0.05, "upper": 0.6}), ("cone", {"lower": 0.1}), ("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.3})]
+    col_proj = np.full(n, -1, dtype=np.int32)
+    col_proj[0:1500], col_proj[1500:2400], col_proj[2400:3000], col_proj[3000:4000] = 0, 1, 2, 3
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.04, dn, lam)
+        td = torch.float32 if dn == "f32" else torch.float64
+        lam_t = torch.from_numpy(lam).to(td).to(DEV)
+        got = f.calculate(lam_t, save_primal=True)
+        g1, x1 = got.dual_gradient.clone(), got.primal_var.clone()
+        monkeypatch.setenv("DUALIP_HIP_FLAT", "0")
+        whole = MatchingSolverDualObjectiveFunction(torch_args(p, dn, pm, DEV), gamma=0.04)
+        monkeypatch.delenv("DUALIP_HIP_FLAT")
+        assert whole.info()["long_columns"] > f.info()["long_columns"]
+        ref = whole.calculate(lam_t, save_primal=True)
+        assert torch.equal(ref.primal_var, x1)
+        assert torch.equal(ref.dual_gradient, g1)
+    # with the hot-rows plan (rows beyond the first 1024 gather / scatter through memory)
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "1024")
+    f = _compare(p, pm, entries, col_proj, 0.04, "f32", lam)
+    assert f.info()["hot_rows"] == 1024
 
 
 def test_all_columns_empty():
@@ -288,6 +336,7 @@ def test_hot_rows_with_single_column_tiles_and_primal(monkeypatch):
     from dualip_amd.projections import create_projection_map
 
     monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "192")
+    monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the single-column walker is the subject: keep long point-wise columns out of the window stream
     p = _random_problem(900, 3_000, 10, seed=55, long_cols=((3, 400), (1500, 700), (2999, 260)), empty_every=17)
     lam = np.random.default_rng(9).uniform(0, 0.02, p["m"])
     for dn in ("f32", "f64"):
@@ -312,6 +361,7 @@ def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
 
     if forced:
         monkeypatch.setenv("DUALIP_HIP_XLONG_MIN", "256")
+    monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the walkers are the subject: keep long point-wise columns out of the window stream
     m, n = 10_000, 3_000
     long_cols = ((2, 9000), (700, 3000), (1500, 2049), (2999, 2048), (5, 600), (2000, 5000))
     p = _random_problem(m, n, 10, seed=77, long_cols=long_cols, empty_every=19)

@@ -123,6 +123,7 @@ def test_kernel_form_through_single_column_tiles_and_the_hot_rows_plan(hot, monk
         pytest.skip("64-wide layout forced")
     if hot:
         monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "512")
+    monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the walkers are the subject: keep long point-wise columns out of the window stream
     p = _random_problem(3_500, 2_500, 10, seed=91, long_cols=((3, 400), (1200, 700), (2400, 3000), (2499, 260)), empty_every=23)
     m, n = p["m"], p["n"]
     rng = np.random.default_rng(12)
