@@ -118,22 +118,30 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     const T th0 = (T)(mx - pj.z);
     T theta0 = th0;
     if (!(g.ablate & 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
-    T sum = (T)0, cnt = (T)0;
+    // (supports are counted in integers: the compiler folds two members' worth of compare masks into one add-with-carry, so a
+    //  step of a pass costs four vector instructions -- compare, select, add, count -- instead of five with a float counter)
+#ifdef DL_X_INT
+    typedef uint32_t CntT;
+#else
+    typedef T CntT;
+#endif
+    T sum = (T)0;
+    CntT cnt = (CntT)0;
 #pragma unroll
     for (int t = 0; t < HM; ++t) {
         const bool in = u[t] > theta0;
-        sum = in ? (T)(sum + u[t]) : sum;
-        cnt = in ? (T)(cnt + (T)1) : cnt;
+        sum = (T)(sum + (in ? u[t] : (T)0));
+        cnt += in ? (CntT)1 : (CntT)0;
     }
     // column state: theta (0 = keep the clamped values), vertex flag
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
     const bool keep = ineq && !(sall > pj.ztol);  // feasible after the clamp (simplex.py:153-158: the sum of the whole column)
-    bool vertex = !keep && cnt == (T)1;
+    bool vertex = !keep && cnt == (CntT)1;
     T theta = (T)0;
     bool act = false;
     if (!keep) {
-        theta = div_exactish((T)(sum - pj.z), cnt > (T)0 ? cnt : (T)1);
-        act = cnt > (T)2;  // a support of two is final: the runner-up stays above (sum - z)/2 exactly when it is above max - z
+        theta = div_exactish((T)(sum - pj.z), (T)(cnt > (CntT)0 ? cnt : (CntT)1));
+        act = cnt > (CntT)2;  // a support of two is final: the runner-up stays above (sum - z)/2 exactly when it is above max - z
     }
     if (eq_row) {  // simplex_eq reference-compatibility mode (cold): a deficit is spread over the padded block height
         if (pj.kind == DL_PROJ_SIMPLEX_EQ && sall < pj.z) {
@@ -145,17 +153,18 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     }
     theta = tmax(theta, keep ? (T)0 : theta0);  // (sum - z)/cnt >= theta_0 in exact arithmetic: keep it so under rounding (nested supports)
     theta = vertex ? theta0 : theta;  // (the threshold the single member was counted at)
-    T cprev = cnt;
+    CntT cprev = cnt;
     for (int it = 0; it < kSellMaxH + 2 && __any(act); ++it) {
-        T s2 = (T)0, c2 = (T)0;
+        T s2 = (T)0;
+        CntT c2 = (CntT)0;
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             const bool in = u[t] > theta;
-            s2 = in ? (T)(s2 + u[t]) : s2;
-            c2 = in ? (T)(c2 + (T)1) : c2;
+            s2 = (T)(s2 + (in ? u[t] : (T)0));
+            c2 += in ? (CntT)1 : (CntT)0;
         }
-        const bool changed = act && c2 != cprev && c2 > (T)0;
-        const T tn = div_exactish((T)(s2 - pj.z), c2 > (T)0 ? c2 : (T)1);
+        const bool changed = act && c2 != cprev && c2 > (CntT)0;
+        const T tn = div_exactish((T)(s2 - pj.z), (T)(c2 > (CntT)0 ? c2 : (CntT)1));
         theta = changed ? tmax(theta, tn) : theta;  // thresholds never decrease: nested supports, guaranteed termination
         cprev = changed ? c2 : cprev;
         act = changed;
@@ -164,8 +173,12 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     T o32 = (T)0, q32 = (T)0, f32 = (T)0;
     auto finish = [&](int t, T at, T ct, uint32_t rt, T ft) {
         const T xg = relu((T)(u[t] - theta));
+#ifdef DL_X_VERT
+        const T x = (vertex && u[t] > theta) ? pj.z : xg;  // vertex: exact z at the maximum, as the reference (xg is 0 at its other members)
+#else
         const T xv = (u[t] > theta) ? pj.z : (T)0;  // vertex: exact z at the maximum, as the reference
         const T x = vertex ? xv : xg;
+#endif
         const T ax = (T)(at * x);
         if (ax != (T)0) {
             if constexpr (HOT) {
@@ -185,11 +198,24 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     uint64_t k0 = 0;
     if (xo && has_col) k0 = gk.sell_colstart[dense];
     if constexpr (!RELOAD) {
+#ifdef DL_X_HOIST
+        if (xo) {  // (primal requested: the last iteration of a solve at most)
+#pragma unroll
+            for (int t = 0; t < HM; ++t) {
+                const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
+                if (has_col && t < len) xo[k0 + (uint64_t)t] = x;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < HM; ++t) finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
             if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
         }
+#endif
     } else {
 #pragma unroll
         for (int t0 = 0; t0 < HM; t0 += CH) {
@@ -256,13 +282,29 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
         // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
-        switch (sell_chunks(H)) {
-            case 1: sell_slice<T, RowT, 4, R4, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break;
-            case 2: sell_slice<T, RowT, 8, R8, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break;
-            case 3: sell_slice<T, RowT, 12, R12, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break;
-            case 4: sell_slice<T, RowT, 16, R16, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break;
-            default: sell_slice<T, RowT, 24, true, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break;
+#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break
+        // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
+        // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
+        // non-zeros per column that padding was ~13 % of the slices' vector instructions.  The others step by four.
+        constexpr bool kExact = sizeof(T) == 4 && !FAIR;
+        const int hv = (kExact && !(g.ablate & 64) && H > 4 && H <= 16) ? H : 4 * sell_chunks(H);  // (DUALIP_HIP_ABLATE=64: steps of four everywhere)
+        switch (hv) {
+            case 4: DL_SELL_CASE(4, R4);
+            case 5: DL_SELL_CASE(kExact ? 5 : 8, R8);
+            case 6: DL_SELL_CASE(kExact ? 6 : 8, R8);
+            case 7: DL_SELL_CASE(kExact ? 7 : 8, R8);
+            case 8: DL_SELL_CASE(8, R8);
+            case 9: DL_SELL_CASE(kExact ? 9 : 12, R12);
+            case 10: DL_SELL_CASE(kExact ? 10 : 12, R12);
+            case 11: DL_SELL_CASE(kExact ? 11 : 12, R12);
+            case 12: DL_SELL_CASE(12, R12);
+            case 13: DL_SELL_CASE(kExact ? 13 : 16, R16);
+            case 14: DL_SELL_CASE(kExact ? 14 : 16, R16);
+            case 15: DL_SELL_CASE(kExact ? 15 : 16, R16);
+            case 16: DL_SELL_CASE(16, R16);
+            default: DL_SELL_CASE(24, true);
         }
+#undef DL_SELL_CASE
     }
 }
 
