@@ -120,11 +120,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     if (!(g.ablate & 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
     // (supports are counted in integers: the compiler folds two members' worth of compare masks into one add-with-carry, so a
     //  step of a pass costs four vector instructions -- compare, select, add, count -- instead of five with a float counter)
-#ifdef DL_X_INT
     typedef uint32_t CntT;
-#else
-    typedef T CntT;
-#endif
     T sum = (T)0;
     CntT cnt = (CntT)0;
 #pragma unroll
@@ -173,12 +169,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     T o32 = (T)0, q32 = (T)0, f32 = (T)0;
     auto finish = [&](int t, T at, T ct, uint32_t rt, T ft) {
         const T xg = relu((T)(u[t] - theta));
-#ifdef DL_X_VERT
         const T x = (vertex && u[t] > theta) ? pj.z : xg;  // vertex: exact z at the maximum, as the reference (xg is 0 at its other members)
-#else
-        const T xv = (u[t] > theta) ? pj.z : (T)0;  // vertex: exact z at the maximum, as the reference
-        const T x = vertex ? xv : xg;
-#endif
         const T ax = (T)(at * x);
         if (ax != (T)0) {
             if constexpr (HOT) {
@@ -198,24 +189,13 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     uint64_t k0 = 0;
     if (xo && has_col) k0 = gk.sell_colstart[dense];
     if constexpr (!RELOAD) {
-#ifdef DL_X_HOIST
-        if (xo) {  // (primal requested: the last iteration of a solve at most)
-#pragma unroll
-            for (int t = 0; t < HM; ++t) {
-                const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
-                if (has_col && t < len) xo[k0 + (uint64_t)t] = x;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < HM; ++t) finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
-        }
-#else
+        // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
+        //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
             if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
         }
-#endif
     } else {
 #pragma unroll
         for (int t0 = 0; t0 < HM; t0 += CH) {
