@@ -309,6 +309,7 @@ static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int3
         const bool tail_quad = (uint64_t)k1 > nnz_al4;  // touches the array's last partial quad: no vector loads there
         // point-wise entry (pid_flat; last element = columns with no entry): windows are cut every 256 non-zeros wherever they fall
         const bool flat = !pid_flat.empty() && (pj == kNoProj ? pid_flat.back() != 0 : (pj < 254u && (size_t)pj + 1 < pid_flat.size() && pid_flat[pj]));
+        const bool flat_align = flat && (pj == kNoProj ? pid_flat.back() : pid_flat[pj]) == 2;
         if ((len > 253 && !flat) || tail_quad || sliced || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
             flush();
             const uint64_t h4[4] = {(uint64_t)len, 0, 0, 0};
@@ -328,10 +329,13 @@ static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int3
                     lo = (uint32_t)(k - W);
                     cur_proj = pj;
                 }
-                const uint64_t stop = (uint64_t)k1 < W + 256 ? (uint64_t)k1 : W + 256;
+                // cut at absolute multiples of 256 non-zeros: every window but a run's first then covers whole 128-byte lines of
+                // the three arrays (1 KB / 1 KB / 512 B spans), none shared with its neighbours
+                const uint64_t cut = flat_align ? ((W + 256) & ~255ull) : W + 256;
+                const uint64_t stop = (uint64_t)k1 < cut ? (uint64_t)k1 : cut;
                 end = (uint32_t)(stop - W);
                 k = stop;
-                if (end == 256) flush();
+                if (W + end == cut) flush();
             }
             continue;
         }
@@ -440,13 +444,15 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // point-wise entries (box, cone, identity): their windows need not hold whole columns (pack_build.hip); DUALIP_HIP_FLAT=0 keeps
     // whole-column windows.  Element n_proj: columns with no entry.
     std::vector<uint8_t> pid_flat;
-    if (h->layout == 4 && !(getenv("DUALIP_HIP_FLAT") && getenv("DUALIP_HIP_FLAT")[0] == '0')) {
+    const char* flat_env = getenv("DUALIP_HIP_FLAT");  // 0: whole-column windows everywhere; 1: cut every 256 from the run's start; default: at multiples of 256
+    if (h->layout == 4 && !(flat_env && flat_env[0] == '0')) {
+        const uint8_t mode = (flat_env && flat_env[0] == '1') ? 1 : 2;
         pid_flat.assign((size_t)n_proj + 1, 0);
         for (int32_t q = 0; q < n_proj; ++q) {
             const int k = projs_host[q].kind;
-            pid_flat[(size_t)q] = (k != DL_PROJ_SIMPLEX && k != DL_PROJ_SIMPLEX_EQ) ? 1 : 0;
+            pid_flat[(size_t)q] = (k != DL_PROJ_SIMPLEX && k != DL_PROJ_SIMPLEX_EQ) ? mode : 0;
         }
-        pid_flat[(size_t)n_proj] = 1;
+        pid_flat[(size_t)n_proj] = mode;
     }
     phase("slice plan");
     // Window tiles are packed on the device (pack_build.hip) unless the map has BOTH instruction-bound window tiles (a simplex

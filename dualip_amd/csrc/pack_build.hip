@@ -88,9 +88,10 @@ __device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, 
             continue;
         }
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
-        const uint8_t fl = pid_sell[pj == kNoProj ? 255u : (pj < 255u ? pj : 254u)];  // bit 0: sliced entry, bit 1: point-wise entry (flat windows)
+        const uint8_t fl = pid_sell[pj == kNoProj ? 255u : (pj < 255u ? pj : 254u)];  // bit 0: sliced entry, bit 1: point-wise entry (flat windows), bit 2: cut at multiples of 256
         const bool sliced = pj != kNoProj && pj < 255u && (fl & 1u);
         const bool flat = (pj == kNoProj || pj < 254u) && (fl & 2u);
+        const bool flat_align = (fl & 4u) != 0;
         if (sliced && len <= kPackSellMaxLen) {
             flush();  // (a window holds consecutive columns only)
             continue;
@@ -115,10 +116,13 @@ __device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, 
                     lo = (uint32_t)(k - W);
                     cur_proj = pj;
                 }
-                const uint64_t stop = (uint64_t)k1 < W + 256 ? (uint64_t)k1 : W + 256;
+                // cut at absolute multiples of 256 non-zeros: every window but a run's first then covers whole 128-byte lines of
+                // the three arrays (1 KB / 1 KB / 512 B spans), none shared with its neighbours
+                const uint64_t cut = flat_align ? ((W + 256) & ~255ull) : W + 256;
+                const uint64_t stop = (uint64_t)k1 < cut ? (uint64_t)k1 : cut;
                 end = (uint32_t)(stop - W);
                 k = stop;
-                if (end == 256) flush();
+                if (W + end == cut) flush();
             }
             continue;
         }
@@ -182,8 +186,8 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
     };
     std::vector<uint8_t> flags_h(256, 0);
     for (size_t q = 0; q < pid_sell_h.size() && q < 255; ++q) flags_h[q] = pid_sell_h[q] ? 1 : 0;
-    for (size_t q = 0; q < pid_flat_h.size() && q < 254; ++q) flags_h[q] |= pid_flat_h[q] ? 2 : 0;
-    if (!pid_flat_h.empty() && pid_flat_h.back()) flags_h[255] = 2;  // last element: columns with no projection entry
+    for (size_t q = 0; q < pid_flat_h.size() && q < 254; ++q) flags_h[q] |= pid_flat_h[q] ? (pid_flat_h[q] == 2 ? 6 : 2) : 0;
+    if (!pid_flat_h.empty() && pid_flat_h.back()) flags_h[255] = pid_flat_h.back() == 2 ? 6 : 2;  // last element: columns with no projection entry
     PackErr err_h = {0, 0, (long long)n};
     hipError_t e = hipMalloc((void**)&counts, sizeof(unsigned long long) * (size_t)(n_chunks + 1));
     if (e == hipSuccess) e = hipMalloc((void**)&offsets, sizeof(unsigned long long) * (size_t)(n_chunks + 1));
