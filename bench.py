@@ -361,7 +361,7 @@ def verify_at_size(args, inp, pm_local, f, local, lam, rank, world, sharded, dev
         note("sharded route (two blocks + exchange, world 1) against the single objective: gradient",
              float((r_sh.dual_gradient.double() - g1).abs().max() / g1.abs().max().clamp_min(1e-30)), 1e-6 if args.dtype == "f32" else 1e-12)
         note("... dual objective", abs(float(r_sh.dual_objective) - float(r_1.dual_objective)) / max(abs(float(r_1.dual_objective)), 1e-30), 1e-6 if args.dtype == "f32" else 1e-12)
-        out["sharded_backend"] = fd.communicator().backend
+        out["sharded_backend"] = fd.communicator().backend if fd.communicator() is not None else "torch.distributed"
         del fd, blocks
     else:
         ours = f.calculate_packed(lam, gamma).clone()
@@ -450,8 +450,8 @@ def main():
             bi.b_vec = None
         f = MatchingSolverDualObjectiveFunctionDistributed(block_inputs if nb > 1 else block_inputs[0], b_vec, args.gamma, host_device=device, comm_backend=args.comm)
         local = f.local_objective
-        comm = f.communicator()
-        if emu:
+        comm = f.communicator()  # (None: no native exchange here -- torch.distributed from Python, aux.collective says why)
+        if emu and comm is not None:
             comm.set_emulation(float(emu))
     else:
         f = MatchingSolverDualObjectiveFunction(inp, args.gamma)
@@ -607,6 +607,8 @@ def main():
             out["aux"]["collective"] = {**comm.info(), "emulated_world": emu or None, "exchanges": comm.exchanges,
                                         "us_per_exchange": (xms / xn * 1e3) if xn else None,
                                         "bracket": "end of the fused pass -> end of the step's first kernel (slab reduction + exchange + gradient statistics)"}
+        elif sharded:
+            out["aux"]["collective"] = {"backend": "torch.distributed", "fallback_reason": getattr(f, "comm_fallback", None)}
         if world == 1 and not args.no_cpu_baseline:
             inp.b_vec = b_vec
             out["cpu_baseline"] = cpu_baseline(args, inp, pm_local, total_nnz)

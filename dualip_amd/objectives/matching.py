@@ -424,6 +424,7 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
         self.process_group = process_group
         self.comm_backend = comm_backend
         self._comm = None
+        self.comm_fallback = None  # why there is no native exchange (communicator() returned None)
         self.more_blocks = []
         if local_objective is None:
             for args in blocks_args:
@@ -459,12 +460,15 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
 
     # ---- the exchange ---------------------------------------------------------------------------------------
     def communicator(self):
-        """The C library's communicator for this objective's device (created on first use: a collective call)."""
+        """The C library's communicator for this objective's device (dualip_amd/utils/comm.py: one-shot P2P exchange or RCCL),
+        created on first use -- a collective call.  None when neither back-end could be set up (``comm_fallback`` says why):
+        the exchange then goes through torch.distributed."""
         if self._comm is None:
-            from dualip_amd.utils.comm import Communicator
+            from dualip_amd.utils.comm import make_communicator
 
-            self._comm = Communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
-        return self._comm
+            comm, why = make_communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
+            self._comm, self.comm_fallback = (comm, None) if comm is not None else (False, why)
+        return self._comm or None
 
     def block_handles(self):
         """ctypes array of the kernel handles of this rank's blocks (for dl_agd_run_matching_sharded)."""
@@ -472,7 +476,7 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
         return (ctypes.c_void_p * len(objs))(*[o._handle for o in objs]), len(objs)
 
     def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
-        if packed.is_cuda and hasattr(self.local_objective, "_handle"):
+        if packed.is_cuda and hasattr(self.local_objective, "_handle") and self.communicator() is not None:
             return self.communicator().all_reduce_(packed)  # the ONE collective of an iteration
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.process_group)

@@ -336,21 +336,25 @@ class MIPLIB2017ObjectiveFunctionDistributed(BaseObjective):
         self.process_group = process_group
         self.comm_backend = comm_backend
         self._comm = None
+        self.comm_fallback = None  # why there is no native exchange (communicator() returned None)
         self.equality_mask = local_input_args.equality_mask
         self.device, self.dtype, self.m = self.local_objective.device, self.local_objective.dtype, self.local_objective.m
         self.b_vec = self.local_objective.b_vec.contiguous()
 
     def communicator(self):
-        """The C library's communicator (dualip_amd/utils/comm.py: one-shot P2P exchange or RCCL), created on first use."""
+        """The C library's communicator for this objective's device (dualip_amd/utils/comm.py: one-shot P2P exchange or RCCL),
+        created on first use -- a collective call.  None when neither back-end could be set up (``comm_fallback`` says why):
+        the exchange then goes through torch.distributed."""
         if self._comm is None:
-            from dualip_amd.utils.comm import Communicator
+            from dualip_amd.utils.comm import make_communicator
 
-            self._comm = Communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
-        return self._comm
+            comm, why = make_communicator(self.m + 2, self.device, group=self.process_group, backend=self.comm_backend)
+            self._comm, self.comm_fallback = (comm, None) if comm is not None else (False, why)
+        return self._comm or None
 
     def _exchange(self, packed: torch.Tensor) -> torch.Tensor:
         if self._dist.is_available() and self._dist.is_initialized():
-            if packed.is_cuda:
+            if packed.is_cuda and self.communicator() is not None:
                 return self.communicator().all_reduce_(packed)  # the ONE collective of an iteration, as for the matching objective
             self._dist.all_reduce(packed, op=self._dist.ReduceOp.SUM, group=self.process_group)
         return packed

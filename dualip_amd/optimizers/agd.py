@@ -223,6 +223,8 @@ class DeviceRun:
             self.sharded and hasattr(f, "block_handles") and hasattr(self.local, "_handle") and not getattr(f, "_needs_dual_tensor", False)
             and self.local.device.type == "cuda" and os.environ.get("DUALIP_SHARDED_LOOP", "c") != "python"
         )
+        if self.native_sharded and f.communicator() is None:  # (collective; no native exchange on this machine: per-iteration route)
+            self.native_sharded = False
         if not self.sharded and f.b_vec is None:
             raise ValueError("a matching objective built with b_vec=None only provides local partial sums; wrap it in the distributed objective")
         self.device, self.dtype, self.m = self.local.device, self.local.dtype, self.local.m

@@ -112,14 +112,23 @@ class Communicator:
         return True, None
 
     def _make_rccl(self):
+        """Every rank raises, or none does: a rank that cannot load RCCL must not leave the others inside ncclCommInitRank."""
         lib = self.lib
         uid = (ctypes.c_ubyte * 128)()
-        if self.rank == 0:
-            _hip.check(lib.dl_comm_rccl_unique_id(uid))
-        ids = _gather(bytes(uid), self.group, self.world)
-        blob = (ctypes.c_ubyte * 128).from_buffer_copy(ids[0])
+        rc = lib.dl_comm_rccl_unique_id(uid)  # (every rank: also the check that the RCCL entry points resolve here)
+        why = None if rc == 0 else _hip.last_error()
+        ids = _gather((bytes(uid), why), self.group, self.world)
+        bad = sorted({w for _, w in ids if w})
+        if bad:
+            raise RuntimeError("RCCL unavailable: " + "; ".join(bad))
+        blob = (ctypes.c_ubyte * 128).from_buffer_copy(ids[0][0])
         with torch.cuda.device(self.device):
-            _hip.check(lib.dl_comm_create_rccl(ctypes.byref(self.handle), self.world, self.rank, blob, self.count))
+            rc = lib.dl_comm_create_rccl(ctypes.byref(self.handle), self.world, self.rank, blob, self.count)
+        why = None if rc == 0 else _hip.last_error()
+        bad = sorted({w for w in _gather(why, self.group, self.world) if w})
+        if bad:
+            self._destroy()
+            raise RuntimeError("RCCL communicator could not be created: " + "; ".join(bad))
 
     # ---- use ------------------------------------------------------------------------------------------------
     @property
@@ -177,3 +186,32 @@ class Communicator:
             self._destroy()
         except Exception:
             pass
+
+
+def make_communicator(count: int, device, group=None, backend: Optional[str] = None):
+    """``(Communicator, None)``, or ``(None, reason)`` when neither back-end can be set up on every rank and none was asked
+    for by name: the caller then exchanges through ``torch.distributed`` (one all_reduce per iteration, issued from Python).
+    A collective call; the outcome is the same on every rank."""
+    import warnings
+
+    explicit = (backend or os.environ.get("DUALIP_COMM", "auto")).lower() != "auto"
+    comm, err = None, None
+    try:
+        if os.environ.get("DUALIP_COMM_DISABLE", "0") not in ("", "0"):  # (switch, and what the fallback's test sets)
+            raise RuntimeError("native exchange switched off by DUALIP_COMM_DISABLE")
+        comm = Communicator(count, device, group=group, backend=backend)
+    except Exception as exc:  # (Communicator raises on every rank or on none; the gather below covers what is left)
+        err = f"{type(exc).__name__}: {exc}"
+    world, rank = _world(group)
+    errs = sorted({e for e in _gather(err, group, world) if e})
+    if not errs:
+        return comm, None
+    if comm is not None:
+        comm.close()
+    reason = "; ".join(errs)
+    if explicit:
+        raise RuntimeError(reason)
+    if rank == 0:
+        warnings.warn(f"dualip_amd: no native exchange ({reason}); falling back to torch.distributed all_reduce from Python")
+    return None, reason
+

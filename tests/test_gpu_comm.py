@@ -99,6 +99,10 @@ def _loop_worker(rank, world, port, kind, q):
         p = problem(z)
         gamma, iters, s0, s1 = z["params"]
         n = p["n"]
+        nocomm = kind.endswith("-nocomm")
+        if nocomm:
+            os.environ["DUALIP_COMM_DISABLE"] = "1"
+            kind = kind[: -len("-nocomm")]
         if kind == "mixed":
             half = int(z["mixed_boundary"])
             pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)), **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n))}
@@ -114,21 +118,25 @@ def _loop_worker(rank, world, port, kind, q):
                      a=np.concatenate([q_["a"] for q_ in parts]), c=np.concatenate([q_["c"] for q_ in parts]), b=p["b"])
         cols = [c for lo, hi in ranges for c in range(lo, hi)]
         args = torch_args(local, "f64", global_to_local_projection_map(pm, cols), "cuda:0", with_b=False)
-        f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0", comm_backend="p2p")
+        f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0", comm_backend=None if nocomm else "p2p")
         solver = AcceleratedGradientDescent(max_iter=int(iters), gamma=float(gamma), initial_step_size=float(s0), max_step_size=float(s1), iteration_callback=False)
         run = solver.start_device_run(f, torch.zeros(p["m"], dtype=torch.float64, device="cuda:0"), rank=rank)
-        assert run.native_sharded  # the loop, exchange included, runs inside the C library
+        if nocomm:  # no native exchange: one torch.distributed all_reduce per iteration, issued from Python
+            assert not run.native_sharded and f.communicator() is None and "DUALIP_COMM_DISABLE" in f.comm_fallback
+        else:
+            assert run.native_sharded  # the loop, exchange included, runs inside the C library
         run.advance(int(iters) // 2)
         run.advance(int(iters))
         res = run.finish()
         run.close()
-        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), f.communicator().backend, f.communicator().exchanges))
+        comm = f.communicator()
+        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy(), comm.backend if comm else "torch.distributed", comm.exchanges if comm else int(iters)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4)])
+@pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4), ("simplex-nocomm", 2)])
 def test_sharded_c_loop_matches_reference_goldens(kind, world):
     from tests.helpers import load, relerr
 
@@ -146,10 +154,10 @@ def test_sharded_c_loop_matches_reference_goldens(kind, world):
         p.join(timeout=180)
         assert p.exitcode == 0
     z = load("g3_syn2000.npz")
-    key = f"simplex1|w{world}|f64" if kind == "simplex" else "mixed|w2|f64"
+    key = f"simplex1|w{world}|f64" if kind.startswith("simplex") else "mixed|w2|f64"
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
     for r in range(world):
-        assert out[r][2] == "p2p" and out[r][3] >= len(want_log)
+        assert out[r][2] == ("torch.distributed" if kind.endswith("-nocomm") else "p2p") and out[r][3] >= len(want_log)
         assert np.array_equal(out[0][1], out[r][1]) and np.array_equal(out[0][0], out[r][0])  # identical update on every rank, no broadcast
     assert relerr(out[0][0][:40], want_log[:40]) < 1e-9
     assert relerr(out[0][0], want_log) < 1e-6
