@@ -153,6 +153,25 @@ __global__ __launch_bounds__(1024) void read_stream_kernel(const read_vec4* __re
     if (acc == 12345.678f) *sink = acc;  // (never true for the buffers this is used on: keeps the loads alive)
 }
 
+// the same, shaped like the fused kernel's windows: every wavefront streams three arrays side by side (16 + 16 + 8 bytes per lane
+// and step, two steps in flight), its steps dealt cyclically over all wavefronts of the launch -- on the boxes measured this reads
+// faster than the single stream above (three DRAM fronts instead of one)
+typedef float read_vec2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(1024) void read_stream3_kernel(const read_vec4* __restrict__ pa, const read_vec4* __restrict__ pc, const read_vec2* __restrict__ pr, size_t n,
+                                                            float* __restrict__ sink) {
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+        const read_vec4 a0 = __builtin_nontemporal_load(pa + i), c0 = __builtin_nontemporal_load(pc + i);
+        const read_vec2 r0 = __builtin_nontemporal_load(pr + i);
+        const read_vec4 a1 = __builtin_nontemporal_load(pa + i + stride), c1 = __builtin_nontemporal_load(pc + i + stride);
+        const read_vec2 r1 = __builtin_nontemporal_load(pr + i + stride);
+        acc += a0[0] + c0[0] + r0[0] + a1[0] + c1[0] + r1[0];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
 static int grid_for(int64_t n, int threads) {
     const int64_t b = (n + threads - 1) / threads;
     return (int)(b > 8192 ? 8192 : (b > 0 ? b : 1));
@@ -181,21 +200,34 @@ int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, doub
     DL_HIP(hipMalloc((void**)&sink, sizeof(float)));
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    float best = 1e30f;
-    for (int r = 0; r <= reps && e == hipSuccess; ++r) {  // (first pass untimed)
-        e = hipEventRecord(e0, st);
-        hipLaunchKernelGGL(read_stream_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)buf, (size_t)bytes / 16, sink);
-        if (e == hipSuccess) e = hipEventRecord(e1, st);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        float ms = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (r > 0 && ms < best) best = ms;
+    // two access shapes, the better one is reported: one stream of 16-byte loads, and three streams side by side (40 bytes per lane)
+    const size_t n3 = ((size_t)bytes / 40) & ~(size_t)2047;  // lanes x steps of the three-stream shape
+    const char* base = (const char*)buf;
+    double best_gbps = 0.0;
+    for (int shape = 0; shape < 2 && e == hipSuccess; ++shape) {
+        float best = 1e30f;
+        const double moved = shape == 0 ? (double)bytes : (double)n3 * 40.0;
+        for (int r = 0; r <= reps && e == hipSuccess; ++r) {  // (first pass untimed)
+            e = hipEventRecord(e0, st);
+            if (shape == 0)
+                hipLaunchKernelGGL(read_stream_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)buf, (size_t)bytes / 16, sink);
+            else
+                hipLaunchKernelGGL(read_stream3_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
+                                   (const read_vec2*)(base + n3 * 32), n3, sink);
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && ms < best) best = ms;
+        }
+        const double gbps = moved / ((double)best * 1e-3) / 1e9;
+        if (gbps > best_gbps) best_gbps = gbps;
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(sink);
     if (e != hipSuccess) return hip_fail(e, "read bandwidth measurement");
-    *gbps_out_host = (double)bytes / ((double)best * 1e-3) / 1e9;
+    *gbps_out_host = best_gbps;
     return 0;
 }
 

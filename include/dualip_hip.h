@@ -286,8 +286,9 @@ int dl_csc_project_columns(int64_t n_sel, const int64_t* cols, const void* colpt
                            const dl_proj_desc* proj_host, int val_dtype, dl_stream_t stream);
 
 /* Measurement hook (bench.py: aux.read_ceiling_GBps): best of `reps` streaming passes over buf[0..bytes) (16-byte aligned,
- * >= 1 MiB) with 16-byte non-temporal loads, 256 workgroups x 1024 threads -- the read bandwidth this device reaches, in GB/s.
- * Synchronises the stream. */
+ * >= 1 MiB) with non-temporal loads, 256 workgroups x 1024 threads, in two shapes -- one stream of 16-byte loads; three streams
+ * side by side (16 + 16 + 8 bytes per lane, what a window of the fused pass reads) -- the better of which is returned: the read
+ * bandwidth this device reaches, in GB/s.  Synchronises the stream. */
 int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, double* gbps_out_host, dl_stream_t stream);
 
 /* jacobi_precondition (src/dualip/preprocessing/precondition.py:8-28): row_norms_out[m] = ||A_i||_2,
