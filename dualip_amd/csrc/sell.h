@@ -250,7 +250,10 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
         const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
         const bool has_col = lane < ncols;
         const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane : 0);
-        const int len = has_col ? (int)g.sell_len[dense] : 0;
+        // columns are sorted by length: all but the slices at a length-class boundary hold columns of ONE length -- no length bytes
+        // are read for those (1 byte per column = 1 % of the slices' traffic, and a dependent load off the slice's critical path)
+        int len = has_col ? H : 0;
+        if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;  // wave-uniform
         const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
         const int32_t* eq_row = nullptr;
         if (pj.kind == DL_PROJ_SIMPLEX_EQ) {  // cold: the pointer is re-read from the kernel arguments
