@@ -68,6 +68,7 @@ _SIGNATURES = {
     "dl_allreduce_sum": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
     "dl_comm_check": (_c_int, [_c_vp, _c_vp]),
     "dl_comm_set_emulation": (_c_int, [_c_vp, _c_dbl]),
+    "dl_comm_set_timeout_ms": (_c_int, [_c_vp, _c_i64]),
     "dl_comm_profile": (_c_int, [_c_vp, _c_int]),
     "dl_comm_profile_read": (_c_int, [_c_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "dl_agd_read_log": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp]),

@@ -310,6 +310,12 @@ int dl_comm_set_emulation(dl_comm* c, double scale) {
     return 0;
 }
 
+int dl_comm_set_timeout_ms(dl_comm* c, int64_t ms) {
+    if (!c || ms <= 0) return fail(DL_E_ARG, "bad argument");
+    c->timeout_ticks = (unsigned long long)ms * 100000ull;  // 100 MHz wall clock
+    return 0;
+}
+
 int dl_comm_check(dl_comm* c, dl_stream_t stream) {
     if (!c) return fail(DL_E_ARG, "null communicator");
     int dead = 0;

@@ -100,6 +100,9 @@ class Communicator:
         n = min(self.count, 4096)
         base = torch.arange(1, n + 1, dtype=torch.float64, device=self.device)
         want = base * (self.world * (self.world + 1) / 2.0)
+        # a mapping that does not carry remote stores into a running kernel shows as a timed-out wait: keep that short here
+        user_ms = int(os.environ.get("DUALIP_COMM_TIMEOUT_MS", "0") or 0)
+        self.lib.dl_comm_set_timeout_ms(self.handle, min(user_ms, 2000) if user_ms > 0 else 2000)
         try:
             for rnd in range(4):
                 v = base * float(self.rank + 1)
@@ -109,6 +112,9 @@ class Communicator:
                     return False, f"P2P self-test round {rnd}: wrong sums on rank {self.rank}"
         except Exception as exc:  # timeouts surface here
             return False, f"P2P self-test failed on rank {self.rank}: {exc}"
+        finally:
+            if self.handle is not None and self.handle.value:
+                self.lib.dl_comm_set_timeout_ms(self.handle, user_ms if user_ms > 0 else 20000)
         return True, None
 
     def _make_rccl(self):

@@ -231,6 +231,9 @@ int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream)
 /* Synchronises `stream` and reports whether a P2P exchange ever timed out waiting for a rank (DL_E_STATE; waits are bounded --
  * 20 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device). */
 int dl_comm_check(dl_comm* c, dl_stream_t stream);
+/* Bound of the in-kernel waits of the P2P exchange from now on, in milliseconds (> 0).  The Python communicator runs its
+ * creation-time self-test under a short bound (2 s) and restores the default afterwards. */
+int dl_comm_set_timeout_ms(dl_comm* c, int64_t ms);
 /* Developer aid: multiply every exchanged sum by `scale` (one rank standing in for W equal shards). */
 int dl_comm_set_emulation(dl_comm* c, double scale);
 /* Measurement hook: HIP events from the end of the last fused pass of an iteration to the end of the step's first kernel
