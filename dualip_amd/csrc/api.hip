@@ -53,7 +53,7 @@ int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_
 int sell_finish(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const std::vector<uint8_t>& pid_sell, const std::vector<uint32_t>& desc,
                 hipStream_t st);
 int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell,
-                const std::vector<uint8_t>& pid_flat,
+                const std::vector<uint8_t>& pid_flat, int compact,
                 uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st);  // pack_build.hip
 int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
@@ -521,7 +521,13 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     } win_guard{win_dev};
     if (dev_pack) {
         std::vector<uint32_t> long_list;
-        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, pid_flat, &win_dev, &n_win_dev, long_list, used_dev, st));
+        // compact window table (2 dwords instead of 12): every entry that can have windows is point-wise (a sliced simplex entry has
+        // none: its long columns are single-column tiles).  DUALIP_HIP_COMPACT=0 keeps the 12-dword table.
+        bool compact = !pid_flat.empty() && pid_flat.back() != 0 && !(getenv("DUALIP_HIP_COMPACT") && getenv("DUALIP_HIP_COMPACT")[0] == '0');
+        for (int32_t q = 0; q < n_proj && compact; ++q)
+            if (!pid_flat[(size_t)q] && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q])) compact = false;
+        h->desc_words = compact ? 2 : 12;
+        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, pid_flat, compact ? 1 : 0, &win_dev, &n_win_dev, long_list, used_dev, st));
         words4 = long_list;  // single-column tiles only; split / ordered below
         for (size_t t = 0; t < long_list.size() / 12; ++t) tile_pid4.push_back(long_list[t * 12 + 10] == 0xFFFFFFFFu ? kNoProj : long_list[t * 12 + 10]);
         h->n_long = (int64_t)(long_list.size() / 12);
@@ -664,7 +670,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const char* row_env = getenv("DUALIP_HIP_ROW32");
     if (row_env && row_env[0] == '1') h->row_bytes = 4;
     CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
-    const size_t win_bytes = dev_pack ? sizeof(uint32_t) * 12 * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
+    const size_t win_bytes = dev_pack ? sizeof(uint32_t) * (size_t)h->desc_words * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
     const size_t tile_bytes = win_bytes + (h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size());
     CK(owned_malloc(h, (void**)&h->tiles, tile_bytes));
     CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));

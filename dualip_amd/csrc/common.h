@@ -77,6 +77,7 @@ struct dl_matching {
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;
     int64_t n_tiles = 0, n_long = 0;
+    int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)
     int64_t n_short = 0;                // layout 4: window tiles (the single-column ones follow them in the descriptor array)
     int64_t n_xlong = 0;                // layout 4: single-column tiles long enough for a whole workgroup (last in the array)
     int n_wg = 0;

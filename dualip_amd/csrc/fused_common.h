@@ -35,6 +35,8 @@ struct FusedArgs {
     uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
     uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
     uint32_t n_xlong;   // layout 4: very long single-column tiles (walked by a whole workgroup), descriptors after those
+    uint32_t desc_words;           // layout 4: dwords per window descriptor: 12, or 2 (compact: { W[31:0] ; W[39:32] | hi << 8 | lo << 17 | proj id << 20 })
+    const uint32_t* __restrict__ long32;  // layout 4: the single-column tiles' descriptors (12 dwords each)
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does

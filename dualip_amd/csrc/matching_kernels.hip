@@ -462,6 +462,8 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.n_tiles = (uint32_t)(h->layout == 4 ? h->n_short : h->n_tiles);
     args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short - h->n_xlong : 0);
     args.n_xlong = (uint32_t)(h->layout == 4 ? h->n_xlong : 0);
+    args.desc_words = (uint32_t)h->desc_words;
+    args.long32 = args.tiles32 + (size_t)h->n_short * (size_t)h->desc_words + 12;  // (after the windows and one all-zero descriptor)
     args.ablate = h->ablate;
     args.timeline = h->timeline;
     args.eq_heights = h->eq_heights;

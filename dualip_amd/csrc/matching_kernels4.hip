@@ -9,7 +9,8 @@
 //   * per-tile fixed costs (descriptor unpack, loop control) amortise over 4x the work, and the four slots of a lane
 //     are independent dependency chains for the element-wise part;
 //   * segment structure = four wave-uniform 64-bit head masks; all predicates are scalar mask arithmetic (simplex4.h).
-// Descriptor: 12 dwords { W[39:0] | hi<<40 | lo<<49 | long<<51 ; H0 ; H1 ; H2 ; H3 ; proj id ; 0 } (long: length in H0).
+// Descriptor: 12 dwords { W[39:0] | hi<<40 | lo<<49 | long<<51 ; H0 ; H1 ; H2 ; H3 ; proj id ; 0 } (long: length in H0); when every
+// window of a handle is point-wise the window table is COMPACT: 2 dwords { W[39:0] | hi<<40 | lo<<49 | proj id<<52 } (0xFFF: none).
 // Columns that cannot sit in a window (longer than 253, touching the array's last partial quad, or using a projection
 // entry beyond the LDS table) are single-column "long" tiles: their descriptors follow the window tiles (after one all-zero
 // descriptor) and are walked by process_long_tile in separate loops ahead of the hot one: by one wavefront each, or -- the
@@ -67,10 +68,15 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
 
     // descriptor word `lane` of schedule slot q (lanes >= 12 re-read word 11; slots past the end read the all-zero
     // descriptor the host appends).  A plain load: nothing consumes it before the next iteration.
+    // Compact table (every window point-wise -- the device packer's case unless a simplex entry is not sliced): 2 dwords per
+    // window, the projection id in the top 12 bits of the second; the head masks do not exist (nothing reads them).
+    const uint32_t dwords = g.desc_words;
+    const bool compact = dwords != (uint32_t)kDesc4Words;
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kDesc4Words ? (uint32_t)lane : (uint32_t)kDesc4Words - 1u;
+    const uint32_t wlane = (uint32_t)lane < dwords ? (uint32_t)lane : dwords - 1u;
     auto load_desc = [&](uint32_t q) -> uint32_t {
         const uint32_t t = q < n_tiles ? q : n_tiles;
-        return byte_offset(g.tiles32 + (size_t)t * kDesc4Words, dlane * 4u)[0];  // (cached: a 48-byte descriptor shares its lines with its neighbours')
+        return byte_offset(g.tiles32 + (size_t)t * dwords, wlane * 4u)[0];  // (cached: a descriptor shares its lines with its neighbours')
     };
     struct Tile {
         uint32_t dv;  // descriptor words, one per lane; the head masks and the projection id are only unpacked when used
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         const uint32_t n_xlong = kernarg_args(g).n_xlong;
         for (uint32_t xt = (uint32_t)wg; xt < n_xlong; xt += (uint32_t)gridDim.x) {
             const FusedArgs<T>& gk = kernarg_args(g);
-            const uint32_t dvl = byte_offset(g.tiles32 + (size_t)(n_tiles + 1u + gk.n_long + xt) * kDesc4Words, dlane * 4u)[0];
+            const uint32_t dvl = byte_offset(gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words, dlane * 4u)[0];
             const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
             const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
             const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     }
     for (uint32_t lt = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave; lt < g.n_long; lt += S) {
         const FusedArgs<T>& gk = kernarg_args(g);
-        const uint32_t dvl = byte_offset(g.tiles32 + (size_t)(n_tiles + 1u + lt) * kDesc4Words, dlane * 4u)[0];
+        const uint32_t dvl = byte_offset(gk.long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0];
         const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
         const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
         const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         unpack_and_issue(dv_cur_next, nxt);
 
         const uint32_t hi = (cur.w0hi >> 8) & 0x1FF, lo = (cur.w0hi >> 17) & 3;
-        const uint32_t pid = rl(cur.dv, 10);
+        uint32_t pid = rl(cur.dv, 10);
+        if (compact) pid = (cur.w0hi >> 20) == 0xFFFu ? 0xFFFFFFFFu : (cur.w0hi >> 20);
         const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
         const int kind = __builtin_amdgcn_readfirstlane(pj.kind);
         T v[kSlots], x[kSlots];

@@ -27,7 +27,7 @@ struct PackErr {
 
 // One chunk of columns.  WRITE = false: count only.
 template <class IdxT, bool WRITE>
-__device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
+__device__ __forceinline__ void pack_chunk(int compact, int64_t j0, int64_t j1, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
                                            const uint8_t* __restrict__ pid_sell, uint32_t& n_win, uint32_t& n_long, uint32_t* __restrict__ win_out,
                                            uint32_t* __restrict__ long_out, uint8_t* __restrict__ used, PackErr* __restrict__ err) {
     const uint64_t nnz_al4 = (uint64_t)nnz & ~3ull;
@@ -60,7 +60,15 @@ __device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, 
     auto flush = [&]() {
         if (!open) return;
         if (end < 256) set_head(end);  // sentinel: elements past the last column form their own dummy segment
-        if constexpr (WRITE) emit12(win_out + (size_t)n_win * 12, W | ((uint64_t)end << 40) | ((uint64_t)lo << 49), H0, H1, H2, H3, cur_proj);
+        if constexpr (WRITE) {
+            const uint64_t w0 = W | ((uint64_t)end << 40) | ((uint64_t)lo << 49);
+            if (compact) {  // (every window point-wise: no head masks; the projection id rides in the top 12 bits)
+                win_out[(size_t)n_win * 2] = (uint32_t)w0;
+                win_out[(size_t)n_win * 2 + 1] = (uint32_t)(w0 >> 32) | ((cur_proj == kNoProj ? 0xFFFu : cur_proj) << 20);
+            } else {
+                emit12(win_out + (size_t)n_win * 12, w0, H0, H1, H2, H3, cur_proj);
+            }
+        }
         n_win += 1;
         open = false;
         H0 = H1 = H2 = H3 = 0;
@@ -141,7 +149,7 @@ __device__ __forceinline__ void pack_chunk(int64_t j0, int64_t j1, int64_t nnz, 
 }
 
 template <class IdxT>
-__global__ __launch_bounds__(64) void pack_count_kernel(int64_t n, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
+__global__ __launch_bounds__(64) void pack_count_kernel(int compact, int64_t n, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
                                                         const uint8_t* __restrict__ pid_sell, unsigned long long* __restrict__ counts, uint8_t* __restrict__ used,
                                                         PackErr* __restrict__ err) {
     const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,12 +157,12 @@ __global__ __launch_bounds__(64) void pack_count_kernel(int64_t n, int64_t nnz, 
     if (j0 >= n) return;
     const int64_t j1 = j0 + kPackChunk < n ? j0 + kPackChunk : n;
     uint32_t nw = 0, nl = 0;
-    pack_chunk<IdxT, false>(j0, j1, nnz, colptr, col_proj, n_proj, pid_sell, nw, nl, nullptr, nullptr, used, err);
+    pack_chunk<IdxT, false>(compact, j0, j1, nnz, colptr, col_proj, n_proj, pid_sell, nw, nl, nullptr, nullptr, used, err);
     counts[ch] = (unsigned long long)nw | ((unsigned long long)nl << 32);  // both counters ride one exclusive scan
 }
 
 template <class IdxT>
-__global__ __launch_bounds__(64) void pack_write_kernel(int64_t n, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
+__global__ __launch_bounds__(64) void pack_write_kernel(int compact, int64_t n, int64_t nnz, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, int32_t n_proj,
                                                         const uint8_t* __restrict__ pid_sell, const unsigned long long* __restrict__ offsets, uint32_t* __restrict__ win_out,
                                                         uint32_t* __restrict__ long_out) {
     const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,12 +170,12 @@ __global__ __launch_bounds__(64) void pack_write_kernel(int64_t n, int64_t nnz, 
     if (j0 >= n) return;
     const int64_t j1 = j0 + kPackChunk < n ? j0 + kPackChunk : n;
     uint32_t nw = (uint32_t)offsets[ch], nl = (uint32_t)(offsets[ch] >> 32);
-    pack_chunk<IdxT, true>(j0, j1, nnz, colptr, col_proj, n_proj, pid_sell, nw, nl, win_out, long_out, nullptr, nullptr);
+    pack_chunk<IdxT, true>(compact, j0, j1, nnz, colptr, col_proj, n_proj, pid_sell, nw, nl, win_out, long_out, nullptr, nullptr);
 }
 
 template <class IdxT>
 static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell_h,
-                             const std::vector<uint8_t>& pid_flat_h, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used_h, hipStream_t st) {
+                             const std::vector<uint8_t>& pid_flat_h, int compact, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used_h, hipStream_t st) {
     *win_dev_out = nullptr;
     *n_win_out = 0;
     long_words.clear();
@@ -200,7 +208,7 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
     if (e == hipSuccess) e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * (size_t)(n_chunks + 1), st);
     const unsigned blocks = (unsigned)((n_chunks + 63) / 64);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pack_count_kernel<IdxT>, dim3(blocks), dim3(64), 0, st, n, nnz, colptr, col_proj, n_proj, flags, counts, used, err);
+        hipLaunchKernelGGL(pack_count_kernel<IdxT>, dim3(blocks), dim3(64), 0, st, compact, n, nnz, colptr, col_proj, n_proj, flags, counts, used, err);
         e = hipGetLastError();
     }
     size_t tmp_bytes = 0;
@@ -229,10 +237,10 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
         cleanup(false);
         return fail(DL_E_ARG, "too many tiles");
     }
-    e = hipMalloc((void**)&win, sizeof(uint32_t) * 12 * (size_t)(n_win ? n_win : 1));
+    e = hipMalloc((void**)&win, sizeof(uint32_t) * (compact ? 2 : 12) * (size_t)(n_win ? n_win : 1));
     if (e == hipSuccess) e = hipMalloc((void**)&lng, sizeof(uint32_t) * 12 * (size_t)(n_long ? n_long : 1));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pack_write_kernel<IdxT>, dim3(blocks), dim3(64), 0, st, n, nnz, colptr, col_proj, n_proj, flags, offsets, win, lng);
+        hipLaunchKernelGGL(pack_write_kernel<IdxT>, dim3(blocks), dim3(64), 0, st, compact, n, nnz, colptr, col_proj, n_proj, flags, offsets, win, lng);
         e = hipGetLastError();
     }
     long_words.resize((size_t)n_long * 12);
@@ -248,14 +256,15 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
     return 0;
 }
 
-// Window descriptors stay on the device (*win_dev_out, 12 dwords each, memory order; the caller frees it); the single-column
+// Window descriptors stay on the device (*win_dev_out, 12 dwords each -- 2 when `compact`, which the caller may ask for when every
+// entry that can have windows is point-wise -- memory order; the caller frees it); the single-column
 // tiles come back to the host (they are few, and the caller orders them longest first).  pid_flat[q] != 0: entry q is point-wise
 // (its last element, index n_proj: columns with no entry).  used[q] != 0: entry q has a window or
 // single-column tile (used[n_proj]: a column with no entry has one).
 int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const int32_t* col_proj, int32_t n_proj, const std::vector<uint8_t>& pid_sell,
-                const std::vector<uint8_t>& pid_flat, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st) {
-    if (idx_dtype == DL_I64) return pack_device_typed<int64_t>(n, nnz, (const int64_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, win_dev_out, n_win_out, long_words, used, st);
-    return pack_device_typed<int32_t>(n, nnz, (const int32_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, win_dev_out, n_win_out, long_words, used, st);
+                const std::vector<uint8_t>& pid_flat, int compact, uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st) {
+    if (idx_dtype == DL_I64) return pack_device_typed<int64_t>(n, nnz, (const int64_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, compact, win_dev_out, n_win_out, long_words, used, st);
+    return pack_device_typed<int32_t>(n, nnz, (const int32_t*)colptr, col_proj, n_proj, pid_sell, pid_flat, compact, win_dev_out, n_win_out, long_words, used, st);
 }
 
 }  // namespace dl
