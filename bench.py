@@ -480,8 +480,9 @@ def main():
     # -- plus, for columns held in column-per-lane slices, the padding of their transposed copy, 16 bytes per slice, one length
     # byte per column
     per_nnz = 2 * vs + lay["row_index_bytes"]
-    phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + lay["tiles"] * (48 if lay["layout"] == 4 else 16) \
-        + lay.get("slices", 0) * 16 + lay.get("slice_columns", 0) + lay["workgroups"] * (m * 8 + 16)
+    desc_bytes = 4 * lay.get("window_descriptor_words", 12 if lay["layout"] == 4 else 4)
+    phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + (lay["tiles"] - lay["long_columns"]) * desc_bytes \
+        + lay["long_columns"] * (48 if lay["layout"] == 4 else 16) + lay.get("slices", 0) * 16 + lay.get("slice_mixed_columns", 0) + lay["workgroups"] * (m * 8 + 16)
 
     def roof(kernel_ms, launches):
         avg_s = (kernel_ms / max(launches, 1)) * 1e-3

@@ -839,6 +839,8 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 13: return h->n_sell_cols;
         case 14: return h->n_sell_elems;
         case 15: return h->n_sell_nnz;
+        case 16: return h->layout == 4 ? h->desc_words : 4;
+        case 17: return h->n_sell_mixed_cols;
         default: return -1;
     }
 }

@@ -183,6 +183,11 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     h->n_sell_cols = (int64_t)n_cols;
     h->n_sell_elems = (int64_t)n_elems;
     h->n_sell_nnz = (int64_t)n_nnz;
+    h->n_sell_mixed_cols = 0;
+    for (size_t t = 0; t + kSellDescWords <= desc.size(); t += kSellDescWords) {
+        const uint32_t w1 = desc[t + 1];
+        if (((w1 >> 8) & 0xFFu) != ((w1 >> 16) & 0xFFu)) h->n_sell_mixed_cols += (int64_t)((w1 >> 24) & 0xFFu) + 1;
+    }
     return 0;
 }
 
