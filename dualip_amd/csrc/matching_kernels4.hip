@@ -118,15 +118,20 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         }
     };
 
-    uint32_t ti = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;  // schedule slot
+    // this wavefront's window tiles: slots of the (XCD-weighted) cyclic deal, fused_common.h
+    const Deal dealw = make_deal(g.balance, (uint32_t)gridDim.x, (uint32_t)wg, (uint32_t)wave, n_tiles);
+    uint32_t kw = 0;                                                    // round
+    uint32_t ti = deal_slot(dealw, 0), ti_next = deal_slot(dealw, 1);   // schedule slots of the current / next tile (n_tiles: none)
     uint32_t dv_next = 0;
     Tile tA, tB;
     // the first two descriptors are in flight while the workgroup stages lambda and zeroes its gradient (their loads
     // are older than the prologue's, so waiting for lambda does not wait for tile data)
     const uint32_t dv0 = load_desc(ti);
-    dv_next = load_desc(ti + S);
+    dv_next = load_desc(ti_next);
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
     stamp(g, wg, tid, 1);
+    unsigned long long* bst = kernarg_args(g).bal_stamps;
+    if (bst && tid == 0) bst[4 * (size_t)wg] = wall_clock64();
     const T s = w.s;
     T sd = (T)0;  // -(lambda_K - lambda_{K+1}) / gamma, K = m - 2
     if constexpr (FAIR) sd = (T)(s * (T)(g.lambda_orig[g.m - 2] - g.lambda_orig[g.m - 1]));
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             else lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
         }
         const uint32_t dv_cur_next = dv_next;
-        dv_next = load_desc(ti + 2u * S);
+        const uint32_t ti_nn = deal_slot(dealw, kw + 2u);
+        dv_next = load_desc(ti_nn);
         unpack_and_issue(dv_cur_next, nxt);
 
         const uint32_t hi = (cur.w0hi >> 8) & 0x1FF, lo = (cur.w0hi >> 17) & 3;
@@ -238,20 +244,25 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             for (int j = 0; j < kSlots; ++j)
                 if (e0 + (uint32_t)j < span) __builtin_nontemporal_store(x[j], &xw[4 * (uint32_t)lane + j]);  // neighbours own the rest of the quad
         }
-        ti += S;
+        kw += 1u;
+        ti = ti_next;
+        ti_next = ti_nn;
     };
     while (ti < n_tiles) {
         step(tA, tB);
         if (ti >= n_tiles) break;
         step(tB, tA);
     }
-    // ---- column-per-lane slices: the short columns of simplex entries (sell.h) ----
-    // the cyclic deal continues where the window tiles stopped: wavefronts that had one window tile fewer take the first slices
+    bst = kernarg_args(g).bal_stamps;
+    if (bst && tid == 0) bst[4 * (size_t)wg + 1] = wall_clock64();
+    // ---- column-per-lane slices: the short columns of simplex entries (sell.h), their own (XCD-weighted) cyclic deal ----
     {
-        const uint32_t me = (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;
-        const uint32_t q0 = (g.ablate & 16) ? me : (me + S - n_tiles % S) % S;  // (DUALIP_HIP_ABLATE=16: every wavefront starts the slices at its own index)
-        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, q0, S, lane, sd, obj, ssq, fair);
+        const int32_t* tab = kernarg_args(g).balance;
+        const Deal deals = make_deal(tab ? tab + 8 : nullptr, (uint32_t)gridDim.x, (uint32_t)wg, (uint32_t)wave, g.n_sell);
+        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, deals, lane, sd, obj, ssq, fair);
     }
+    bst = kernarg_args(g).bal_stamps;
+    if (bst && tid == 0) bst[4 * (size_t)wg + 2] = wall_clock64();
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 2);

@@ -459,3 +459,51 @@ def test_handles_on_two_devices_in_one_process():
         f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, dev), 0.02)
         out.append(f.calculate(torch.from_numpy(z["lam_small"]).to(dev), 0.02).dual_gradient.cpu())
     assert torch.equal(out[0], out[1])
+
+
+def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
+    """The cyclic deal of tiles to wavefronts with a per-XCD number of rounds (csrc/fused_common.h: Deal), adapted from the first
+    launches' stamps.  Only large problems adapt by default; here the threshold is lowered so that a 3M-entity mixed problem does.
+    Whatever table the timings produce, every tile keeps exactly one slot: the gradient (integer fixed point) and the primal
+    are bit-identical to a handle with the even deal, the floating-point objective sums agree to rounding."""
+    import os
+
+    from benchmark.synthetic import generate_matching_problem
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
+        pytest.skip("the 64-wide layout deals contiguous ranges")
+    n, m = 3_000_000, 2_000
+    prob = generate_matching_problem(n, m, 5e-3, seed=5, device=torch.device(DEV), dtype=torch.float32)
+    inp = prob["input_args"]
+    half = n // 2
+    inp.projection_map = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)),
+                          **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n))}
+    lam = torch.rand(m, device=DEV) * 0.01
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE", "0")
+    even = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    assert even._lib.dl_matching_info(even._handle, 18) == -1
+    want = even.calculate(lam, save_primal=True)
+    wg, wx, wo = want.dual_gradient.clone(), want.primal_var.clone(), float(want.dual_objective)
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE", "1")
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS", "4")
+    f = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    info = f.info()
+    if info["workgroups"] % 8:
+        pytest.skip("workgroups do not map evenly onto XCDs")
+    tables = set()
+    for it in range(12):  # the first 8 launches adapt the table
+        got = f.calculate(lam, save_primal=(it % 3 == 0))
+        tab = tuple(int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(16))
+        tables.add(tab)
+        assert min(tab) >= 0
+        S = info["workgroups"] * 16
+        wpx = S // 8
+        assert sum(tab[:8]) * wpx >= info["tiles"] - info["long_columns"] and sum(tab[8:]) * wpx >= info["slices"]
+        assert torch.equal(got.dual_gradient, wg)
+        if it % 3 == 0:
+            assert torch.equal(got.primal_var, wx)
+        assert abs(float(got.dual_objective) - wo) <= 1e-6 * abs(wo)
+    # (the timings of a real device are never perfectly even: the table moves; if it ever did not, the test still passed the invariants)
+    print("tables seen", len(tables))
