@@ -811,22 +811,19 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             default: h->has_unbounded = true; break;
         }
     }
-    // ---- XCD balance (fused_common.h: Deal): a table of rounds per XCD, uniform to start with, adapted by the first launches.
+    // ---- XCD balance of the window tiles (fused_common.h: Deal): a table of rounds per XCD, even to start with, adapted by the first launches.
     //      Only where a round is a small share of a wavefront's work (>= kBalMinRounds rounds) and workgroups map evenly onto XCDs.
     //      DUALIP_HIP_XCD_BALANCE=0: every XCD keeps the same number of rounds. ----
     {
         const char* be = getenv("DUALIP_HIP_XCD_BALANCE");
         const int64_t S = (int64_t)h->n_wg * kFusedWaves;
-        const int64_t rw = S > 0 ? (h->n_short + S - 1) / S : 0, rs = S > 0 ? (h->n_sell + S - 1) / S : 0;
+        const int64_t rw = S > 0 ? (h->n_short + S - 1) / S : 0;
         if (const char* mr = getenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
-        if (h->layout == 4 && !(be && be[0] == '0') && h->n_wg >= 8 && h->n_wg % 8 == 0 && (rw >= h->bal_min_rounds || rs >= h->bal_min_rounds)) {
-            CK(owned_malloc(h, (void**)&h->bal, sizeof(int32_t) * 16));
+        if (h->layout == 4 && !(be && be[0] == '0') && h->n_wg >= 8 && h->n_wg % 8 == 0 && rw >= h->bal_min_rounds) {
+            CK(owned_malloc(h, (void**)&h->bal, sizeof(int32_t) * 8));
             CK(owned_malloc(h, (void**)&h->bal_stamps, sizeof(unsigned long long) * 4 * (size_t)h->n_wg));
-            int32_t tab[16];
-            for (int x = 0; x < 8; ++x) {
-                tab[x] = (int32_t)rw;
-                tab[8 + x] = (int32_t)rs;
-            }
+            int32_t tab[8];
+            for (int x = 0; x < 8; ++x) tab[x] = (int32_t)rw;
             CKH(hipMemcpyAsync(h->bal, tab, sizeof(tab), hipMemcpyHostToDevice, st));
             CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
             CKH(hipStreamSynchronize(st));  // (tab is a host temporary)
@@ -865,7 +862,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
         default:
-            if (what >= 18 && what < 34) {  // XCD balance table (synchronous read; -1: no table)
+            if (what >= 18 && what < 26) {  // XCD balance table (synchronous read; -1: no table)
                 if (!h->bal) return -1;
                 int32_t v = -1;
                 if (hipMemcpy(&v, h->bal + (what - 18), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -79,10 +79,10 @@ struct dl_matching {
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;
     int64_t n_tiles = 0, n_long = 0;
-    // XCD balance (fused_common.h: Deal): rounds of the cyclic deal per XCD -- [0..8) window tiles, [8..16) slices -- adapted from
-    // per-workgroup stamps of the first launches; null = every XCD takes the same number of rounds
-    int32_t* bal = nullptr;                  // owned, device, 16 ints
-    unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, windows done, slices done
+    // XCD balance (fused_common.h: Deal): rounds of the window tiles' cyclic deal per XCD, adapted from per-workgroup stamps of the
+    // first launches; null = every XCD takes the same number of rounds
+    int32_t* bal = nullptr;                  // owned, device, 8 ints
+    unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, windows done
     int bal_launches = 0;                    // launches that have adapted the table so far
     int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)
     int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)

@@ -37,7 +37,7 @@ struct FusedArgs {
     uint32_t n_xlong;   // layout 4: very long single-column tiles (walked by a whole workgroup), descriptors after those
     uint32_t desc_words;           // layout 4: dwords per window descriptor: 12, or 2 (compact: { W[31:0] ; W[39:32] | hi << 8 | lo << 17 | proj id << 20 })
     const uint32_t* __restrict__ long32;  // layout 4: the single-column tiles' descriptors (12 dwords each)
-    const int32_t* balance;               // layout 4: rounds of the cyclic deal per XCD ([0..8) windows, [8..16) slices), or null (same for all)
+    const int32_t* balance;               // layout 4: rounds of the window tiles' cyclic deal per XCD (8 entries), or null (same for all)
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
@@ -72,51 +72,50 @@ struct FusedArgs {
 // in round k:  sum_x' Wx * min(k, n_x')  +  (g * c_k + below_k(x)) * 16 + v,   c_k = #{x': n_x' > k},  below_k(x) = #{x' < x: n_x' > k},
 // Wx = wavefronts per XCD -- a bijection onto the slots for any table.  For k < min n_x that is k S + W: the common case costs nothing;
 // the general formula (a scalar loop over eight table entries) runs in the last few per cent of the rounds.
+// A wavefront carries only n_min and its own n across its loops (two scalar registers; everything else is recomputed from the
+// workgroup / wavefront ids where it is needed: carried as a struct of eleven scalars, the deal's state was spilled to vector lanes
+// inside every slice variant -- all-simplex maps +3 %).
 struct Deal {
-    const int32_t* tab;  // 8 entries, or null
-    uint32_t S, me, wpx, grp16, xcd, v, n_mine, n_min, N;
+    uint32_t n_mine, n_min;
 };
-__device__ __forceinline__ Deal make_deal(const int32_t* tab, uint32_t n_wg, uint32_t wg, uint32_t wave, uint32_t N) {
+__device__ __forceinline__ Deal make_deal(const int32_t* tab) {
     Deal d;
-    d.tab = tab;
-    d.S = n_wg * (uint32_t)kFusedWaves;
-    d.me = wg * (uint32_t)kFusedWaves + wave;
-    d.wpx = (n_wg >> 3) * (uint32_t)kFusedWaves;
-    d.grp16 = wg >> 3;
-    d.xcd = wg & 7u;
-    d.v = wave;
-    d.N = N;
     d.n_mine = 0xFFFFFFFFu;
     d.n_min = 0xFFFFFFFFu;
     if (tab) {
+        // (the table lives in global memory the compiler cannot prove constant: its loads are vector loads, and without the
+        //  readfirstlane every slot computation downstream runs on the vector unit -- +20 VALU per window tile, measured)
         uint32_t mn = 0xFFFFFFFFu;
         for (int x = 0; x < 8; ++x) {
-            const uint32_t n = (uint32_t)tab[x];
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(tab[x]);
             mn = n < mn ? n : mn;
         }
         d.n_min = mn;
-        d.n_mine = (uint32_t)tab[d.xcd];
+        d.n_mine = (uint32_t)__builtin_amdgcn_readfirstlane(tab[blockIdx.x & 7u]);
     }
     return d;
 }
-// slot of this wavefront's k-th tile; >= N: none (and none after it)
-__device__ __forceinline__ uint32_t deal_slot(const Deal& d, uint32_t k) {
+// slot of this wavefront's k-th tile among N; >= N: none (and none after it).  32-bit arithmetic: N < 2^31 and a wavefront stops at
+// its first slot >= N, so k S stays below N + 2 S.
+__device__ __forceinline__ uint32_t deal_slot(const Deal& d, const int32_t* tab, uint32_t k, uint32_t N) {
+    const uint32_t n_wg = gridDim.x, wg = blockIdx.x;
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (k < d.n_min) {  // (also the whole of an unweighted deal)
-        const uint64_t q = (uint64_t)k * d.S + d.me;
-        return q < d.N ? (uint32_t)q : d.N;
+        const uint32_t q = (k * n_wg + wg) * (uint32_t)kFusedWaves + v;
+        return q < N ? q : N;
     }
-    if (k >= d.n_mine) return d.N;
-    uint64_t off = 0;
-    uint32_t c = 0, below = 0;
+    if (k >= d.n_mine) return N;
+    const uint32_t wpx = (n_wg >> 3) * (uint32_t)kFusedWaves, xcd = wg & 7u;
+    uint32_t off = 0, c = 0, below = 0;
     for (uint32_t x = 0; x < 8; ++x) {
-        const uint32_t n = (uint32_t)d.tab[x];
-        off += (uint64_t)d.wpx * (n < k ? n : k);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(tab[x]);
+        off += wpx * (n < k ? n : k);
         const uint32_t in = n > k ? 1u : 0u;
         c += in;
-        below += x < d.xcd ? in : 0u;
+        below += x < xcd ? in : 0u;
     }
-    const uint64_t q = off + (uint64_t)(d.grp16 * c + below) * (uint32_t)kFusedWaves + d.v;
-    return q < d.N ? (uint32_t)q : d.N;
+    const uint32_t q = off + ((wg >> 3) * c + below) * (uint32_t)kFusedWaves + v;
+    return q < N ? q : N;
 }
 
 // The cold paths re-read the kernel arguments from the kernarg segment (they sit at offset 0) instead of keeping a dozen

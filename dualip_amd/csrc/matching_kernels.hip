@@ -411,75 +411,67 @@ __global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, cons
 }
 
 // fairness pair: (A x) of the two dense rows from the workgroups' partial sums (fixed order)
-// XCD balance (fused_common.h: Deal).  st[w][0..2] = wall clock of workgroup w after its prologue, its window tiles, its slices
-// (workgroup w runs on XCD w mod 8).  Per phase: rate of an XCD = its rounds / its mean duration; the rounds are re-divided in
-// proportion to the rates (damped -- see the gain below --, at most +-15 % from the even share), rounded down, and the missing tiles go to the XCDs with the
-// largest remainders.  One thread does the arithmetic: 2 x 8 numbers.
-__global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ tab, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, uint32_t n_sell, int min_rounds) {
-    __shared__ double dur[2][8];
+// XCD balance of the window tiles (fused_common.h: Deal).  st[w][0..1] = wall clock of workgroup w after its prologue and after its
+// window tiles (wavefront 0; workgroup w runs on XCD w mod 8).  Rate of an XCD = its rounds / its mean duration; the rounds are
+// re-divided in proportion to the rates (gain 0.6, at most +-15 % from the even share), rounded down, and the missing tiles go to the
+// XCDs with the largest remainders.  One thread does the arithmetic: 8 numbers.
+__global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ n, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, int min_rounds) {
+    __shared__ double dur[8];
     const int lane = threadIdx.x;
-    if (lane < 16) {
-        const int x = lane & 7, ph = lane >> 3;
+    if (lane < 8) {
         double t = 0.0;
         int cnt = 0;
-        for (int w = x; w < n_wg; w += 8) {
-            const unsigned long long a = st[4 * (size_t)w + ph], b = st[4 * (size_t)w + ph + 1];
+        for (int w = lane; w < n_wg; w += 8) {
+            const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1];
             if (b > a) {
                 t += (double)(b - a);
                 cnt += 1;
             }
         }
-        dur[ph][x] = cnt > 0 ? t / cnt : 0.0;
+        dur[lane] = cnt > 0 ? t / cnt : 0.0;
     }
     __syncthreads();
     if (lane != 0) return;
     const double wpx = (double)((n_wg >> 3) * kFusedWaves);
-    for (int ph = 0; ph < 2; ++ph) {
-        int32_t* n = tab + 8 * ph;
-        const double N = (double)(ph == 0 ? n_win : n_sell);
-        const double need = N / wpx;        // rounds, summed over the XCDs
-        const double even = need / 8.0;
-        if (even < (double)min_rounds - 1.0) continue;
-        double rate[8], rsum = 0.0;
-        bool ok = true;
-        for (int x = 0; x < 8; ++x) {
-            ok = ok && dur[ph][x] > 0.0 && n[x] > 0;
-            rate[x] = ok ? (double)n[x] / dur[ph][x] : 0.0;
-            rsum += rate[x];
-        }
-        if (!ok || !(rsum > 0.0)) continue;
-        double want[8];
-        long long have = 0;
-        int32_t fl[8];
-        for (int x = 0; x < 8; ++x) {
-            // gain: window rounds all cost the same (0.6 converges in a few steps); slices are sorted by height, the rounds an XCD
-            // gains or loses are the LAST ones -- the tallest slices, up to ~3.5 x the average round -- so the loop gain must stay
-            // below 2 / 3.5 (0.7 was measured diverging: the slow XCDs ended up with MORE rounds)
-            const double gain = ph == 0 ? 0.6 : 0.3;
-            double t = (double)n[x] + gain * (need * rate[x] / rsum - (double)n[x]);
-            t = t < 0.85 * even ? 0.85 * even : (t > 1.15 * even ? 1.15 * even : t);
-            want[x] = t;
-            fl[x] = (int32_t)t;
-            have += fl[x];
-        }
-        // every tile must have a slot: sum of rounds * wavefronts per XCD >= N
-        for (int guard = 0; guard < 64 && (double)have * wpx < N; ++guard) {
-            int best = 0;
-            double bf = -1.0;
-            for (int x = 0; x < 8; ++x) {
-                const double f = want[x] - (double)fl[x];
-                if (f > bf) {
-                    bf = f;
-                    best = x;
-                }
-            }
-            fl[best] += 1;
-            want[best] = (double)fl[best];  // (its remainder is used up)
-            have += 1;
-        }
-        if ((double)have * wpx < N) continue;  // (cannot happen: the clamps leave room; keep the old table)
-        for (int x = 0; x < 8; ++x) n[x] = fl[x];
+    const double N = (double)n_win;
+    const double need = N / wpx;  // rounds, summed over the XCDs
+    const double even = need / 8.0;
+    if (even < (double)min_rounds - 1.0) return;
+    double rate[8], rsum = 0.0;
+    bool ok = true;
+    for (int x = 0; x < 8; ++x) {
+        ok = ok && dur[x] > 0.0 && n[x] > 0;
+        rate[x] = ok ? (double)n[x] / dur[x] : 0.0;
+        rsum += rate[x];
     }
+    if (!ok || !(rsum > 0.0)) return;
+    double want[8];
+    long long have = 0;
+    int32_t fl[8];
+    for (int x = 0; x < 8; ++x) {
+        double t = (double)n[x] + 0.6 * (need * rate[x] / rsum - (double)n[x]);
+        t = t < 0.85 * even ? 0.85 * even : (t > 1.15 * even ? 1.15 * even : t);
+        want[x] = t;
+        fl[x] = (int32_t)t;
+        have += fl[x];
+    }
+    // every tile must have a slot: sum of rounds * wavefronts per XCD >= N
+    for (int guard = 0; guard < 64 && (double)have * wpx < N; ++guard) {
+        int best = 0;
+        double bf = -1.0;
+        for (int x = 0; x < 8; ++x) {
+            const double f = want[x] - (double)fl[x];
+            if (f > bf) {
+                bf = f;
+                best = x;
+            }
+        }
+        fl[best] += 1;
+        want[best] = (double)fl[best];  // (its remainder is used up)
+        have += 1;
+    }
+    if ((double)have * wpx < N) return;  // (cannot happen: the clamps leave room; keep the old table)
+    for (int x = 0; x < 8; ++x) n[x] = fl[x];
 }
 
 __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restrict__ partial_fair, int n_wg, double* __restrict__ dense_ax) {
@@ -594,7 +586,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     if (args.bal_stamps) {  // the first launches of a handle adapt its per-XCD rounds to what their stamps say (a few microseconds each)
-        hipLaunchKernelGGL(xcd_balance_kernel, dim3(1), dim3(64), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, (uint32_t)h->n_sell, h->bal_min_rounds);
+        hipLaunchKernelGGL(xcd_balance_kernel, dim3(1), dim3(64), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds);
         DL_HIP(hipGetLastError());
         h->bal_launches += 1;
     }

@@ -132,9 +132,9 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     uint32_t dv_first = 0, dv_next = 0;
     Tile tA, tB;
     auto open_windows = [&]() __attribute__((always_inline)) {
-        dealw = make_deal(kernarg_args(g).balance, (uint32_t)gridDim.x, (uint32_t)wg, (uint32_t)wave, n_tiles);
-        ti = deal_slot(dealw, 0);
-        ti_next = deal_slot(dealw, 1);
+        dealw = make_deal(kernarg_args(g).balance);
+        ti = deal_slot(dealw, kernarg_args(g).balance, 0u, n_tiles);
+        ti_next = deal_slot(dealw, kernarg_args(g).balance, 1u, n_tiles);
         dv_first = load_desc(ti);
         dv_next = load_desc(ti_next);
     };
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             else lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
         }
         const uint32_t dv_cur_next = dv_next;
-        const uint32_t ti_nn = deal_slot(dealw, kw + 2u);
+        const uint32_t ti_nn = deal_slot(dealw, kernarg_args(g).balance, kw + 2u, n_tiles);
         dv_next = load_desc(ti_nn);
         unpack_and_issue(dv_cur_next, nxt);
 
@@ -260,26 +260,28 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         ti = ti_next;
         ti_next = ti_nn;
     };
-    auto slices = [&]() __attribute__((always_inline)) {
-        const int32_t* tab = kernarg_args(g).balance;
-        const Deal deals = make_deal(tab ? tab + 8 : nullptr, (uint32_t)gridDim.x, (uint32_t)wg, (uint32_t)wave, g.n_sell);
-        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, deals, lane, sd, obj, ssq, fair);
+    // (ONE copy of the slice walker -- fourteen height variants, ~100 KB of code -- and two of the much smaller window loop: with the
+    //  slice walker inlined twice, all-simplex maps, whose wavefronts then ran two copies side by side, measured 2-4 % slower)
+    auto windows = [&]() __attribute__((always_inline)) {
+        if (ti < n_tiles) unpack_and_issue(dv_first, tA);
+        while (ti < n_tiles) {
+            step(tA, tB);
+            if (ti >= n_tiles) break;
+            step(tB, tA);
+        }
     };
+    if (!sell_first) {
+        windows();
+        bst = kernarg_args(g).bal_stamps;
+        if (bst && tid == 0) bst[4 * (size_t)wg + 1] = wall_clock64();
+    }
+    {
+        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, obj, ssq, fair);
+    }
     if (sell_first) {
-        slices();
         open_windows();
+        windows();
     }
-    if (ti < n_tiles) unpack_and_issue(dv_first, tA);
-    while (ti < n_tiles) {
-        step(tA, tB);
-        if (ti >= n_tiles) break;
-        step(tB, tA);
-    }
-    bst = kernarg_args(g).bal_stamps;
-    if (bst && tid == 0) bst[4 * (size_t)wg + 1] = wall_clock64();
-    if (!sell_first) slices();
-    bst = kernarg_args(g).bal_stamps;
-    if (bst && tid == 0) bst[4 * (size_t)wg + 2] = wall_clock64();
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 2);

@@ -230,24 +230,23 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     if constexpr (FAIR) fair += (double)f32;
 }
 
-// The slices of one wavefront: the slots of its (XCD-weighted) cyclic deal, like the window tiles; the next descriptor and the
-// columns' lengths travel while the current slice is processed.
+// The slices of one wavefront: descriptors q0, q0 + S, ... (plain cyclic deal: the XCD-weighted deal of the window tiles, carried
+// into this loop, measured +2.5 ... 4.6 % on all-simplex maps whatever its table -- more scalar state across fourteen variants --
+// and the slices' own imbalance is small); the next descriptor travels while the current slice is processed.
 template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
-__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, const Deal& deal, int lane, T sd, double& obj, double& ssq, double& fair) {
+__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, double& obj, double& ssq, double& fair) {
     const uint32_t n_sell = g.n_sell;
-    uint32_t ks = 0, q = deal_slot(deal, 0);
-    if (q >= n_sell) return;
-    uint32_t q_next = deal_slot(deal, 1);
+    if (q0 >= n_sell) return;
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
     auto load_desc = [&](uint32_t q) -> uint32_t {
         const uint32_t t = q < n_sell ? q : n_sell - 1u;
         return byte_offset(g.sell_desc + (size_t)t * kSellDescWords, dlane * 4u)[0];
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
-    uint32_t dv = load_desc(q);
-    for (; q < n_sell; q = q_next, q_next = deal_slot(deal, ++ks + 1u)) {
+    uint32_t dv = load_desc(q0);
+    for (uint32_t q = q0; q < n_sell; q += S) {
         const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
-        dv = load_desc(q_next);
+        dv = load_desc(q + S);
         const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
         const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
         const bool has_col = lane < ncols;

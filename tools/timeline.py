@@ -32,7 +32,7 @@ tl = f.timeline().astype(np.int64)
 t0 = tl[:, 0].min()
 us = (tl - t0) / 100.0  # 100 MHz
 print("info", f.info())
-print("balance table", [int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(16)])
+print("balance table", [int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(8)])
 print("kernel span us", us[:, 3].max())
 for k, name in enumerate(["start", "prologue_done", "loop_done", "end"]):
     print(f"{name:14s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
