@@ -54,7 +54,8 @@ struct ProjDev {
 constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
 constexpr int kFusedWaves = kFusedThreads / 64;
 constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
-constexpr int kBalLaunches = 8;     // launches of a handle that adapt the table; it is frozen afterwards
+constexpr int kBalLaunches = 8;     // first launches of a handle, which all adapt the table ...
+constexpr int kBalEvery = 16;       // ... afterwards every kBalEvery-th launch does
 constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
 constexpr size_t kLdsScratch = 512;            // per-workgroup reduction scratch (bytes)
 constexpr int kProjLdsSlots = 256;            // projection table slots in LDS (simplex.h kProjLds)
@@ -83,7 +84,7 @@ struct dl_matching {
     // first launches; null = every XCD takes the same number of rounds
     int32_t* bal = nullptr;                  // owned, device, 8 ints
     unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, windows done
-    int bal_launches = 0;                    // launches that have adapted the table so far
+    int bal_launches = 0;                    // launches of the handle so far
     int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)
     int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)
     int64_t n_short = 0;                // layout 4: window tiles (the single-column ones follow them in the descriptor array)

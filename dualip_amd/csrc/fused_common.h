@@ -489,6 +489,9 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
     }
     __syncthreads();
     if (tid == 0) {
+        // (XCD balance: every wavefront of the workgroup has walked all its tiles by now)
+        unsigned long long* bst = kernarg_args(g).bal_stamps;
+        if (bst) bst[4 * (size_t)wg + 2] = wall_clock64();
         double o = 0.0, q = 0.0;
         for (int k = 0; k < kFusedWaves; ++k) {
             o += w.red_s[2 * k];

@@ -411,24 +411,31 @@ __global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, cons
 }
 
 // fairness pair: (A x) of the two dense rows from the workgroups' partial sums (fixed order)
-// XCD balance of the window tiles (fused_common.h: Deal).  st[w][0..1] = wall clock of workgroup w after its prologue and after its
-// window tiles (wavefront 0; workgroup w runs on XCD w mod 8).  Rate of an XCD = its rounds / its mean duration; the rounds are
-// re-divided in proportion to the rates (gain 0.6, at most +-15 % from the even share), rounded down, and the missing tiles go to the
-// XCDs with the largest remainders.  One thread does the arithmetic: 8 numbers.
+// XCD balance of the window tiles (fused_common.h: Deal).  st[w][0..2] = wall clock of workgroup w after its prologue, after
+// wavefront 0's window tiles, and when all its wavefronts have walked everything (workgroup w runs on XCD w mod 8).  The knob is the
+// number of window rounds n_x of each XCD, the target equal FINISH times (half the wavefronts walk their slices first, so the end
+// of wavefront 0's windows is not the end of the workgroup): n_x <- n_x - gain (D_x - mean D) / tau, D_x = mean finish time of
+// the XCD's workgroups, tau = the measured time of one window round; at most +-15 % from the even share; rounded down, and the
+// missing tiles go to the XCDs with the largest remainders.  One thread does the arithmetic: 8 numbers.
 __global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ n, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, int min_rounds) {
-    __shared__ double dur[8];
+    __shared__ double dwin[8], dall[8];
     const int lane = threadIdx.x;
     if (lane < 8) {
-        double t = 0.0;
-        int cnt = 0;
+        double tw = 0.0, ta = 0.0;
+        int cw = 0, ca = 0;
         for (int w = lane; w < n_wg; w += 8) {
-            const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1];
+            const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1], c = st[4 * (size_t)w + 2];
             if (b > a) {
-                t += (double)(b - a);
-                cnt += 1;
+                tw += (double)(b - a);
+                cw += 1;
+            }
+            if (c > a) {
+                ta += (double)(c - a);
+                ca += 1;
             }
         }
-        dur[lane] = cnt > 0 ? t / cnt : 0.0;
+        dwin[lane] = cw > 0 ? tw / cw : 0.0;
+        dall[lane] = ca > 0 ? ta / ca : 0.0;
     }
     __syncthreads();
     if (lane != 0) return;
@@ -437,28 +444,31 @@ __global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ n
     const double need = N / wpx;  // rounds, summed over the XCDs
     const double even = need / 8.0;
     if (even < (double)min_rounds - 1.0) return;
-    double rate[8], rsum = 0.0;
+    double tau = 0.0, dmean = 0.0;
     bool ok = true;
     for (int x = 0; x < 8; ++x) {
-        ok = ok && dur[x] > 0.0 && n[x] > 0;
-        rate[x] = ok ? (double)n[x] / dur[x] : 0.0;
-        rsum += rate[x];
+        ok = ok && dwin[x] > 0.0 && dall[x] > 0.0 && n[x] > 0;
+        tau += ok ? dwin[x] / (double)n[x] : 0.0;
+        dmean += dall[x];
     }
-    if (!ok || !(rsum > 0.0)) return;
+    if (!ok) return;
+    tau /= 8.0;
+    dmean /= 8.0;
+    if (!(tau > 0.0)) return;
     double want[8];
     long long have = 0;
     int32_t fl[8];
     for (int x = 0; x < 8; ++x) {
-        double t = (double)n[x] + 0.6 * (need * rate[x] / rsum - (double)n[x]);
+        double t = (double)n[x] - 0.5 * (dall[x] - dmean) / tau;
         t = t < 0.85 * even ? 0.85 * even : (t > 1.15 * even ? 1.15 * even : t);
         want[x] = t;
         fl[x] = (int32_t)t;
         have += fl[x];
     }
     // every tile must have a slot: sum of rounds * wavefronts per XCD >= N
-    for (int guard = 0; guard < 64 && (double)have * wpx < N; ++guard) {
+    for (int guard = 0; guard < 512 && (double)have * wpx < N; ++guard) {
         int best = 0;
-        double bf = -1.0;
+        double bf = -1e300;
         for (int x = 0; x < 8; ++x) {
             const double f = want[x] - (double)fl[x];
             if (f > bf) {
@@ -467,10 +477,9 @@ __global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ n
             }
         }
         fl[best] += 1;
-        want[best] = (double)fl[best];  // (its remainder is used up)
         have += 1;
     }
-    if ((double)have * wpx < N) return;  // (cannot happen: the clamps leave room; keep the old table)
+    if ((double)have * wpx < N) return;  // (keep the old table)
     for (int x = 0; x < 8; ++x) n[x] = fl[x];
 }
 
@@ -545,7 +554,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.sell_f = static_cast<const T*>(h->sell_f);
     args.n_sell = (uint32_t)h->n_sell;
     args.balance = h->bal;
-    args.bal_stamps = (h->bal && h->bal_launches < kBalLaunches) ? h->bal_stamps : nullptr;
+    // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
+    //  slices get slower as the Newton passes multiply, the windows do not)
+    args.bal_stamps = (h->bal && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
     args.do_apply = 0;
     args.apply = ApplyArgs<T>();
     if (pending && pending->valid) {
@@ -585,11 +596,11 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
-    if (args.bal_stamps) {  // the first launches of a handle adapt its per-XCD rounds to what their stamps say (a few microseconds each)
+    if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
         hipLaunchKernelGGL(xcd_balance_kernel, dim3(1), dim3(64), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds);
         DL_HIP(hipGetLastError());
-        h->bal_launches += 1;
     }
+    if (h->bal) h->bal_launches += 1;
     if (h->fair) {
         hipLaunchKernelGGL(fair_finish_kernel, dim3(1), dim3(256), 0, st, h->partial_fair, h->n_wg, h->dense_ax);
         DL_HIP(hipGetLastError());
