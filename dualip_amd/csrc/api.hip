@@ -811,21 +811,27 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             default: h->has_unbounded = true; break;
         }
     }
-    // ---- XCD balance of the window tiles (fused_common.h: Deal): a table of rounds per XCD, even to start with, adapted by the first launches.
-    //      Only where a round is a small share of a wavefront's work (>= kBalMinRounds rounds) and workgroups map evenly onto XCDs.
-    //      DUALIP_HIP_XCD_BALANCE=0: every XCD keeps the same number of rounds. ----
+    // ---- balance of the window tiles (fused_common.h: Deal): rounds per workgroup, even to start with, adapted from the launches' stamps.
+    //      Only where a round is a small share of a wavefront's work (>= kBalMinRounds rounds).  DUALIP_HIP_XCD_BALANCE=0: even deal. ----
     {
         const char* be = getenv("DUALIP_HIP_XCD_BALANCE");
         const int64_t S = (int64_t)h->n_wg * kFusedWaves;
         const int64_t rw = S > 0 ? (h->n_short + S - 1) / S : 0;
         if (const char* mr = getenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
-        if (h->layout == 4 && !(be && be[0] == '0') && h->n_wg >= 8 && h->n_wg % 8 == 0 && rw >= h->bal_min_rounds) {
-            CK(owned_malloc(h, (void**)&h->bal, sizeof(int32_t) * 8));
-            CK(owned_malloc(h, (void**)&h->bal_stamps, sizeof(unsigned long long) * 4 * (size_t)h->n_wg));
-            int32_t tab[8];
-            for (int x = 0; x < 8; ++x) tab[x] = (int32_t)rw;
-            CKH(hipMemcpyAsync(h->bal, tab, sizeof(tab), hipMemcpyHostToDevice, st));
-            CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
+        if (const char* gn = getenv("DUALIP_HIP_BALANCE_GAIN")) h->bal_gain = atof(gn) > 0.0 ? atof(gn) : h->bal_gain;
+        const bool adapt = !(be && be[0] == '0') && h->n_wg >= 2 && h->n_wg <= 1024 && rw >= h->bal_min_rounds;
+        if (h->layout == 4) {  // (every layout-4 handle has a table; only those that adapt have stamps)
+            const size_t words = bal_table_words(h->n_wg > 0 ? h->n_wg : 1);
+            CK(owned_malloc(h, (void**)&h->bal, sizeof(int32_t) * words));
+            std::vector<int32_t> tab(words, 0);
+            const int32_t n0 = adapt ? (int32_t)rw : 0x7FFFFFFF;
+            tab[0] = n0;  // minimum = every workgroup's rounds: no tail tables in use
+            for (int w = 0; w < h->n_wg; ++w) tab[4 + (size_t)w] = n0;
+            CKH(hipMemcpyAsync(h->bal, tab.data(), sizeof(int32_t) * words, hipMemcpyHostToDevice, st));
+            if (adapt) {
+                CK(owned_malloc(h, (void**)&h->bal_stamps, sizeof(unsigned long long) * 4 * (size_t)h->n_wg));
+                CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
+            }
             CKH(hipStreamSynchronize(st));  // (tab is a host temporary)
         }
     }
@@ -862,10 +868,10 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
         default:
-            if (what >= 18 && what < 26) {  // XCD balance table (synchronous read; -1: no table)
-                if (!h->bal) return -1;
+            if (what >= 18 && what < 18 + 1024) {  // rounds of workgroup (what - 18) in the window tiles' deal (synchronous read; -1: no table)
+                if (!h->bal_stamps || what - 18 >= h->n_wg) return -1;
                 int32_t v = -1;
-                if (hipMemcpy(&v, h->bal + (what - 18), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                if (hipMemcpy(&v, h->bal + 4 + (what - 18), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
                 return v;
             }
             return -1;

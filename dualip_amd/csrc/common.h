@@ -54,6 +54,8 @@ struct ProjDev {
 constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
 constexpr int kFusedWaves = kFusedThreads / 64;
 constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
+constexpr int kBalTail = 64;       // balance: most rounds by which two workgroups may differ (fused_common.h: Deal, table layout)
+inline size_t bal_table_words(int n_wg) { return 4 + (size_t)n_wg + kBalTail + (size_t)kBalTail * (size_t)n_wg; }
 constexpr int kBalLaunches = 8;     // first launches of a handle, which all adapt the table ...
 constexpr int kBalEvery = 16;       // ... afterwards every kBalEvery-th launch does
 constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
@@ -80,10 +82,11 @@ struct dl_matching {
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;
     int64_t n_tiles = 0, n_long = 0;
-    // XCD balance (fused_common.h: Deal): rounds of the window tiles' cyclic deal per XCD, adapted from per-workgroup stamps of the
-    // first launches; null = every XCD takes the same number of rounds
-    int32_t* bal = nullptr;                  // owned, device, 8 ints
-    unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, windows done
+    // Balance (fused_common.h: Deal): rounds of the window tiles' cyclic deal per workgroup + the tables of the last rounds, adapted
+    // from per-workgroup stamps; null = every workgroup takes the same number of rounds
+    int32_t* bal = nullptr;                  // owned, device, bal_table_words(n_wg) ints
+    unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, wavefront 0's windows done, all done
+    double bal_gain = 0.3;                   // (DUALIP_HIP_BALANCE_GAIN)
     int bal_launches = 0;                    // launches of the handle so far
     int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)
     int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)

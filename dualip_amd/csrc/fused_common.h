@@ -37,7 +37,7 @@ struct FusedArgs {
     uint32_t n_xlong;   // layout 4: very long single-column tiles (walked by a whole workgroup), descriptors after those
     uint32_t desc_words;           // layout 4: dwords per window descriptor: 12, or 2 (compact: { W[31:0] ; W[39:32] | hi << 8 | lo << 17 | proj id << 20 })
     const uint32_t* __restrict__ long32;  // layout 4: the single-column tiles' descriptors (12 dwords each)
-    const int32_t* balance;               // layout 4: rounds of the window tiles' cyclic deal per XCD (8 entries), or null (same for all)
+    const int32_t* balance;               // layout 4: the window tiles' weighted deal (Deal: rounds per workgroup + tables), or null (same for all)
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
@@ -64,35 +64,27 @@ struct FusedArgs {
     ApplyArgs<T> apply;
 };
 
-// ---- the cyclic deal of tiles to wavefronts, with a per-XCD number of rounds ----
-// Unweighted, wavefront W of the S = 16 * workgroups of a launch takes slots W, W + S, W + 2S, ...  The eight XCDs do not stream at
-// the same speed (workgroup w runs on XCD w mod 8; measured at 100M entities, all-box: the XCDs' mean finish times spread over
-// 8.5 % -- 1382 ... 1505 us -- and the launch ends with the slowest), so each XCD x gets its own number of rounds n_x: in round k
-// only the XCDs with n_x > k take part, their wavefronts ranked by (workgroup / 8, XCD, wavefront).  Slot of wavefront (g, x, v)
-// in round k:  sum_x' Wx * min(k, n_x')  +  (g * c_k + below_k(x)) * 16 + v,   c_k = #{x': n_x' > k},  below_k(x) = #{x' < x: n_x' > k},
-// Wx = wavefronts per XCD -- a bijection onto the slots for any table.  For k < min n_x that is k S + W: the common case costs nothing;
-// the general formula (a scalar loop over eight table entries) runs in the last few per cent of the rounds.
-// A wavefront carries only n_min and its own n across its loops (two scalar registers; everything else is recomputed from the
-// workgroup / wavefront ids where it is needed: carried as a struct of eleven scalars, the deal's state was spilled to vector lanes
-// inside every slice variant -- all-simplex maps +3 %).
+// ---- the cyclic deal of window tiles to wavefronts, with a per-WORKGROUP number of rounds ----
+// Unweighted, wavefront W of the S = 16 * workgroups of a launch takes slots W, W + S, W + 2S, ...  The workgroups do not stream at
+// the same speed: the eight XCDs differ (workgroup w runs on XCD w mod 8; measured at 100M entities, all-box: the XCDs' mean finish
+// times spread over 8.5 %, the odd XCDs late) and inside an XCD single workgroups are persistently early or late (12.5M entities:
+// +-4 % of the launch, correlation 0.9 from launch to launch) -- and the launch ends with the slowest.  So every workgroup w gets
+// its own number of rounds n_w: in round k only the workgroups with n_w > k take part, ranked by workgroup.  Slot of wavefront v
+// of workgroup w in round k:   16 sum_w' min(k, n_w')  +  16 #{w' < w: n_w' > k}  +  v   -- a bijection onto the slots for any
+// table.  For k < min n_w that is k S + W: the common case costs nothing; for the last rounds the two terms come from tables the
+// balance kernel (matching_kernels.hip) writes next to the rounds.
+// Table layout (int32 words): [0] min n_w, [1] J = max n_w - min n_w (<= kBalTail), [2..3] unused, [4 .. 4 + G) n_w,
+// then J offsets 16 sum_w' min(k, n_w') for k = min + j, then J x G ranks #{w' < w: n_w' > k}.
 struct Deal {
     uint32_t n_mine, n_min;
 };
 __device__ __forceinline__ Deal make_deal(const int32_t* tab) {
+    // (layout-4 handles always have a table -- an even deal is min = every n_w = 2^31 - 1 -- so there is no null case to branch on.
+    //  It lives in global memory the compiler cannot prove constant: its loads are vector loads, and without the readfirstlane
+    //  every slot computation downstream runs on the vector unit -- +20 VALU per window tile, measured)
     Deal d;
-    d.n_mine = 0xFFFFFFFFu;
-    d.n_min = 0xFFFFFFFFu;
-    if (tab) {
-        // (the table lives in global memory the compiler cannot prove constant: its loads are vector loads, and without the
-        //  readfirstlane every slot computation downstream runs on the vector unit -- +20 VALU per window tile, measured)
-        uint32_t mn = 0xFFFFFFFFu;
-        for (int x = 0; x < 8; ++x) {
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(tab[x]);
-            mn = n < mn ? n : mn;
-        }
-        d.n_min = mn;
-        d.n_mine = (uint32_t)__builtin_amdgcn_readfirstlane(tab[blockIdx.x & 7u]);
-    }
+    d.n_min = (uint32_t)__builtin_amdgcn_readfirstlane(tab[0]);
+    d.n_mine = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + blockIdx.x]);
     return d;
 }
 // slot of this wavefront's k-th tile among N; >= N: none (and none after it).  32-bit arithmetic: N < 2^31 and a wavefront stops at
@@ -105,16 +97,11 @@ __device__ __forceinline__ uint32_t deal_slot(const Deal& d, const int32_t* tab,
         return q < N ? q : N;
     }
     if (k >= d.n_mine) return N;
-    const uint32_t wpx = (n_wg >> 3) * (uint32_t)kFusedWaves, xcd = wg & 7u;
-    uint32_t off = 0, c = 0, below = 0;
-    for (uint32_t x = 0; x < 8; ++x) {
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(tab[x]);
-        off += wpx * (n < k ? n : k);
-        const uint32_t in = n > k ? 1u : 0u;
-        c += in;
-        below += x < xcd ? in : 0u;
-    }
-    const uint32_t q = off + ((wg >> 3) * c + below) * (uint32_t)kFusedWaves + v;
+    uint32_t j = k - d.n_min;  // (< J <= kBalTail: n_mine <= n_min + J)
+    j = j < (uint32_t)kBalTail ? j : (uint32_t)kBalTail - 1u;  // (keeps the two loads below inside the table wherever the compiler places them)
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + n_wg + j]);
+    const uint32_t rank = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + n_wg + kBalTail + j * n_wg + wg]);
+    const uint32_t q = off + rank * (uint32_t)kFusedWaves + v;
     return q < N ? q : N;
 }
 

@@ -411,76 +411,141 @@ __global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, cons
 }
 
 // fairness pair: (A x) of the two dense rows from the workgroups' partial sums (fixed order)
-// XCD balance of the window tiles (fused_common.h: Deal).  st[w][0..2] = wall clock of workgroup w after its prologue, after
-// wavefront 0's window tiles, and when all its wavefronts have walked everything (workgroup w runs on XCD w mod 8).  The knob is the
-// number of window rounds n_x of each XCD, the target equal FINISH times (half the wavefronts walk their slices first, so the end
-// of wavefront 0's windows is not the end of the workgroup): n_x <- n_x - gain (D_x - mean D) / tau, D_x = mean finish time of
-// the XCD's workgroups, tau = the measured time of one window round; at most +-15 % from the even share; rounded down, and the
-// missing tiles go to the XCDs with the largest remainders.  One thread does the arithmetic: 8 numbers.
-__global__ __launch_bounds__(64) void xcd_balance_kernel(int32_t* __restrict__ n, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, int min_rounds) {
-    __shared__ double dwin[8], dall[8];
-    const int lane = threadIdx.x;
-    if (lane < 8) {
-        double tw = 0.0, ta = 0.0;
-        int cw = 0, ca = 0;
-        for (int w = lane; w < n_wg; w += 8) {
-            const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1], c = st[4 * (size_t)w + 2];
-            if (b > a) {
-                tw += (double)(b - a);
-                cw += 1;
-            }
-            if (c > a) {
-                ta += (double)(c - a);
-                ca += 1;
-            }
+// Balance of the window tiles (fused_common.h: Deal).  st[w][0..2] = wall clock of workgroup w after its prologue, after wavefront
+// 0's window tiles, and when all its wavefronts have walked everything.  The knob is the number of window rounds n_w of each
+// workgroup, the target equal FINISH times (half the wavefronts walk their slices first, so the end of wavefront 0's windows is not
+// the end of the workgroup): n_w <- n_w - gain (D_w - mean D) / tau, D_w = the workgroup's finish time, tau = the measured time
+// of one window round; at most +-15 % / +-kBalTail/2 rounds from the even share; rounded down, the missing rounds go to the
+// workgroups with the largest remainders; then the offsets and ranks of the rounds above the minimum are tabulated.
+// One workgroup of 1024 threads, thread w = workgroup w (n_wg <= 1024).
+__global__ __launch_bounds__(1024) void wg_balance_kernel(int32_t* __restrict__ tab, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, int min_rounds,
+                                                          double gain) {
+    __shared__ double red[16];
+    __shared__ long long redi[16];
+    __shared__ double frac_s[1024];
+    __shared__ int flag_wave[16];
+    __shared__ int bcast[4];
+    const int w = threadIdx.x, lane = w & 63, wave = w >> 6;
+    const bool live = w < n_wg;
+    auto block_sum = [&](double x) -> double {
+        x = wave_allreduce(x, OpAdd());
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q];
+        return t;
+    };
+    auto block_sum_i = [&](long long x) -> long long {
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(x & 0xFFFFFFFFll)), hi = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(x >> 32));
+            x += ((long long)hi << 32) | (unsigned int)lo;
         }
-        dwin[lane] = cw > 0 ? tw / cw : 0.0;
-        dall[lane] = ca > 0 ? ta / ca : 0.0;
+        __syncthreads();
+        if (lane == 0) redi[wave] = x;
+        __syncthreads();
+        long long t = 0;
+        for (int q = 0; q < 16; ++q) t += redi[q];
+        return t;
+    };
+    int32_t* n = tab + 4;
+    const double need = ceil((double)n_win / (double)kFusedWaves);  // rounds, summed over the workgroups
+    const double even = need / (double)n_wg;
+    if (even < (double)min_rounds - 1.0) return;  // (uniform: every thread)
+    double dall = 0.0, dwin = 0.0;
+    int n_old = 0;
+    bool ok = true;
+    if (live) {
+        const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1], c = st[4 * (size_t)w + 2];
+        n_old = n[w];
+        ok = b > a && c > a && n_old > 0;
+        dwin = ok ? (double)(b - a) : 0.0;
+        dall = ok ? (double)(c - a) : 0.0;
+    }
+    const double bad = block_sum(ok ? 0.0 : 1.0);
+    if (bad > 0.0) return;  // (a launch without window tiles in some workgroup, or no stamps: keep the table)
+    const double dmean = block_sum(dall) / (double)n_wg;
+    const double tau = block_sum(live ? dwin / (double)n_old : 0.0) / (double)n_wg;
+    if (!(tau > 0.0)) return;
+    double t = 0.0;
+    if (live) {
+        t = (double)n_old - gain * (dall - dmean) / tau;
+        const double lo = fmax(0.85 * even, even - 0.5 * kBalTail + 2.0), hi = fmin(1.15 * even, even + 0.5 * kBalTail - 2.0);
+        t = t < lo ? lo : (t > hi ? hi : t);
+        t = t < 1.0 ? 1.0 : t;
+    }
+    int fl = live ? (int)t : 0;
+    long long have = block_sum_i(fl);
+    long long deficit = (long long)need - have;
+    if (deficit > 0) {  // every tile must have a slot: the missing rounds go to the largest remainders
+        const int all = (int)(deficit / n_wg);
+        fl += live ? all : 0;
+        deficit -= (long long)all * n_wg;
+        frac_s[w] = live ? t - floor(t) : -1.0;
+        __syncthreads();
+        if (live && deficit > 0) {
+            int larger = 0;
+            const double mine = frac_s[w];
+            for (int q = 0; q < n_wg; ++q) larger += (frac_s[q] > mine || (frac_s[q] == mine && q < w)) ? 1 : 0;
+            fl += larger < (int)deficit ? 1 : 0;
+        }
+    }
+    // minimum / maximum of the new rounds
+    int mn = live ? fl : 0x7FFFFFFF, mx = live ? fl : 0;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int a = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, mn), b = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, mx);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
     }
     __syncthreads();
-    if (lane != 0) return;
-    const double wpx = (double)((n_wg >> 3) * kFusedWaves);
-    const double N = (double)n_win;
-    const double need = N / wpx;  // rounds, summed over the XCDs
-    const double even = need / 8.0;
-    if (even < (double)min_rounds - 1.0) return;
-    double tau = 0.0, dmean = 0.0;
-    bool ok = true;
-    for (int x = 0; x < 8; ++x) {
-        ok = ok && dwin[x] > 0.0 && dall[x] > 0.0 && n[x] > 0;
-        tau += ok ? dwin[x] / (double)n[x] : 0.0;
-        dmean += dall[x];
+    if (lane == 0) {
+        flag_wave[wave] = mn;
+        redi[wave] = mx;
     }
-    if (!ok) return;
-    tau /= 8.0;
-    dmean /= 8.0;
-    if (!(tau > 0.0)) return;
-    double want[8];
-    long long have = 0;
-    int32_t fl[8];
-    for (int x = 0; x < 8; ++x) {
-        double t = (double)n[x] - 0.5 * (dall[x] - dmean) / tau;
-        t = t < 0.85 * even ? 0.85 * even : (t > 1.15 * even ? 1.15 * even : t);
-        want[x] = t;
-        fl[x] = (int32_t)t;
-        have += fl[x];
-    }
-    // every tile must have a slot: sum of rounds * wavefronts per XCD >= N
-    for (int guard = 0; guard < 512 && (double)have * wpx < N; ++guard) {
-        int best = 0;
-        double bf = -1e300;
-        for (int x = 0; x < 8; ++x) {
-            const double f = want[x] - (double)fl[x];
-            if (f > bf) {
-                bf = f;
-                best = x;
-            }
+    __syncthreads();
+    if (w == 0) {
+        int a = 0x7FFFFFFF, b = 0;
+        for (int q = 0; q < 16; ++q) {
+            a = flag_wave[q] < a ? flag_wave[q] : a;
+            b = (int)redi[q] > b ? (int)redi[q] : b;
         }
-        fl[best] += 1;
-        have += 1;
+        bcast[0] = a;
+        bcast[1] = b;
     }
-    if ((double)have * wpx < N) return;  // (keep the old table)
-    for (int x = 0; x < 8; ++x) n[x] = fl[x];
+    __syncthreads();
+    const int n_min = bcast[0], J = bcast[1] - bcast[0];
+    if (J > kBalTail || n_min < 1) return;  // (cannot happen: the clamps bound the range; keep the old table)
+    if (live) n[w] = fl;
+    // tables of the rounds above the minimum: wavefront q tabulates rounds q, q + 16, ... on its own (no workgroup barriers: with
+    // them this kernel took ~50 us, 0.5 % of the launches it follows)
+    __shared__ int fl_s[1024];
+    fl_s[w] = live ? fl : 0;
+    __syncthreads();
+    int32_t* off = tab + 4 + n_wg;
+    int32_t* rank = off + kBalTail;
+    for (int j = wave; j < J; j += 16) {
+        const int k = n_min + j;
+        int running = 0;
+        long long sum_min = 0;
+        for (int base = 0; base < n_wg; base += 64) {
+            const int ww = base + lane;
+            const int f = ww < n_wg ? fl_s[ww] : 0;
+            const bool in = ww < n_wg && f > k;
+            const unsigned long long bal = __ballot(in);
+            if (ww < n_wg) rank[(size_t)j * n_wg + ww] = running + __popcll(bal & ((1ull << lane) - 1ull));
+            running += __popcll(bal);
+            sum_min += ww < n_wg ? (f < k ? f : k) : 0;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(sum_min & 0xFFFFFFFFll)), hi = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(sum_min >> 32));
+            sum_min += ((long long)hi << 32) | (unsigned int)lo;
+        }
+        if (lane == 0) off[j] = (int32_t)(sum_min * kFusedWaves);
+    }
+    if (w == 0) {
+        tab[0] = n_min;
+        tab[1] = J;
+    }
 }
 
 __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restrict__ partial_fair, int n_wg, double* __restrict__ dense_ax) {
@@ -556,7 +621,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.balance = h->bal;
     // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
     //  slices get slower as the Newton passes multiply, the windows do not)
-    args.bal_stamps = (h->bal && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
+    args.bal_stamps = (h->bal_stamps && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
     args.do_apply = 0;
     args.apply = ApplyArgs<T>();
     if (pending && pending->valid) {
@@ -597,10 +662,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
-        hipLaunchKernelGGL(xcd_balance_kernel, dim3(1), dim3(64), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds);
+        hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
         DL_HIP(hipGetLastError());
     }
-    if (h->bal) h->bal_launches += 1;
+    if (h->bal_stamps) h->bal_launches += 1;
     if (h->fair) {
         hipLaunchKernelGGL(fair_finish_kernel, dim3(1), dim3(256), 0, st, h->partial_fair, h->n_wg, h->dense_ax);
         DL_HIP(hipGetLastError());

@@ -37,7 +37,14 @@ struct alignas(sizeof(RowT) * 4) RowQuad {
 template <class T>
 __device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, int k) {
     unsigned long long* tl = kernarg_args(g).timeline;
-    if (tl && tid == 0) tl[4 * (size_t)wg + k] = wall_clock64();
+    if (tl && tid == 0) {
+        unsigned long long t = wall_clock64();
+        if (k == 0) {  // (developer aid: the XCD this workgroup really runs on rides in the top four bits of its first stamp)
+            const unsigned int xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11));
+            t = (t & 0x0FFFFFFFFFFFFFFFull) | ((unsigned long long)(xcc & 0xFu) << 60);
+        }
+        tl[4 * (size_t)wg + k] = t;
+    }
 }
 
 // HOT: the hot-rows plan (common.h) -- rows are renumbered by frequency, rows < g.m_hot gather from / scatter to LDS, the
@@ -125,7 +132,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     // than one whose sixteen wavefronts move through the phases together.  Same box, 100M mixed: iterations 801-900 1.603 -> 1.557
     // ms (-2.8 %), whole 1000-iteration solve 1.600 -> 1.567 s, iterations 6-35 unchanged.  (DUALIP_HIP_ABLATE=128: windows first
     // everywhere.  Wavefront 0, whose stamps feed the XCD balance, is windows-first.)
-    const bool sell_first = !(g.ablate & 128) && ((wave >> 2) & 1);
+    // (only for the plan with the dual vector and the gradient in LDS: the others are bound by their global gathers / atomics)
+    const bool sell_first = LAM_LDS && GRAD_LDS && !(g.ablate & 128) && ((wave >> 2) & 1);
     Deal dealw;
     uint32_t kw = 0;                            // round
     uint32_t ti = n_tiles, ti_next = n_tiles;   // schedule slots of the current / next tile (n_tiles: none)

@@ -462,8 +462,8 @@ def test_handles_on_two_devices_in_one_process():
 
 
 def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
-    """The cyclic deal of window tiles to wavefronts with a per-XCD number of rounds (csrc/fused_common.h: Deal), adapted from the first
-    launches' stamps.  Only large problems adapt by default; here the threshold is lowered so that a 3M-entity mixed problem does.
+    """The cyclic deal of window tiles to wavefronts with a per-workgroup number of rounds (csrc/fused_common.h: Deal), adapted from
+    the launches' stamps.  Only large problems adapt by default; here the threshold is lowered so that a 3M-entity mixed problem does.
     Whatever table the timings produce, every tile keeps exactly one slot: the gradient (integer fixed point) and the primal
     are bit-identical to a handle with the even deal, the floating-point objective sums agree to rounding."""
     import os
@@ -490,17 +490,14 @@ def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
     monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS", "4")
     f = MatchingSolverDualObjectiveFunction(inp, 1e-2)
     info = f.info()
-    if info["workgroups"] % 8:
-        pytest.skip("workgroups do not map evenly onto XCDs")
+    n_wg = info["workgroups"]
     tables = set()
     for it in range(12):  # the first 8 launches adapt the table
         got = f.calculate(lam, save_primal=(it % 3 == 0))
-        tab = tuple(int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(8))
+        tab = tuple(int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(n_wg))
         tables.add(tab)
-        assert min(tab) >= 0
-        S = info["workgroups"] * 16
-        wpx = S // 8
-        assert sum(tab) * wpx >= info["tiles"] - info["long_columns"]
+        assert min(tab) >= 1 and max(tab) - min(tab) <= 64
+        assert sum(tab) * 16 >= info["tiles"] - info["long_columns"]
         assert torch.equal(got.dual_gradient, wg)
         if it % 3 == 0:
             assert torch.equal(got.primal_var, wx)

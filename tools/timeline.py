@@ -28,11 +28,13 @@ solver = AcceleratedGradientDescent(max_iter=iters, gamma=1e-3, initial_step_siz
 run = solver.start_device_run(f, torch.zeros(10_000, dtype=torch.float32, device=dev), rank=0)
 run.advance(iters)
 torch.cuda.synchronize()
-tl = f.timeline().astype(np.int64)
+raw = f.timeline().astype(np.uint64)
+raw[:, 0] &= np.uint64(0x0FFFFFFFFFFFFFFF)  # (top four bits: the workgroup's real XCD)
+tl = raw.astype(np.int64)
 t0 = tl[:, 0].min()
 us = (tl - t0) / 100.0  # 100 MHz
 print("info", f.info())
-print("balance table", [int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(8)])
+print("balance table", [int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(16)])
 print("kernel span us", us[:, 3].max())
 for k, name in enumerate(["start", "prologue_done", "loop_done", "end"]):
     print(f"{name:14s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
