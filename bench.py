@@ -387,7 +387,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # developer aid: DUALIP_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with a gloo side channel (RCCL refuses two ranks on one
-    # device; the P2P exchange does not) -- a functional check of the N > 1 harness on a single-GPU box; the number is not a result
+    # device; the P2P exchange does not) -- a functional check of the N > 1 harness on a single-GPU box; the number is not a result.
+    # (Two ranks work; with four at 10M entities each a rank's kernel spins in its bounded wait while the GPU time-slices the other
+    # processes' kernels, and the wait runs into its limit: an artefact of sharing one device, reported as such by dl_comm_check.)
     one_device = os.environ.get("DUALIP_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
