@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""BASELINE config 1 at full size, on the GPU: a MovieLens-20M-SHAPED matching problem (the data set itself is not in the
+reference tree and there is no network).  Shape and parameters as examples/movielens_matching/movies_lens_matching.py:
+138 493 users (columns) x 26 744 movies (rows), ~20 M ratings, a = 1, c = -rating in {0.5, ..., 5}, one simplex z = 1 per
+user, capacity b = 30 per movie, gamma = 0.1, step sizes 1e-8 / 1e-6.  Ratings per user are heavy tailed (20 ... ~9 000, mean
+~144) and movie popularity is Zipf-like, as in ml-20m -- so most non-zeros sit in columns longer than one 256-element window
+(the single-column path) and the dual vector does not fit the LDS (the hot-rows plan).
+
+    python benchmark/movielens_like.py [--max-iter 1000]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def generate(n_users=138_493, n_movies=26_744, seed=7, device="cuda:0"):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # ratings per user: log-normal body, clipped to [20, 9254] (ml-20m keeps users with >= 20 ratings)
+    deg = torch.exp(torch.randn(n_users, device=device, generator=g) * 1.0 + 4.35).clamp_(20, 9254).to(torch.int64)
+    total = int(deg.sum())
+    col = torch.repeat_interleave(torch.arange(n_users, device=device), deg, output_size=total)
+    # movie popularity ~ rank^-1
+    w = 1.0 / torch.arange(1, n_movies + 1, device=device, dtype=torch.float64)
+    cdf = torch.cumsum(w / w.sum(), 0)
+    mov = torch.searchsorted(cdf, torch.rand(total, device=device, dtype=torch.float64, generator=g)).clamp_(max=n_movies - 1)
+    key = torch.unique(col * n_movies + mov)  # sorted by (user, movie), duplicates dropped
+    col = torch.div(key, n_movies, rounding_mode="floor")
+    mov = key - col * n_movies
+    rating = (torch.randint(1, 11, (key.numel(),), device=device, generator=g).float()) * 0.5
+    counts = torch.bincount(col, minlength=n_users)
+    colptr = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+    colptr[1:] = torch.cumsum(counts, 0)
+    A = torch.sparse_csc_tensor(colptr, mov, torch.ones_like(rating), size=(n_movies, n_users), check_invariants=False)
+    C = torch.sparse_csc_tensor(colptr, mov, -rating, size=(n_movies, n_users), check_invariants=False)
+    return A, C, counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-iter", type=int, default=1000)
+    ap.add_argument("--capacity", type=float, default=30.0)
+    ap.add_argument("--gamma", type=float, default=0.1)
+    args = ap.parse_args()
+    from dualip_amd.objectives.matching import MatchingInputArgs
+    from dualip_amd.projections import create_projection_map
+
+    dev = "cuda:0"
+    t0 = time.perf_counter()
+    A, C, counts = generate(device=dev)
+    torch.cuda.synchronize()
+    n, m, nnz = A.shape[1], A.shape[0], A.values().numel()
+    print(f"generated {n} users x {m} movies, {nnz} ratings in {time.perf_counter() - t0:.2f}s; ratings per user: min {int(counts.min())} "
+          f"median {int(counts.median())} mean {float(counts.float().mean()):.0f} max {int(counts.max())}; "
+          f"{float((counts > 253).float().mean()) * 100:.1f}% of the users (holding {float(counts[counts > 253].sum()) / nnz * 100:.0f}% of the ratings) exceed one 256-window")
+    inp = MatchingInputArgs(A=A, c=C, projection_map=create_projection_map("simplex", {"z": 1.0}, n, indices=range(n)),
+                            b_vec=torch.full((m,), args.capacity, device=dev), equality_mask=None)
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+
+    t0 = time.perf_counter()
+    f = MatchingSolverDualObjectiveFunction(matching_input_args=inp, gamma=args.gamma)
+    torch.cuda.synchronize()
+    print(f"objective built in {time.perf_counter() - t0:.3f}s: {f.info()}")
+    solver = AcceleratedGradientDescent(max_iter=args.max_iter, gamma=args.gamma, initial_step_size=1e-8, max_step_size=1e-6, iteration_callback=False)
+    t0 = time.perf_counter()
+    res = solver.maximize(f, torch.zeros(m, device=dev))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if os.environ.get("DUALIP_HIP_TIMELINE"):
+        import numpy as np
+
+        tl = f.timeline().astype(np.int64)
+        us = (tl - tl[:, 0].min()) / 100.0
+        d = us[:, 2] - us[:, 1]
+        print(f"per-workgroup tile-loop duration of the last launch (us): min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f}; kernel span {us[:, 3].max():.0f}")
+    print(f"maximize: {args.max_iter} iterations in {dt:.3f}s ({args.max_iter / dt:.1f} iterations/s, {dt / args.max_iter * 1e3:.3f} ms each); dual objective "
+          f"{res.dual_objective:.3f} (first {res.dual_objective_log[0]:.3f})")
+
+
+if __name__ == "__main__":
+    main()

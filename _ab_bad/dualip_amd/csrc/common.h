@@ -1,0 +1,168 @@
+// common.h -- shared declarations of libdualip_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/dualip_hip.h"
+
+namespace dl {
+
+// ---------------------------------------------------------------------------------------------------------
+// status plumbing (no exception crosses the C ABI)
+// ---------------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DL_HIP(expr)                                          \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return ::dl::hip_fail(_e, #expr); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// wave tiles: the unit of work of one 64-lane wavefront
+// ---------------------------------------------------------------------------------------------------------
+// A SHORT tile is a run of whole, consecutive, non-empty columns with <= 64 non-zeros in total, all of the same
+// projection entry; lane k owns non-zero (nnz_start + k).  A LONG tile is one column with more than 64 non-zeros,
+// walked by the wavefront in 64-wide strides.
+//   w0: [ 0..39] nnz_start   [40..46] count (short tiles, 1..64)   [47] long flag   [48..63] projection id
+//   w1: short: bit k set <=> lane k starts a column (plus a sentinel bit at `count` when count < 64)
+//       long : the column length
+struct TileDesc {
+    uint64_t w0;
+    uint64_t w1;
+};
+constexpr int kTileLanes = 64;
+constexpr uint64_t kTileLongFlag = 1ull << 47;
+constexpr uint32_t kNoProj = 0xFFFFu;
+
+__host__ __device__ inline uint64_t tile_nnz_start(uint64_t w0) { return w0 & ((1ull << 40) - 1); }
+__host__ __device__ inline uint32_t tile_count(uint64_t w0) { return (uint32_t)((w0 >> 40) & 0x7F); }
+__host__ __device__ inline uint32_t tile_proj(uint64_t w0) { return (uint32_t)(w0 >> 48); }
+
+// device copy of dl_proj_desc in the working precision is built on the fly from this
+struct ProjDev {
+    int32_t kind;
+    int32_t pad;
+    double p0;
+    double p1;
+};
+
+constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
+constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
+constexpr int kBalTail = 64;       // balance: most rounds by which two workgroups may differ (fused_common.h: Deal, table layout)
+inline size_t bal_table_words(int n_wg) { return 4 + (size_t)n_wg + kBalTail + (size_t)kBalTail * (size_t)n_wg; }
+constexpr int kBalLaunches = 8;     // first launches of a handle, which all adapt the table ...
+constexpr int kBalEvery = 16;       // ... afterwards every kBalEvery-th launch does
+constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
+constexpr size_t kLdsScratch = 512;            // per-workgroup reduction scratch (bytes)
+constexpr int kProjLdsSlots = 256;            // projection table slots in LDS (simplex.h kProjLds)
+constexpr int kLogCols = 8;                    // doubles per iteration in the AGD log
+
+// ---------------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------------
+}  // namespace dl
+
+struct dl_matching {
+    int64_t m = 0, n = 0, nnz = 0;
+    int val_dtype = DL_F32;
+    int device = 0;
+    const void* a = nullptr;  // caller-owned
+    const void* c = nullptr;  // caller-owned
+    void* rowidx = nullptr;   // owned, uint16 or uint32
+    int row_bytes = 4;
+    dl::TileDesc* tiles = nullptr;      // owned (layout 1: TileDesc[]; layout 4: 12 dwords per tile)
+    int layout = 1;                     // 1 = one non-zero per lane (64-wide tiles), 4 = four per lane (256-wide tiles)
+    uint32_t* wg_tile_begin = nullptr;  // owned, [n_wg + 1]
+    dl::ProjDev* projs = nullptr;       // owned
+    int32_t n_proj = 0;
+    int64_t n_tiles = 0, n_long = 0;
+    // Balance (fused_common.h: Deal): rounds of the window tiles' cyclic deal per workgroup + the tables of the last rounds, adapted
+    // from per-workgroup stamps; null = every workgroup takes the same number of rounds
+    int32_t* bal = nullptr;                  // owned, device, bal_table_words(n_wg) ints
+    unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, wavefront 0's windows done, all done
+    double bal_gain = 0.3;                   // (DUALIP_HIP_BALANCE_GAIN)
+    int bal_launches = 0;                    // launches of the handle so far
+    int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)
+    int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)
+    int64_t n_short = 0;                // layout 4: window tiles (the single-column ones follow them in the descriptor array)
+    int64_t n_xlong = 0;                // layout 4: single-column tiles long enough for a whole workgroup (last in the array)
+    int n_wg = 0;
+    bool lam_lds = false, grad_lds = false;
+    size_t lds_bytes = 0;
+    int64_t mpad = 0;          // row stride of the partial slabs (elements)
+    void* partial = nullptr;   // owned: int64 fixed point, [n_wg][mpad] (grad_lds) or [1][mpad] (global atomics)
+    int* shift_dev = nullptr;  // owned: fixed-point exponent of the latest launch
+    double amax = 0.0, cmax = 0.0;      // max |a|, max |c| (read once at creation: A and c must not change afterwards)
+    double xmax_bounded = 0.0;          // largest |x| a bounded projection in use can return
+    double pmax_unbounded = 0.0;        // largest |bound| of the one-sided projections in use
+    bool has_unbounded = false;         // cone / identity columns exist: |x| is bounded through |v| per launch
+    int64_t row_count_max = 0;          // most non-zeros in one row
+    double* partial_scal = nullptr;  // owned: [n_wg][2]
+    size_t owned_bytes = 0;
+    bool use_dpp = true;
+    int ablate = 0;  // developer-only timing ablations, see FusedArgs
+    // "hot rows" plan (dual vector / gradient too large for the LDS): rows renumbered by frequency, the m_hot most frequent
+    // ones live in LDS, the cold tail goes through L2 (gathers) and 64-bit global atomics (cold_grad)
+    int64_t m_hot = 0;                // 0 = plan not in use
+    double hot_fraction = 1.0;        // share of the non-zeros whose row is hot
+    int32_t* row_inv = nullptr;       // owned, [m]: renumbered row -> caller's row
+    int32_t* row_perm = nullptr;      // owned, [m]: caller's row -> renumbered row
+    // device-resident AGD loop: its step kernels leave the renumbered dual vector in lam_perm and the cold accumulators
+    // zeroed for the next launch (two launches less per iteration); valid only for the dual vector at hot_ready_lambda
+    bool hot_ready = false;
+    const void* hot_ready_lambda = nullptr;
+    uint64_t hot_ready_owner = 0;           // uid of the dl_agd whose loop prepared them (never an address: a freed optimiser's
+                                            // buffers can be handed out again at the same addresses)
+    // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 are dense, +f_k / -f_k on every non-zero
+    const void* fair = nullptr;       // caller-owned val[nnz]
+    double fair_max = 0.0;            // max |f|
+    double* partial_fair = nullptr;   // owned, [n_wg]
+    double* dense_ax = nullptr;       // owned, [2]: (A x) of the two rows, written after every fused launch
+    void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
+    long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
+    // column-per-lane slices (sell.h): short columns of simplex entries, sorted by length, 64 per slice, transposed copies of
+    // their values and row indices owned by the handle
+    int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0, n_sell_nnz = 0;  // slices, their columns, slots (with padding), non-zeros
+    int64_t n_sell_mixed_cols = 0;    // columns of slices that hold more than one length (the only ones whose length bytes are read)
+    uint32_t* sell_desc = nullptr;    // owned, 4 dwords per slice
+    uint8_t* sell_len = nullptr;      // owned, [n_sell_cols]
+    uint64_t* sell_colstart = nullptr;  // owned, [n_sell_cols]: the column's first non-zero in the caller's arrays (primal output)
+    void* sell_a = nullptr;           // owned, val[n_sell_elems]
+    void* sell_c = nullptr;
+    void* sell_r = nullptr;           // owned, row indices (row_bytes wide)
+    void* sell_f = nullptr;           // owned: fairness values in slice order (dl_matching_set_fairness)
+    int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)
+    unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
+    // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
+    bool prof_on = false;
+    int prof_stride = 1;      // bracket every prof_stride-th launch (the event records cost ~5 us per launch pair)
+    uint64_t prof_seen = 0;
+    size_t prof_used = 0;
+    std::vector<hipEvent_t> prof_start, prof_stop;
+};
+
+struct dl_agd {
+    uint64_t uid = 0;        // process-unique, never reused
+    int64_t m = 0, max_iter = 0;
+    int val_dtype = DL_F32;
+    void* x = nullptr;       // owned, val[m]: point of evaluation
+    void* y = nullptr;       // owned
+    void* y_old = nullptr;   // owned: the dual stored with the previous history entry
+    void* g = nullptr;       // owned: gradient of the latest step (A x - b)
+    void* g_old = nullptr;   // owned
+    const uint8_t* eq_mask = nullptr;  // caller-owned
+    float* beta = nullptr;   // owned, float[max_iter]
+    double* log = nullptr;   // owned, [max_iter][kLogCols]
+    void* state = nullptr;   // owned, two dl::AgdDevState (double buffered)
+    int state_cur = 0;
+    void* x_alt = nullptr;   // owned: the buffer the next iterate is written to
+    double* packed = nullptr;  // owned scratch double[m+2]: the sums the latest step used
+    double* packed_blk[3] = {nullptr, nullptr, nullptr};  // owned, lazily: reduced sums of the further blocks of a split shard
+    double* partial_stats = nullptr;  // owned: per-workgroup partial reductions of the step kernel
+};

@@ -1,0 +1,509 @@
+// fused_common.h -- pieces shared by the two tile layouts of the fused pass (matching_kernels.hip: one non-zero per
+// lane, 64-wide tiles; matching_kernels4.hip: four per lane, 256-wide tiles): kernel arguments, the exact fixed-point
+// scatter, SGPR-base addressing and the single-column ("long tile") walker.
+#pragma once
+#include "agd_step.h"
+#include "common.h"
+#include "simplex.h"
+#include "wave.h"
+
+namespace dl {
+
+template <class T>
+struct FusedArgs {
+    const uint32_t* __restrict__ tiles32;  // TileDesc as 4 dwords each
+    const uint32_t* __restrict__ wg_tile_begin;
+    const void* __restrict__ rowidx;
+    const T* __restrict__ a;
+    const T* __restrict__ c;
+    const T* __restrict__ lambda;
+    T* __restrict__ x_out;
+    const ProjDev* __restrict__ projs;
+    long long* __restrict__ partial;     // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
+    double* __restrict__ partial_scal;   // [n_wg][2]
+    int* __restrict__ shift_out;         // fixed-point exponent chosen for this launch
+    double gamma;
+    double amax, cmax;                   // max |a|, max |c|
+    double xmax_bounded;                 // max |x| any bounded projection present can return (box bounds, simplex z)
+    double pmax_unbounded;               // max |bound| of one-sided projections present
+    double row_count_max;                // largest number of non-zeros in one row (of this shard)
+    int has_unbounded;                   // some column's projection does not bound |x| (cone / none): use the |v| bound
+    int64_t m;
+    int64_t mpad;
+    int64_t nnz;
+    int32_t n_proj;
+    uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
+    uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
+    uint32_t n_xlong;   // layout 4: very long single-column tiles (walked by a whole workgroup), descriptors after those
+    uint32_t desc_words;           // layout 4: dwords per window descriptor: 12, or 2 (compact: { W[31:0] ; W[39:32] | hi << 8 | lo << 17 | proj id << 20 })
+    const uint32_t* __restrict__ long32;  // layout 4: the single-column tiles' descriptors (12 dwords each)
+    const int32_t* balance;               // layout 4: the window tiles' weighted deal (Deal: rounds per workgroup + tables), or null (same for all)
+    unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
+    int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
+    unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
+    int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does
+    long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed)
+    const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
+    // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 carry +f_k / -f_k on EVERY non-zero k
+    const T* fair;                 // f, in the order of a / c, or null
+    const T* lambda_orig;          // the caller's dual vector (g.lambda is the renumbered copy under the hot-rows plan)
+    double* partial_fair;          // [n_wg]: sum f_k x_k of the workgroup
+    double fair_max;               // max |f| (0 without the pair): enters the |v| bound of unbounded projections
+    // column-per-lane slices (sell.h)
+    const uint32_t* __restrict__ sell_desc;
+    const uint8_t* __restrict__ sell_len;
+    const uint64_t* __restrict__ sell_colstart;
+    const T* __restrict__ sell_a;
+    const T* __restrict__ sell_c;
+    const void* __restrict__ sell_r;
+    const T* __restrict__ sell_f;
+    uint32_t n_sell;
+    // the previous iteration's optimiser step, applied in this launch's prologue (agd_step.h): do_apply != 0 => `lambda` is not read,
+    // every workgroup forms the new iterate from apply.{x, g_new, y} and stages THAT; workgroup 0 also stores it (and the state / log)
+    int do_apply;
+    ApplyArgs<T> apply;
+};
+
+// ---- the cyclic deal of window tiles to wavefronts, with a per-WORKGROUP number of rounds ----
+// Unweighted, wavefront W of the S = 16 * workgroups of a launch takes slots W, W + S, W + 2S, ...  The workgroups do not stream at
+// the same speed: the eight XCDs differ (workgroup w runs on XCD w mod 8; measured at 100M entities, all-box: the XCDs' mean finish
+// times spread over 8.5 %, the odd XCDs late) and inside an XCD single workgroups are persistently early or late (12.5M entities:
+// +-4 % of the launch, correlation 0.9 from launch to launch) -- and the launch ends with the slowest.  So every workgroup w gets
+// its own number of rounds n_w: in round k only the workgroups with n_w > k take part, ranked by workgroup.  Slot of wavefront v
+// of workgroup w in round k:   16 sum_w' min(k, n_w')  +  16 #{w' < w: n_w' > k}  +  v   -- a bijection onto the slots for any
+// table.  For k < min n_w that is k S + W: the common case costs nothing; for the last rounds the two terms come from tables the
+// balance kernel (matching_kernels.hip) writes next to the rounds.
+// Table layout (int32 words): [0] min n_w, [1] J = max n_w - min n_w (<= kBalTail), [2..3] unused, [4 .. 4 + G) n_w,
+// then J offsets 16 sum_w' min(k, n_w') for k = min + j, then J x G ranks #{w' < w: n_w' > k}.
+struct Deal {
+    uint32_t n_mine, n_min;
+};
+__device__ __forceinline__ Deal make_deal(const int32_t* tab) {
+    // (layout-4 handles always have a table -- an even deal is min = every n_w = 2^31 - 1 -- so there is no null case to branch on.
+    //  It lives in global memory the compiler cannot prove constant: its loads are vector loads, and without the readfirstlane
+    //  every slot computation downstream runs on the vector unit -- +20 VALU per window tile, measured)
+    Deal d;
+    d.n_min = (uint32_t)__builtin_amdgcn_readfirstlane(tab[0]);
+    d.n_mine = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + blockIdx.x]);
+    return d;
+}
+// slot of this wavefront's k-th tile among N; >= N: none (and none after it).  32-bit arithmetic: N < 2^31 and a wavefront stops at
+// its first slot >= N, so k S stays below N + 2 S.
+__device__ __forceinline__ uint32_t deal_slot(const Deal& d, const int32_t* tab, uint32_t k, uint32_t N) {
+    const uint32_t n_wg = gridDim.x, wg = blockIdx.x;
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (k < d.n_min) {  // (also the whole of an unweighted deal)
+        const uint32_t q = (k * n_wg + wg) * (uint32_t)kFusedWaves + v;
+        return q < N ? q : N;
+    }
+    if (k >= d.n_mine) return N;
+    uint32_t j = k - d.n_min;  // (< J <= kBalTail: n_mine <= n_min + J)
+    j = j < (uint32_t)kBalTail ? j : (uint32_t)kBalTail - 1u;  // (keeps the two loads below inside the table wherever the compiler places them)
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + n_wg + j]);
+    const uint32_t rank = (uint32_t)__builtin_amdgcn_readfirstlane(tab[4 + n_wg + kBalTail + j * n_wg + wg]);
+    const uint32_t q = off + rank * (uint32_t)kFusedWaves + v;
+    return q < N ? q : N;
+}
+
+// The cold paths re-read the kernel arguments from the kernarg segment (they sit at offset 0) instead of keeping a dozen
+// pointers alive in SGPRs across the hot loop.
+template <class T>
+__device__ __forceinline__ const FusedArgs<T>& kernarg_args(const FusedArgs<T>& fallback) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const FusedArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return fallback;
+#endif
+}
+
+// a x -> 64-bit fixed point (round to nearest at 2^-shift) and integer atomic add: exact, order independent.
+// float : 1.5 * 2^52 trick -- for |ax * 2^shift| < 2^51 the integer sits in the mantissa of the fma result (3 VALU);
+// double: full 62-bit conversion (the 2^-50 grid of the trick would be coarser than the values themselves).
+template <class T>
+struct FixedBits {
+    static constexpr int value = 50;
+};
+template <>
+struct FixedBits<double> {
+    static constexpr int value = 61;
+};
+__device__ __forceinline__ long long to_fixed(float ax, double scale) {
+    const double magic = 6755399441055744.0;
+    const double d = fma((double)ax, scale, magic);
+    return __double_as_longlong(d) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ long long to_fixed(double ax, double scale) { return __double2ll_rn(ax * scale); }
+
+template <class T>
+__device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax, double scale) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
+}
+
+template <class P>
+__device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
+    return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
+}
+
+// Long tile: one column too long for a window, walked by the whole wavefront.  The walk is latency bound (one wavefront,
+// dependent loads), so it moves in batches of four 64-wide strides whose loads are all issued before the first is used;
+// data are re-read (L2-hot) for every Newton pass.  Per-lane partial sums run over the strides in ascending order.
+// WG = true: the same walk by the whole workgroup (columns of thousands of non-zeros: one wavefront walking them alone sets
+// the critical path of the launch).  `lane` is then the thread index, strides are kFusedThreads wide, reductions go through
+// `red` (>= kFusedWaves doubles of LDS) with workgroup barriers -- every thread of the workgroup must make the call.
+template <class T, class RowT, bool LAM_LDS, bool WG = false>
+__device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
+                                              double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
+                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr) {
+    constexpr int kLB = 4;
+    constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
+    auto all_sum = [&](double x) -> double {
+        x = wave_allreduce(x, OpAdd());
+        if constexpr (WG) {
+            __syncthreads();  // the previous reduction's readers are done
+            if ((lane & 63) == 0) red[lane >> 6] = x;
+            __syncthreads();
+            x = red[0];
+            for (int q = 1; q < kFusedWaves; ++q) x += red[q];  // fixed order
+        }
+        return x;
+    };
+    auto all_max = [&](double x) -> double {
+        x = wave_allreduce(x, OpMax());
+        if constexpr (WG) {
+            __syncthreads();
+            if ((lane & 63) == 0) red[lane >> 6] = x;
+            __syncthreads();
+            x = red[0];
+            for (int q = 1; q < kFusedWaves; ++q) x = red[q] > x ? red[q] : x;
+        }
+        return x;
+    };
+    const bool is_simplex = is_simplex_kind(pj.kind);
+    // v = a * (-lambda/gamma) + (-c/gamma) for the elements o0 + lane + kStride u (ok[u]: inside the column)
+    auto load_batch = [&](uint64_t o0, T (&av)[kLB], T (&cv)[kLB], uint32_t (&rv)[kLB], bool (&ok)[kLB], T (&v)[kLB]) {
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            const uint64_t o = o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u;
+            ok[u] = o < len;
+            const uint64_t k = k0 + (ok[u] ? o : len - 1);
+            av[u] = g.a[k];
+            cv[u] = g.c[k];
+            rv[u] = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
+        }
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv[u] < m_hot)) ? lam_s[rv[u]] : (T)(s * g.lambda[rv[u]]);
+            v[u] = (T)((T)(av[u] * lam) + (T)(s * cv[u]));
+        }
+        if (fair_acc) {  // fairness pair: + f_k * (-(lambda_K - lambda_{K+1}) / gamma)
+#pragma unroll
+            for (int u = 0; u < kLB; ++u) {
+                const uint64_t o = o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u;
+                v[u] = (T)(v[u] + (T)(sd * g.fair[k0 + (ok[u] ? o : len - 1)]));
+            }
+        }
+    };
+    T th = (T)0;
+    bool projected = false, onehot = false;
+    // columns of up to kRB strides keep their clamped values in registers across the Newton passes (-inf outside the column);
+    // longer ones re-read the arrays (L2-hot) in every pass
+    constexpr int kRB = WG ? 8 : 16;
+    const bool cached = len <= (uint64_t)kStride * kRB && !(g.ablate & 8);
+    T vr[kRB];
+    if (is_simplex) {
+        T S = (T)0, v1 = (T)(-INFINITY);
+        if (cached) {
+#pragma unroll
+            for (int bt = 0; bt < kRB / kLB; ++bt) {
+#pragma unroll
+                for (int u = 0; u < kLB; ++u) vr[bt * kLB + u] = (T)(-INFINITY);
+                if ((uint64_t)bt * kStride * kLB < len) {
+                    T av[kLB], cv[kLB], v[kLB];
+                    uint32_t rv[kLB];
+                    bool ok[kLB];
+                    load_batch((uint64_t)bt * kStride * kLB, av, cv, rv, ok, v);
+#pragma unroll
+                    for (int u = 0; u < kLB; ++u) {
+                        const T uu = tmax(v[u], (T)0);
+                        S = ok[u] ? (T)(S + uu) : S;
+                        v1 = ok[u] ? tmax(v1, uu) : v1;
+                        vr[bt * kLB + u] = ok[u] ? uu : (T)(-INFINITY);
+                    }
+                }
+            }
+        } else {
+            for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
+                T av[kLB], cv[kLB], v[kLB];
+                uint32_t rv[kLB];
+                bool ok[kLB];
+                load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+                for (int u = 0; u < kLB; ++u) {
+                    const T uu = tmax(v[u], (T)0);
+                    S = ok[u] ? (T)(S + uu) : S;
+                    v1 = ok[u] ? tmax(v1, uu) : v1;
+                }
+            }
+        }
+        if constexpr (WG) {  // (wavefront partials combined in double, rounded once)
+            S = (T)all_sum((double)S);
+            v1 = (T)all_max((double)v1);
+        } else {
+            S = wave_allreduce(S, OpAdd());
+            v1 = wave_allreduce(v1, OpMax());
+        }
+        projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
+        const bool padded = eq_row && pj.kind == DL_PROJ_SIMPLEX_EQ && S < pj.z;
+        if (padded) {  // every entry and every padding zero is in the support: theta = (S - z) / L, final
+            th = (T)((T)(S - pj.z) / (T)eq_row[eq_bucket((int)(len < 0x7fffffff ? len : 0x7fffffff))]);
+        } else if (projected) {
+            const T z = pj.z;
+            th = tmax((T)(v1 - z), (T)((T)(S - z) / (T)len));
+            long long cnt_prev = 0;
+            for (int it = 0; it < 4096; ++it) {
+                T sumA = (T)0;
+                long long cntl = 0;
+                if (cached) {
+#pragma unroll
+                    for (int i = 0; i < kRB; ++i) {
+                        const bool in = vr[i] > th;
+                        sumA = in ? (T)(sumA + vr[i]) : sumA;
+                        cntl += in ? 1 : 0;
+                    }
+                } else {
+                    for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
+                        T av[kLB], cv[kLB], v[kLB];
+                        uint32_t rv[kLB];
+                        bool ok[kLB];
+                        load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+                        for (int u = 0; u < kLB; ++u) {
+                            const T uu = tmax(v[u], (T)0);
+                            const bool in = ok[u] && uu > th;
+                            sumA = in ? (T)(sumA + uu) : sumA;
+                            cntl += in ? 1 : 0;
+                        }
+                    }
+                }
+                long long cntw;
+                if constexpr (WG) {
+                    sumA = (T)all_sum((double)sumA);
+                    cntw = (long long)all_sum((double)cntl);
+                } else {
+                    sumA = wave_allreduce(sumA, OpAdd());
+                    cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                }
+                if (it == 0 && cntw == 1) {
+                    onehot = true;
+                    break;
+                }
+                if (cntw == cnt_prev || cntw == 0) break;
+                // Michelot's thresholds never decrease in exact arithmetic; enforcing it in floating point keeps the supports
+                // nested, so the loop ends after at most `len` passes (without it a value within rounding of the threshold
+                // can leave and re-enter the support for thousands of passes -- measured on ratings-like data with ties)
+                th = tmax(th, (T)((T)(sumA - z) / (T)cntw));
+                cnt_prev = cntw;
+            }
+        }
+    }
+    for (uint64_t o0 = 0; o0 < len; o0 += kStride * kLB) {
+        T av[kLB], cv[kLB], v[kLB];
+        uint32_t rv[kLB];
+        bool ok[kLB];
+        load_batch(o0, av, cv, rv, ok, v);
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            if (!ok[u]) continue;
+            T x;
+            if (is_simplex) {
+                const T uu = tmax(v[u], (T)0);
+                if (!projected) x = uu;
+                else if (onehot) x = (uu > th) ? pj.z : (T)0;
+                else x = tmax((T)(uu - th), (T)0);
+            } else {
+                x = project_pointwise(v[u], pj);
+            }
+            const T ax = (T)(av[u] * x);
+            if (ax != (T)0) {
+                if (m_hot == 0 || (int64_t)rv[u] < m_hot) scatter_fixed(gacc, rv[u], ax, scale);
+                else scatter_fixed(g.cold_grad, rv[u], ax, scale);
+            }
+            obj += (double)(T)(cv[u] * x);
+            ssq += (double)(T)(x * x);
+            if (fair_acc) *fair_acc += (double)(T)(g.fair[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] * x);
+            if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] = x;
+        }
+    }
+}
+
+
+// ---- workgroup context shared by both tile layouts ----
+template <class T>
+struct WgCtx {
+    long long* grad_s;
+    T* lam_s;
+    ProjT<T>* proj_s;
+    double* red_s;
+    long long* gacc;
+    T s;           // -1/gamma rounded once to the working precision (matching.py:136)
+    double scale;  // 2^shift of the fixed-point gradient
+};
+
+// Prologue: carve LDS, stage -lambda/gamma, zero the private gradient, cache the projection table, choose the
+// fixed-point exponent from max|lambda| (identical in every workgroup).
+template <class T, bool LAM_LDS, bool GRAD_LDS>
+__device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsigned char* smem, int tid, int lane, int wave, int wg) {
+    WgCtx<T> w;
+    // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
+    const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;  // rows that live in LDS (all of them unless the hot-rows plan is on)
+    w.grad_s = reinterpret_cast<long long*>(smem);
+    size_t off = GRAD_LDS ? (size_t)m_lds * 8 : 0;
+    w.lam_s = reinterpret_cast<T*>(smem + off);
+    off += LAM_LDS ? (size_t)m_lds * sizeof(T) : 0;
+    off = (off + 15) / 16 * 16;
+    w.proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
+    off += (size_t)kProjLds * sizeof(ProjT<T>);
+    w.red_s = reinterpret_cast<double*>(smem + off);
+    w.s = (T)(-1.0 / g.gamma);
+    double lmax = 0.0;
+    // The optimiser step of the previous iteration, if this launch carries it (agd_step.h; opt-in, DUALIP_HIP_FUSE_APPLY=1): every
+    // wavefront derives the same step and every workgroup forms the new iterate itself.  Measured on one box at the per-rank size
+    // of an 8-GPU run (12.5M entities): the launch grows by 7 us -- the stats partials, then the rows, are two dependent memory
+    // latencies at the head of a launch whose CUs have nothing else to do yet -- which is what the separate apply launch and its
+    // boundary cost: 0.2317 / 0.2333 / 0.2314 ms per iteration with it, 0.2323 / 0.2313 / 0.2302 without.  Requesting the rows
+    // before deriving the step (twelve per thread in registers) made the launch 12 us longer.  Kept as a tested route, not the default.
+    const bool applying = g.do_apply != 0;
+    T a_stp = (T)0, a_bb = (T)0, a_omb = (T)0;
+    if (applying) {
+        const ApplyArgs<T>& ap = kernarg_args(g).apply;
+        a_stp = (T)agd_step_scalars(ap, lane, wg == 0, tid);
+        const float bt = ap.beta[ap.iter - 1];
+        a_bb = (T)bt;
+        a_omb = (T)(float)(1.0f - bt);
+    }
+    {   // latency bound (every workgroup pulls the whole dual vector from L2): four loads in flight per thread
+        constexpr int kU = 4;
+        for (int64_t i0 = tid; i0 < g.m; i0 += (int64_t)kU * kFusedThreads) {
+            T l[kU];
+            if (!applying) {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    l[u] = g.lambda[i < g.m ? i : g.m - 1];
+                }
+            } else {
+                const ApplyArgs<T>& ap = kernarg_args(g).apply;
+                T xx[kU], gg[kU], yy[kU];
+                bool eq[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    const int64_t ic = i < g.m ? i : g.m - 1;
+                    xx[u] = ap.x[ic];
+                    gg[u] = ap.g_new[ic];
+                    yy[u] = ap.y[ic];
+                    eq[u] = ap.eq_mask && ap.eq_mask[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                    T yn, xn;
+                    agd_update_values(xx[u], gg[u], yy[u], eq[u], a_stp, a_bb, a_omb, yn, xn);
+                    l[u] = xn;
+                    if (wg == 0 && i < g.m) {  // one workgroup stores the new iterate for the launches that follow
+                        ap.y_new[i] = yn;
+                        ap.x_next[i] = xn;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t i = i0 + (int64_t)u * kFusedThreads;
+                if (i < g.m) {
+                    if constexpr (LAM_LDS) {
+                        if (i < m_lds) w.lam_s[i] = (T)(w.s * l[u]);
+                    }
+                    const double al = fabs((double)l[u]);
+                    lmax = al > lmax ? al : lmax;
+                }
+            }
+        }
+    }
+    if constexpr (GRAD_LDS) {
+        for (int64_t i = tid; i < m_lds; i += kFusedThreads) w.grad_s[i] = 0;
+    }
+    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
+        w.proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
+    }
+    lmax = wave_allreduce(lmax, OpMax());
+    if (lane == 0) w.red_s[wave] = lmax;
+    __syncthreads();
+    lmax = w.red_s[0];
+    for (int q = 1; q < kFusedWaves; ++q) lmax = w.red_s[q] > lmax ? w.red_s[q] : lmax;
+    __syncthreads();  // red_s is reused by the epilogue
+    // every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
+    int shift;
+    {
+        double xmax = g.xmax_bounded;
+        if (g.has_unbounded) {
+            const double vmax = fabs(-1.0 / g.gamma) * ((g.amax + 2.0 * g.fair_max) * lmax + g.cmax);  // (|lambda_K - lambda_{K+1}| <= 2 lmax)
+            const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
+            xmax = ub > xmax ? ub : xmax;
+        }
+        const double bound = g.amax * xmax * g.row_count_max;
+        int e = 0;
+        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+        shift = FixedBits<T>::value - e;
+        shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+    }
+    w.scale = ldexp(1.0, shift);
+    if (wg == 0 && tid == 0) *g.shift_out = shift;
+    w.gacc = GRAD_LDS ? w.grad_s : g.partial;
+    return w;
+}
+
+// Epilogue: scalar partials of the workgroup, then its private gradient slab.
+template <class T, bool GRAD_LDS, bool FAIR = false>
+__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, double obj, double ssq, int tid, int lane, int wave, int wg,
+                                               double fair = 0.0) {
+    obj = wave_allreduce(obj, OpAdd());
+    ssq = wave_allreduce(ssq, OpAdd());
+    if constexpr (FAIR) fair = wave_allreduce(fair, OpAdd());
+    if (lane == 0) {
+        w.red_s[2 * wave] = obj;
+        w.red_s[2 * wave + 1] = ssq;
+        if constexpr (FAIR) w.red_s[2 * kFusedWaves + wave] = fair;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // (XCD balance: every wavefront of the workgroup has walked all its tiles by now)
+        unsigned long long* bst = kernarg_args(g).bal_stamps;
+        if (bst) bst[4 * (size_t)wg + 2] = wall_clock64();
+        double o = 0.0, q = 0.0;
+        for (int k = 0; k < kFusedWaves; ++k) {
+            o += w.red_s[2 * k];
+            q += w.red_s[2 * k + 1];
+        }
+        g.partial_scal[2 * (int64_t)wg] = o;
+        g.partial_scal[2 * (int64_t)wg + 1] = q;
+        if constexpr (FAIR) {
+            double fsum = 0.0;
+            for (int k = 0; k < kFusedWaves; ++k) fsum += w.red_s[2 * kFusedWaves + k];
+            g.partial_fair[wg] = fsum;
+        }
+    }
+    if constexpr (GRAD_LDS) {
+        long long* slab = g.partial + (int64_t)wg * g.mpad;
+        const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;
+        for (int64_t i = tid; i < m_lds; i += kFusedThreads) slab[i] = w.grad_s[i];
+    }
+}
+
+template <class T>
+__device__ __forceinline__ ProjT<T> lookup_proj(const FusedArgs<T>& g, const ProjT<T>* proj_s, uint32_t pid) {
+    ProjT<T> p = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+    if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj && pid != 0xFFFFFFFFu) p = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
+    return p;
+}
+
+}  // namespace dl

@@ -1,0 +1,713 @@
+// matching_kernels.hip -- the fused dual-gradient pass of the matching LP for gfx950.
+//
+// One launch streams the CSC arrays (a, c, row index) exactly once and performs, per non-zero / per column,
+// what the reference does in ~10^2 ATen launches (src/dualip/objectives/matching.py:136-161):
+//     gather  v = a * (-(1/g) lambda[row]) + (-(1/g) c)     left_multiply_sparse + elementwise_csc(add)
+//     project x = Proj_column(v)                              apply_F_to_columns (box / cone / simplex)
+//     scatter (A x)[row] += a x ;  c.x ;  sum x^2             row_sums_csc(A*x), dot, norm
+//
+// Mapping to the hardware (measured facts behind each choice are in DESIGN.md / profiles/)
+//   * one 1024-thread workgroup per CU (16 wavefronts).  lambda (pre-scaled by -1/gamma) is staged in LDS; the
+//     gradient is privatised in LDS as 64-bit FIXED-POINT integers and accumulated with ds_add_u64: the hardware
+//     float LDS atomic (ds_add_f32) retires ~1 lane per 3 cycles (185 cycles per wavefront instruction, measured),
+//     the integer one runs at gather speed, and integer sums are exact -> the gradient is bit-reproducible;
+//   * a wavefront owns "tiles": <= 64 non-zeros of whole consecutive columns, one non-zero per lane, described by a
+//     16-byte record (start, count, column-head bit mask, projection id) that replaces the column-pointer array.
+//     A wavefront works on a BATCH of kBatch tiles in lock-step (independent dependency chains for the scans) and
+//     keeps the next batch's CSC loads and the batch-after-next's descriptors in flight.  Descriptors travel
+//     through the vector-memory path (one coalesced 64-byte load + v_readlane), because scalar loads share the
+//     LDS wait counter and would put an HBM round trip in front of every LDS operation;
+//   * the simplex projection runs in registers: segmented DPP scans give per-column sum / max, a ballot gives the
+//     support size, and a monotone Newton (Michelot) iteration on the piecewise-linear f(theta) = sum max(u-theta,0)
+//     finds the exact threshold the reference obtains by sort + cumsum;
+//   * columns longer than 64 non-zeros are walked by a whole wavefront in 64-wide strides (re-reading L2-hot data
+//     per Newton pass);
+//   * every workgroup writes its private integer gradient to its own slab; a second small kernel sums the slabs
+//     (exactly) and converts to double.
+#include <atomic>
+
+#include "comm.h"
+#include "fused_common.h"
+
+namespace dl {
+
+// ---------------------------------------------------------------------------------------------------------
+// fused kernel
+// ---------------------------------------------------------------------------------------------------------
+template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool USE_DPP>
+__global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs<T> g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
+    long long* grad_s = reinterpret_cast<long long*>(smem);
+    size_t off = GRAD_LDS ? (size_t)g.m * 8 : 0;
+    T* lam_s = reinterpret_cast<T*>(smem + off);
+    off += LAM_LDS ? (size_t)g.m * sizeof(T) : 0;
+    off = (off + 15) / 16 * 16;
+    ProjT<T>* proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
+    off += (size_t)kProjLds * sizeof(ProjT<T>);
+    double* red_s = reinterpret_cast<double*>(smem + off);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const T s = (T)(-1.0 / g.gamma);  // matching.py:136: the scalar is formed in double, rounded once
+
+    // ---- prologue: stage -lambda/gamma, max |lambda|, zero the private gradient, cache the projection table ----
+    double lmax = 0.0;
+    for (int64_t i = tid; i < g.m; i += kFusedThreads) {
+        const T l = g.lambda[i];
+        if constexpr (LAM_LDS) lam_s[i] = (T)(s * l);
+        const double al = fabs((double)l);
+        lmax = al > lmax ? al : lmax;
+    }
+    if constexpr (GRAD_LDS) {
+        for (int64_t i = tid; i < g.m; i += kFusedThreads) grad_s[i] = 0;
+    }
+    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
+        proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
+    }
+    const LaneConst lc = make_lane_const(lane);
+    lmax = wave_allreduce(lmax, OpMax());
+    if (lane == 0) red_s[wave] = lmax;
+    __syncthreads();
+    lmax = red_s[0];
+    for (int w = 1; w < kFusedWaves; ++w) lmax = red_s[w] > lmax ? red_s[w] : lmax;
+    __syncthreads();  // red_s is reused by the epilogue
+    // fixed-point exponent: every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
+    // (the same value in every workgroup; the slab reduction adds at most log2(#workgroups) <= 12 more bits)
+    int shift;
+    {
+        double xmax = g.xmax_bounded;
+        if (g.has_unbounded) {
+            const double vmax = fabs(-1.0 / g.gamma) * (g.amax * lmax + g.cmax);
+            const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
+            xmax = ub > xmax ? ub : xmax;
+        }
+        const double bound = g.amax * xmax * g.row_count_max;
+        int e = 0;
+        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+        shift = FixedBits<T>::value - e;
+        shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+    }
+    const double scale = ldexp(1.0, shift);
+    if (wg == 0 && tid == 0) *g.shift_out = shift;
+
+    long long* gacc = GRAD_LDS ? grad_s : g.partial;
+    double obj = 0.0, ssq = 0.0;
+
+    const uint32_t t_begin = g.wg_tile_begin[wg];
+    const uint32_t t_end = g.wg_tile_begin[wg + 1];
+    // 32-bit byte offsets relative to the workgroup's first non-zero (SGPR base + VGPR offset addressing)
+    uint64_t k_base = 0;
+    if (t_begin < t_end) {
+        const uint32_t lo = g.tiles32[(size_t)t_begin * 4], hi = g.tiles32[(size_t)t_begin * 4 + 1];
+        k_base = tile_nnz_start(((uint64_t)hi << 32) | lo);
+    }
+    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)k_base);
+    k_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(k_base >> 32)) << 32) | kb_lo;
+    const T* __restrict__ a_wg = g.a + k_base;
+    const T* __restrict__ c_wg = g.c + k_base;
+    const RowT* __restrict__ r_wg = reinterpret_cast<const RowT*>(g.rowidx) + k_base;
+    T* __restrict__ x_wg = g.x_out ? g.x_out + k_base : nullptr;
+
+    // descriptor words of one batch through the vector path: lane l (< 4*kBatch) holds dword l of the 16-byte records.
+    // The load is UNCONDITIONAL (clamped index, result zeroed past the end): a load issued under a branch makes the
+    // compiler's wait-count insertion fall back to vmcnt(0) at the join and serialises the software pipeline.
+    const size_t last_word = (size_t)t_end * 4 - 1;
+    auto load_desc = [&](uint32_t tb) -> uint32_t {
+        const uint32_t l = (uint32_t)lane < 4u * kBatch ? (uint32_t)lane : 4u * kBatch - 1u;
+        size_t idx = (size_t)tb * 4 + l;
+        idx = idx < last_word ? idx : last_word;
+        const uint32_t v = g.tiles32[idx];
+        const bool ok = (uint32_t)lane < 4u * kBatch && tb < t_end && tb + (l >> 2) < t_end;
+        return v & (0u - (uint32_t)ok);  // an AND, not a select: a select lets the compiler sink the load under a branch
+    };
+    struct Batch {
+        uint32_t w0lo[kBatch], w0hi[kBatch];
+        uint64_t w1[kBatch];
+        uint32_t koff[kBatch];  // element offset of lane 0 relative to k_base (0 for padding / long tiles)
+        T a[kBatch], c[kBatch];
+        uint32_t r[kBatch];
+    };
+    // loads are unconditional: lanes past the tile's count re-read its first element and are masked at the end
+    auto unpack_and_issue = [&](uint32_t dv, Batch& b) {
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            b.w0lo[q] = __builtin_amdgcn_readlane(dv, 4 * q);
+            b.w0hi[q] = __builtin_amdgcn_readlane(dv, 4 * q + 1);
+            const uint32_t w1lo = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 2);  // readlane returns a signed int:
+            const uint32_t w1hi = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 3);  // never widen it directly
+            b.w1[q] = ((uint64_t)w1hi << 32) | w1lo;
+            const uint32_t cnt = (b.w0hi[q] >> 8) & 0x7F;
+            const bool is_long = (b.w0hi[q] & 0x8000u) != 0;
+            b.koff[q] = (cnt == 0 || is_long) ? 0u : b.w0lo[q] - kb_lo;  // exact: a workgroup spans < 2^32 non-zeros
+            const uint32_t k = b.koff[q] + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u);
+            b.a[q] = *byte_offset(a_wg, k * (uint32_t)sizeof(T));
+            b.c[q] = *byte_offset(c_wg, k * (uint32_t)sizeof(T));
+            b.r[q] = (uint32_t)*byte_offset(r_wg, k * (uint32_t)sizeof(RowT));
+        }
+    };
+
+    // ---- main loop: batch k is processed while the CSC values of batch k+1 and the descriptors of batch k+2 fly ----
+    const uint32_t stride = kFusedWaves * kBatch;
+    uint32_t tb = t_begin + (uint32_t)wave * kBatch;
+    Batch cur;
+    uint32_t dv_next = 0;
+    if (tb < t_end) {
+        const uint32_t dv0 = load_desc(tb);
+        dv_next = load_desc(tb + stride);
+        unpack_and_issue(dv0, cur);
+    }
+    while (tb < t_end) {
+        Batch nxt;
+        const uint32_t tb_next = tb + stride;
+        unpack_and_issue(dv_next, nxt);  // past the end dv_next is 0: dummy loads of the workgroup's first element
+        dv_next = load_desc(tb_next + stride);
+
+        // ------------------------------ batch of short tiles: one non-zero per lane and tile ------------------------------
+        ProjT<T> pj[kBatch];
+        bool valid[kBatch], smp[kBatch];
+        const int32_t* eq_row[kBatch];
+        bool any_simplex = false, any_long = false;
+        T v[kBatch], x[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const uint32_t cnt = (cur.w0hi[q] >> 8) & 0x7F;
+            const bool is_long = (cur.w0hi[q] & 0x8000u) != 0;
+            const uint32_t pid = cur.w0hi[q] >> 16;
+            any_long = any_long || is_long;
+            // entries beyond the LDS table only occur in single-column "long" tiles (see pack_tiles), never here
+            pj[q] = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+            const int kind = __builtin_amdgcn_readfirstlane(pj[q].kind);
+            valid[q] = !is_long && (uint32_t)lane < cnt;
+            smp[q] = !is_long && cnt > 0 && is_simplex_kind(kind);
+            eq_row[q] = (kind == DL_PROJ_SIMPLEX_EQ && g.eq_heights) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
+            any_simplex = any_simplex || smp[q];
+            T lam = (T)1;
+            if (!(g.ablate & 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
+            const T t1 = (T)(cur.a[q] * lam);          // sparse_utils.py:79
+            v[q] = (T)(t1 + (T)(s * cur.c[q]));        // matching.py:66,142
+            x[q] = (g.ablate & 4) ? v[q] : project_pointwise(v[q], pj[q]);
+        }
+        if (any_simplex && !(g.ablate & 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x, eq_row);
+        T o32 = (T)0, q32 = (T)0;
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const T xq = valid[q] ? x[q] : (T)0;
+            const T ax = (T)(cur.a[q] * xq);
+            if (ax != (T)0 && !(g.ablate & 1)) scatter_fixed(gacc, cur.r[q], ax, scale);
+            o32 = (T)(o32 + (T)(cur.c[q] * xq));
+            q32 = (T)(q32 + (T)(xq * xq));
+            x[q] = xq;
+        }
+        obj += (double)o32;
+        ssq += (double)q32;
+        if (x_wg) {
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+                if (valid[q]) x_wg[cur.koff[q] + (uint32_t)lane] = x[q];
+        }
+        if (any_long) {
+            // one shared code instance: the tile's words are selected by a run-time index
+#pragma unroll 1
+            for (int q = 0; q < kBatch; ++q) {
+                uint32_t w0lo = cur.w0lo[0], w0hi = cur.w0hi[0];
+                uint64_t w1 = cur.w1[0];
+#pragma unroll
+                for (int j = 1; j < kBatch; ++j) {
+                    if (q == j) {
+                        w0lo = cur.w0lo[j];
+                        w0hi = cur.w0hi[j];
+                        w1 = cur.w1[j];
+                    }
+                }
+                if (w0hi & 0x8000u) {
+                    const uint32_t pid = w0hi >> 16;
+                    ProjT<T> pl = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+                    if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj) pl = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
+                    const uint64_t w0 = ((uint64_t)w0hi << 32) | w0lo;
+                    const int32_t* eq_long = (g.eq_heights && pid != kNoProj) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
+                    process_long_tile<T, RowT, LAM_LDS>(g, pl, tile_nnz_start(w0), w1, lam_s, gacc, s, scale, lane, obj, ssq, eq_long);
+                }
+            }
+        }
+
+        tb = tb_next;
+        cur = nxt;
+    }
+
+    // ---- epilogue: scalar partials, then the private gradient slab ----
+    obj = wave_allreduce(obj, OpAdd());
+    ssq = wave_allreduce(ssq, OpAdd());
+    if (lane == 0) {
+        red_s[2 * wave] = obj;
+        red_s[2 * wave + 1] = ssq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, q = 0.0;
+        for (int w = 0; w < kFusedWaves; ++w) {
+            o += red_s[2 * w];
+            q += red_s[2 * w + 1];
+        }
+        g.partial_scal[2 * (int64_t)wg] = o;
+        g.partial_scal[2 * (int64_t)wg + 1] = q;
+    }
+    if constexpr (GRAD_LDS) {
+        long long* slab = g.partial + (int64_t)wg * g.mpad;
+        for (int64_t i = tid; i < g.m; i += kFusedThreads) slab[i] = grad_s[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// slab reduction: packed[0..m) = 2^-shift * sum_w partial[w][i] (exact integer sum), packed[m], packed[m+1] = scalars
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRedThreads = 1024;
+constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
+
+// Hot-rows plan (inv != null): slab column p belongs to the caller's row inv[p]; columns >= m_hot hold nothing -- their sums
+// are in `cold` (one int64 per row, global atomics).
+// MODE 0: packed[i] = sum.  MODE 1: packed[i] += sum (second and later blocks of a split shard).  MODE 2: the sum (plus
+// packed[i] when `accumulate`) goes to this rank's slot in EVERY rank's mailbox (comm.h: the P2P exchange) -- the slab
+// reduction is the pushing launch, no separate collective.
+template <int MODE>
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
+                                                                      const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
+                                                                      double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
+                                                                      const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
+                                                                      int accumulate) {
+    auto emit = [&](int64_t i, double v) {
+        if constexpr (MODE == 0) packed[i] = v;
+        else if constexpr (MODE == 1) packed[i] += v;
+        else push_value(push, i, accumulate ? packed[i] + v : v);
+    };
+    __shared__ long long shi[kRedThreads];
+    __shared__ double sh[kRedThreads / 32];
+    const int tid = threadIdx.x;
+    if (blockIdx.x + 1 < gridDim.x) {  // row blocks; the LAST block only sums the scalar partials (runs beside them)
+        const int rl = tid & (kRedRows - 1);
+        const int ws = tid / kRedRows;
+        const int64_t row = (int64_t)blockIdx.x * kRedRows + rl;
+        const int64_t rc = row < m ? row : (m > 0 ? m - 1 : 0);
+        long long acc = 0;
+        const bool in_slabs = !inv || rc < m_hot;
+        if (!in_slabs && ws == 0) acc = cold[rc];
+        // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
+        constexpr int kU = 8, kStride = kRedThreads / kRedRows;
+        for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
+            long long v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int w = w0 + kStride * u;
+                v[u] = partial[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
+        }
+        shi[tid] = acc;
+        __syncthreads();
+        if (ws == 0 && row < m) {
+            long long t = shi[rl];
+            for (int q = 1; q < kRedThreads / kRedRows; ++q) t += shi[q * kRedRows + rl];
+            const int64_t orow = inv ? (int64_t)inv[row] : row;
+            emit(orow, (dense && orow >= m - 2) ? dense[orow - (m - 2)] : ldexp((double)t, -(*shift_in)));  // (fairness pair: the two dense rows)
+        }
+        if constexpr (MODE == 2) push_finish(push);
+        return;
+    }
+    {
+        double o = 0.0, q = 0.0;
+        for (int w = tid; w < n_scal; w += kRedThreads) {
+            o += partial_scal[2 * w];
+            q += partial_scal[2 * w + 1];
+        }
+        o = wave_allreduce(o, OpAdd());
+        q = wave_allreduce(q, OpAdd());
+        if ((tid & 63) == 0) {
+            sh[2 * (tid >> 6)] = o;
+            sh[2 * (tid >> 6) + 1] = q;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double oo = 0.0, qq = 0.0;
+            for (int w = 0; w < kRedThreads / 64; ++w) {
+                oo += sh[2 * w];
+                qq += sh[2 * w + 1];
+            }
+            emit(m, oo);
+            emit(m + 1, qq);
+        }
+        if constexpr (MODE == 2) push_finish(push);
+    }
+}
+
+// max |v| over an array (one-off, at handle creation): non-negative floats order like their bit patterns
+template <class T>
+__global__ void absmax_kernel(int64_t n, const T* __restrict__ v, unsigned long long* __restrict__ out_bits) {
+    double mx = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const double a = fabs((double)v[k]);
+        mx = a > mx ? a : mx;  // NaN is ignored here; it poisons the results elsewhere
+    }
+    mx = wave_allreduce(mx, OpMax());
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int threads = 256;
+    int64_t b64 = (n + threads - 1) / threads;
+    const int blocks = (int)(b64 > 4096 ? 4096 : b64);
+    if (val_dtype == DL_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(threads), 0, st, n, (const float*)v, out_bits);
+    else hipLaunchKernelGGL(absmax_kernel<double>, dim3(blocks), dim3(threads), 0, st, n, (const double*)v, out_bits);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad) {
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    size_t off = (grad ? (size_t)m * 8 : 0) + (lam ? (size_t)m * vs : 0);
+    off = (off + 15) / 16 * 16;
+    off += (size_t)kProjLds * (val_dtype == DL_F32 ? sizeof(ProjT<float>) : sizeof(ProjT<double>));
+    off += kLdsScratch;
+    return off;
+}
+
+template <class T, class RowT, bool LAM, bool GRAD, bool DPP>
+static int launch_fused_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
+    auto kern = matching_fused_kernel<T, RowT, LAM, GRAD, DPP>;
+    static std::atomic<uint64_t> attr_set{0};  // per instantiation, one bit per device (the opt-in to > 64 KB of LDS is per device)
+    const uint64_t bit = 1ull << (h->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+        DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(h->n_wg), dim3(kFusedThreads), h->lds_bytes, st, args);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+template <class T, class RowT>
+static int launch_fused_rt(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
+    const bool L = h->lam_lds, G = h->grad_lds, D = h->use_dpp;
+    if (L && G) return D ? launch_fused_inst<T, RowT, true, true, true>(h, args, st) : launch_fused_inst<T, RowT, true, true, false>(h, args, st);
+    if (!L && G) return D ? launch_fused_inst<T, RowT, false, true, true>(h, args, st) : launch_fused_inst<T, RowT, false, true, false>(h, args, st);
+    return D ? launch_fused_inst<T, RowT, false, false, true>(h, args, st) : launch_fused_inst<T, RowT, false, false, false>(h, args, st);
+}
+
+int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4.hip
+int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
+static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) { return launch_fused4_f32(h, args, st); }
+static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) { return launch_fused4_f64(h, args, st); }
+
+template <class T>
+__global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, const int32_t* __restrict__ inv, T* __restrict__ dst) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < m) dst[p] = src[inv[p]];
+}
+
+// fairness pair: (A x) of the two dense rows from the workgroups' partial sums (fixed order)
+// Balance of the window tiles (fused_common.h: Deal).  st[w][0..2] = wall clock of workgroup w after its prologue, after wavefront
+// 0's window tiles, and when all its wavefronts have walked everything.  The knob is the number of window rounds n_w of each
+// workgroup, the target equal FINISH times (half the wavefronts walk their slices first, so the end of wavefront 0's windows is not
+// the end of the workgroup): n_w <- n_w - gain (D_w - mean D) / tau, D_w = the workgroup's finish time, tau = the measured time
+// of one window round; at most +-15 % / +-kBalTail/2 rounds from the even share; rounded down, the missing rounds go to the
+// workgroups with the largest remainders; then the offsets and ranks of the rounds above the minimum are tabulated.
+// One workgroup of 1024 threads, thread w = workgroup w (n_wg <= 1024).
+__global__ __launch_bounds__(1024) void wg_balance_kernel(int32_t* __restrict__ tab, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_win, int min_rounds,
+                                                          double gain) {
+    __shared__ double red[16];
+    __shared__ long long redi[16];
+    __shared__ double frac_s[1024];
+    __shared__ int flag_wave[16];
+    __shared__ int bcast[4];
+    const int w = threadIdx.x, lane = w & 63, wave = w >> 6;
+    const bool live = w < n_wg;
+    auto block_sum = [&](double x) -> double {
+        x = wave_allreduce(x, OpAdd());
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q];
+        return t;
+    };
+    auto block_sum_i = [&](long long x) -> long long {
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(x & 0xFFFFFFFFll)), hi = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(x >> 32));
+            x += ((long long)hi << 32) | (unsigned int)lo;
+        }
+        __syncthreads();
+        if (lane == 0) redi[wave] = x;
+        __syncthreads();
+        long long t = 0;
+        for (int q = 0; q < 16; ++q) t += redi[q];
+        return t;
+    };
+    int32_t* n = tab + 4;
+    const double need = ceil((double)n_win / (double)kFusedWaves);  // rounds, summed over the workgroups
+    const double even = need / (double)n_wg;
+    if (even < (double)min_rounds - 1.0) return;  // (uniform: every thread)
+    double dall = 0.0, dwin = 0.0;
+    int n_old = 0;
+    bool ok = true;
+    if (live) {
+        const unsigned long long a = st[4 * (size_t)w], b = st[4 * (size_t)w + 1], c = st[4 * (size_t)w + 2];
+        n_old = n[w];
+        ok = b > a && c > a && n_old > 0;
+        dwin = ok ? (double)(b - a) : 0.0;
+        dall = ok ? (double)(c - a) : 0.0;
+    }
+    const double bad = block_sum(ok ? 0.0 : 1.0);
+    if (bad > 0.0) return;  // (a launch without window tiles in some workgroup, or no stamps: keep the table)
+    const double dmean = block_sum(dall) / (double)n_wg;
+    const double tau = block_sum(live ? dwin / (double)n_old : 0.0) / (double)n_wg;
+    if (!(tau > 0.0)) return;
+    double t = 0.0;
+    if (live) {
+        t = (double)n_old - gain * (dall - dmean) / tau;
+        const double lo = fmax(0.85 * even, even - 0.5 * kBalTail + 2.0), hi = fmin(1.15 * even, even + 0.5 * kBalTail - 2.0);
+        t = t < lo ? lo : (t > hi ? hi : t);
+        t = t < 1.0 ? 1.0 : t;
+    }
+    int fl = live ? (int)t : 0;
+    long long have = block_sum_i(fl);
+    long long deficit = (long long)need - have;
+    if (deficit > 0) {  // every tile must have a slot: the missing rounds go to the largest remainders
+        const int all = (int)(deficit / n_wg);
+        fl += live ? all : 0;
+        deficit -= (long long)all * n_wg;
+        frac_s[w] = live ? t - floor(t) : -1.0;
+        __syncthreads();
+        if (live && deficit > 0) {
+            int larger = 0;
+            const double mine = frac_s[w];
+            for (int q = 0; q < n_wg; ++q) larger += (frac_s[q] > mine || (frac_s[q] == mine && q < w)) ? 1 : 0;
+            fl += larger < (int)deficit ? 1 : 0;
+        }
+    }
+    // minimum / maximum of the new rounds
+    int mn = live ? fl : 0x7FFFFFFF, mx = live ? fl : 0;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int a = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, mn), b = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, mx);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        flag_wave[wave] = mn;
+        redi[wave] = mx;
+    }
+    __syncthreads();
+    if (w == 0) {
+        int a = 0x7FFFFFFF, b = 0;
+        for (int q = 0; q < 16; ++q) {
+            a = flag_wave[q] < a ? flag_wave[q] : a;
+            b = (int)redi[q] > b ? (int)redi[q] : b;
+        }
+        bcast[0] = a;
+        bcast[1] = b;
+    }
+    __syncthreads();
+    const int n_min = bcast[0], J = bcast[1] - bcast[0];
+    if (J > kBalTail || n_min < 1) return;  // (cannot happen: the clamps bound the range; keep the old table)
+    if (live) n[w] = fl;
+    // tables of the rounds above the minimum: wavefront q tabulates rounds q, q + 16, ... on its own (no workgroup barriers: with
+    // them this kernel took ~50 us, 0.5 % of the launches it follows)
+    __shared__ int fl_s[1024];
+    fl_s[w] = live ? fl : 0;
+    __syncthreads();
+    int32_t* off = tab + 4 + n_wg;
+    int32_t* rank = off + kBalTail;
+    for (int j = wave; j < J; j += 16) {
+        const int k = n_min + j;
+        int running = 0;
+        long long sum_min = 0;
+        for (int base = 0; base < n_wg; base += 64) {
+            const int ww = base + lane;
+            const int f = ww < n_wg ? fl_s[ww] : 0;
+            const bool in = ww < n_wg && f > k;
+            const unsigned long long bal = __ballot(in);
+            if (ww < n_wg) rank[(size_t)j * n_wg + ww] = running + __popcll(bal & ((1ull << lane) - 1ull));
+            running += __popcll(bal);
+            sum_min += ww < n_wg ? (f < k ? f : k) : 0;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(sum_min & 0xFFFFFFFFll)), hi = __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, (int)(sum_min >> 32));
+            sum_min += ((long long)hi << 32) | (unsigned int)lo;
+        }
+        if (lane == 0) off[j] = (int32_t)(sum_min * kFusedWaves);
+    }
+    if (w == 0) {
+        tab[0] = n_min;
+        tab[1] = J;
+    }
+}
+
+__global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restrict__ partial_fair, int n_wg, double* __restrict__ dense_ax) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int w = threadIdx.x; w < n_wg; w += 256) v += partial_fair[w];
+    v = wave_allreduce(v, OpAdd());
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double f = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        dense_ax[0] = f;
+        dense_ax[1] = -f;
+    }
+}
+
+// the fused pass alone: fills the handle's integer slabs, scalar partials and the fixed-point exponent
+// the step of the previous iteration CAN ride this handle's launches when every dual entry the kernel reads comes from the
+// workgroup's own LDS copy (256-wide layout, whole dual vector and gradient in LDS, no fairness stream)
+bool matching_can_fuse_apply(const dl_matching* h) {
+    const char* e = getenv("DUALIP_HIP_FUSE_APPLY");  // opt-in ("1"): measured neutral (fused_common.h), so every step is its own launch by default
+    const bool off = !(e && e[0] == '1');
+    return !off && h->layout == 4 && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
+}
+
+template <class T>
+static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd, const PendingStep* pending) {
+    FusedArgs<T> args;
+    args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
+    args.wg_tile_begin = h->wg_tile_begin;
+    args.rowidx = h->rowidx;
+    args.a = static_cast<const T*>(h->a);
+    args.c = static_cast<const T*>(h->c);
+    args.lambda = static_cast<const T*>(lambda);
+    args.x_out = static_cast<T*>(x_out);
+    args.projs = h->projs;
+    args.partial = static_cast<long long*>(h->partial);
+    args.partial_scal = h->partial_scal;
+    args.shift_out = h->shift_dev;
+    args.gamma = gamma;
+    args.amax = h->amax;
+    args.cmax = h->cmax;
+    args.xmax_bounded = h->xmax_bounded;
+    args.pmax_unbounded = h->pmax_unbounded;
+    args.row_count_max = (double)(h->row_count_max > 0 ? h->row_count_max : 1);
+    args.has_unbounded = h->has_unbounded ? 1 : 0;
+    args.m = h->m;
+    args.mpad = h->mpad;
+    args.nnz = h->nnz;
+    args.n_proj = h->n_proj;
+    args.n_tiles = (uint32_t)(h->layout == 4 ? h->n_short : h->n_tiles);
+    args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short - h->n_xlong : 0);
+    args.n_xlong = (uint32_t)(h->layout == 4 ? h->n_xlong : 0);
+    args.desc_words = (uint32_t)h->desc_words;
+    args.long32 = args.tiles32 + (size_t)h->n_short * (size_t)h->desc_words + 12;  // (after the windows and one all-zero descriptor)
+    args.ablate = h->ablate;
+    args.timeline = h->timeline;
+    args.eq_heights = h->eq_heights;
+    args.m_hot = h->m_hot;
+    args.cold_grad = h->cold_grad;
+    args.fair = static_cast<const T*>(h->fair);
+    args.lambda_orig = static_cast<const T*>(lambda);
+    args.partial_fair = h->partial_fair;
+    args.fair_max = h->fair ? h->fair_max : 0.0;
+    args.sell_desc = h->sell_desc;
+    args.sell_len = h->sell_len;
+    args.sell_colstart = h->sell_colstart;
+    args.sell_a = static_cast<const T*>(h->sell_a);
+    args.sell_c = static_cast<const T*>(h->sell_c);
+    args.sell_r = h->sell_r;
+    args.sell_f = static_cast<const T*>(h->sell_f);
+    args.n_sell = (uint32_t)h->n_sell;
+    args.balance = h->bal;
+    // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
+    //  slices get slower as the Newton passes multiply, the windows do not)
+    args.bal_stamps = (h->bal_stamps && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
+    args.do_apply = 0;
+    args.apply = ApplyArgs<T>();
+    if (pending && pending->valid) {
+        if (!agd || !matching_can_fuse_apply(h) || agd->m != h->m || agd->val_dtype != h->val_dtype) return fail(DL_E_STATE, "this handle cannot apply an optimiser step in its prologue");
+        args.do_apply = 1;
+        args.apply = make_apply_args<T>(agd, *pending);
+    }
+    if (h->m_hot > 0) {  // hot-rows plan: the kernel reads the dual vector in renumbered order and adds the cold rows globally
+        // (the device-resident AGD loop leaves both prepared, common.h -- only honoured for the optimiser that prepared them)
+        if (!(h->hot_ready && owner_uid != 0 && h->hot_ready_owner == owner_uid && h->hot_ready_lambda == lambda)) {
+            const unsigned blocks = (unsigned)((h->m + 255) / 256);
+            hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
+            DL_HIP(hipGetLastError());
+            DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad, st));
+        }
+        h->hot_ready = false;  // this launch fills the cold accumulators
+        args.lambda = static_cast<const T*>(h->lam_perm);
+    }
+    if (!h->grad_lds) DL_HIP(hipMemsetAsync(h->partial, 0, sizeof(long long) * (size_t)h->mpad, st));
+    hipEvent_t ev_stop = nullptr;
+    if (h->prof_on && (h->prof_seen++ % (uint64_t)h->prof_stride) == 0) {
+        if (h->prof_used == h->prof_start.size() && h->prof_start.size() < 16384) {
+            hipEvent_t e0, e1;
+            DL_HIP(hipEventCreate(&e0));
+            DL_HIP(hipEventCreate(&e1));
+            h->prof_start.push_back(e0);
+            h->prof_stop.push_back(e1);
+        }
+        if (h->prof_used < h->prof_start.size()) {
+            DL_HIP(hipEventRecord(h->prof_start[h->prof_used], st));
+            ev_stop = h->prof_stop[h->prof_used];
+            h->prof_used += 1;
+        }
+    }
+    int rc;
+    if (h->layout == 4) rc = launch_fused4(h, args, st);
+    else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
+    if (rc) return rc;
+    if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
+    if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
+        hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
+        DL_HIP(hipGetLastError());
+    }
+    if (h->bal_stamps) h->bal_launches += 1;
+    if (h->fair) {
+        hipLaunchKernelGGL(fair_finish_kernel, dim3(1), dim3(256), 0, st, h->partial_fair, h->n_wg, h->dense_ax);
+        DL_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int matching_launch_fused(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd, const PendingStep* pending) {
+    if (h->val_dtype == DL_F32) return fused_typed<float>(h, lambda, gamma, x_out, st, owner_uid, agd, pending);
+    return fused_typed<double>(h, lambda, gamma, x_out, st, owner_uid, agd, pending);
+}
+
+
+template <class T>
+static int calculate_typed(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
+    if ((h->n_tiles == 0 && h->n_sell == 0) || h->n_wg == 0) {  // no non-zeros at all: A x = 0
+        DL_HIP(hipMemsetAsync(packed_out, 0, sizeof(double) * (size_t)(h->m + 2), st));
+        return 0;
+    }
+    int rc = fused_typed<T>(h, lambda, gamma, x_out, st, 0, nullptr, nullptr);
+    if (rc) return rc;
+    return matching_reduce(h, packed_out, 0, nullptr, st, 0);
+}
+
+// The slab reduction alone (after matching_launch_fused).  mode 0: packed = sums; 1: packed += sums; 2: the sums
+// (+ packed when `push_accumulate`) go to the mailboxes described by *push.
+int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* push, hipStream_t st, int push_accumulate) {
+    const int n_slabs = h->grad_lds ? h->n_wg : 1;
+    const int blocks = (int)((h->m + kRedRows - 1) / kRedRows);
+    PushArgs pa = PushArgs();
+    if (push) pa = *push;
+    auto kern = mode == 0 ? reduce_partials_kernel<0> : (mode == 1 ? reduce_partials_kernel<1> : reduce_partials_kernel<2>);
+    hipLaunchKernelGGL(kern, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial), h->partial_scal, h->shift_dev, n_slabs,
+                       h->n_wg, h->m, h->mpad, packed, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad, h->fair ? h->dense_ax : nullptr, pa,
+                       push_accumulate);
+    DL_HIP(hipGetLastError());
+    return 0;
+}
+
+int matching_calculate(dl_matching* h, const void* lambda, double gamma, double* packed_out, void* x_out, hipStream_t st) {
+    if (h->val_dtype == DL_F32) return calculate_typed<float>(h, lambda, gamma, packed_out, x_out, st);
+    return calculate_typed<double>(h, lambda, gamma, packed_out, x_out, st);
+}
+
+}  // namespace dl

@@ -1,0 +1,295 @@
+// sell.h -- "column per lane" slices for short simplex columns (layout 4 handles; built by sell_build.hip).
+//
+// The 256-wide window tile keeps the caller's CSC order: four consecutive non-zeros per lane, a column spread over lanes,
+// every per-column quantity of the simplex projection (max, sum and size of the support, each Newton pass) a SEGMENTED
+// cross-lane reduction -- ~38 vector instructions each, however short the columns are.  At the benchmark's ten non-zeros
+// per column that machinery makes the simplex tile instruction bound (322 VALU per 256 non-zeros early in a solve, 543 late,
+// against 89 for a clamp tile; profiles/r01f_bench_10m_simplex_pmc.json).
+//
+// Here the DATA are re-laid instead (one-off, at handle creation; the handle owns the copy): the short columns of a simplex
+// entry are sorted by length and cut into slices of 64; inside a slice element t of column L sits at base + 64 t + L.  Lane L
+// then owns column L: every load of a wavefront is one contiguous 256-byte (values) or 128-byte (uint16 rows) run, and max,
+// sum, count and every Newton pass are plain per-lane recurrences over the column's registers -- no cross-lane traffic at all,
+// and a per-COLUMN scalar (threshold, division) costs one instruction for 64 columns.  Sorting by length makes the slice
+// height equal to (almost) every column's length, so padding is a few slots per length class.
+//
+// Same arithmetic contract as simplex4.h (the reference's _duchi_proj, simplex.py:126-236): clamp at 0, keep if the sum of
+// the first support is <= z + 1e-6 ("simplex" only), vertex z e_argmax when only the maximum exceeds max - z, otherwise
+// x = max(u - theta, 0) with theta from monotone Newton (Michelot) passes started at max - z; thresholds never decrease.
+#pragma once
+#include "fused_common.h"
+#include "simplex4.h"
+
+namespace dl {
+
+constexpr int kSellMaxH = 24;     // tallest slice (a column's clamped values stay in registers across the passes: 32 steps would
+                                  // spill); longer columns stay on the window / single-column paths
+constexpr int kSellDescWords = 4; // { base[31:0] ; base[39:32] | H << 8 | Hmin << 16 | (ncols - 1) << 24 ; projection id ; dense0 }
+
+__host__ __device__ inline int sell_chunks(int H) { return (H + 3) >> 2; }
+
+// One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
+// read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
+template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR>
+__device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, uint64_t dense,
+                                           bool has_col, int lane, T sd, const int32_t* eq_row, double& obj, double& ssq, double& fair) {
+    const T s = w.s;
+    // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
+    const T* __restrict__ pa = byte_offset(g.sell_a + base, (uint32_t)lane * (uint32_t)sizeof(T));
+    const T* __restrict__ pc = byte_offset(g.sell_c + base, (uint32_t)lane * (uint32_t)sizeof(T));
+    const RowT* __restrict__ pr = byte_offset(reinterpret_cast<const RowT*>(g.sell_r) + base, (uint32_t)lane * (uint32_t)sizeof(RowT));
+    const T* __restrict__ pf = FAIR ? byte_offset(g.sell_f + base, (uint32_t)lane * (uint32_t)sizeof(T)) : nullptr;
+    constexpr int KEEP = RELOAD ? 1 : HM;
+    constexpr int CH = 4;  // steps per batch of the RELOAD variants (loads of a batch are in flight together)
+    T a[KEEP], c[KEEP], f[FAIR ? KEEP : 1], u[HM];
+    uint32_t r[KEEP];
+    auto lam_of = [&](uint32_t row) -> T {
+        if constexpr (HOT) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
+        else return LAM_LDS ? w.lam_s[row] : (T)(s * g.lambda[row]);
+    };
+    const T NEG = (T)(-INFINITY);
+    // ---- pass 1: v = a (-lambda/gamma)[row] + (-c/gamma), u = max(v, 0); steps past the slice's height are never issued ----
+    if constexpr (!RELOAD) {
+#pragma unroll
+        for (int t = 0; t < HM; ++t) {
+            if (t < H) {  // wave-uniform
+                a[t] = __builtin_nontemporal_load(pa + 64 * t);
+                c[t] = __builtin_nontemporal_load(pc + 64 * t);
+                r[t] = (uint32_t)__builtin_nontemporal_load(pr + 64 * t);
+                if constexpr (FAIR) f[t] = __builtin_nontemporal_load(pf + 64 * t);
+            } else {
+                a[t] = (T)0;
+                c[t] = (T)0;
+                r[t] = 0u;
+                if constexpr (FAIR) f[t] = (T)0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HM; ++t) {
+            T v = (T)((T)(a[t] * lam_of(r[t])) + (T)(s * c[t]));
+            if constexpr (FAIR) v = (T)(v + (T)(sd * f[t]));
+            u[t] = relu_finite(v);
+        }
+    } else {
+#pragma unroll
+        for (int t0 = 0; t0 < HM; t0 += CH) {
+            T a8[CH], c8[CH], f8[CH];
+            uint32_t r8[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int t = t0 + q;
+                if (t < H) {
+                    a8[q] = pa[64 * t];  // (cached loads: the second pass re-reads them)
+                    c8[q] = pc[64 * t];
+                    r8[q] = (uint32_t)pr[64 * t];
+                    if constexpr (FAIR) f8[q] = pf[64 * t];
+                } else {
+                    a8[q] = (T)0;
+                    c8[q] = (T)0;
+                    r8[q] = 0u;
+                    f8[q] = (T)0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                T v = (T)((T)(a8[q] * lam_of(r8[q])) + (T)(s * c8[q]));
+                if constexpr (FAIR) v = (T)(v + (T)(sd * f8[q]));
+                u[t0 + q] = relu_finite(v);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: hoisting every chunk's loads would cost the registers this variant exists to save
+        }
+    }
+    // ---- projection: per-lane recurrences ----
+    T mx = (T)0, sall = (T)0;  // (padding slots hold a = c = 0, so u = 0 there: harmless for the maximum and the sum)
+#pragma unroll
+    for (int t = 0; t < HM; ++t) {
+        mx = max_nonneg(mx, u[t]);
+        sall = (T)(sall + u[t]);
+    }
+    // slots past a column's own length (the slice's padding; none below Hmin) must not count as members
+#pragma unroll
+    for (int t = 0; t < HM; ++t)
+        if (t >= Hmin) u[t] = t < len ? u[t] : NEG;
+    // first support {u > theta_0}, theta_0 = the larger of two lower bounds of the threshold: max - z (the reference's top-2
+    // shortcut: only the maximum above it <=> vertex) and (sum of all - z) / length (Michelot's start).  Late in a solve, when
+    // most of a column is in its support, the second one is close to the answer and saves a pass or two; a single member can
+    // only happen with theta_0 = max - z (the threshold of a one-element support IS max - z, and theta_0 never exceeds the
+    // threshold), so the vertex test is unchanged.
+    const T th0 = (T)(mx - pj.z);
+    T theta0 = th0;
+    if (!(g.ablate & 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
+    // (supports are counted in integers: the compiler folds two members' worth of compare masks into one add-with-carry, so a
+    //  step of a pass costs four vector instructions -- compare, select, add, count -- instead of five with a float counter)
+    typedef uint32_t CntT;
+    T sum = (T)0;
+    CntT cnt = (CntT)0;
+#pragma unroll
+    for (int t = 0; t < HM; ++t) {
+        const bool in = u[t] > theta0;
+        sum = (T)(sum + (in ? u[t] : (T)0));
+        cnt += in ? (CntT)1 : (CntT)0;
+    }
+    // column state: theta (0 = keep the clamped values), vertex flag
+    const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
+    const bool keep = ineq && !(sall > pj.ztol);  // feasible after the clamp (simplex.py:153-158: the sum of the whole column)
+    bool vertex = !keep && cnt == (CntT)1;
+    T theta = (T)0;
+    bool act = false;
+    if (!keep) {
+        theta = div_exactish((T)(sum - pj.z), (T)(cnt > (CntT)0 ? cnt : (CntT)1));
+        act = cnt > (CntT)2;  // a support of two is final: the runner-up stays above (sum - z)/2 exactly when it is above max - z
+    }
+    if (eq_row) {  // simplex_eq reference-compatibility mode (cold): a deficit is spread over the padded block height
+        if (pj.kind == DL_PROJ_SIMPLEX_EQ && sall < pj.z) {
+            const T L = (T)eq_row[eq_bucket(len > 0 ? len : 1)];
+            theta = (T)((T)(sall - pj.z) / L);
+            vertex = L == (T)1;
+            act = false;
+        }
+    }
+    theta = tmax(theta, keep ? (T)0 : theta0);  // (sum - z)/cnt >= theta_0 in exact arithmetic: keep it so under rounding (nested supports)
+    theta = vertex ? theta0 : theta;  // (the threshold the single member was counted at)
+    CntT cprev = cnt;
+    for (int it = 0; it < kSellMaxH + 2 && __any(act); ++it) {
+        T s2 = (T)0;
+        CntT c2 = (CntT)0;
+#pragma unroll
+        for (int t = 0; t < HM; ++t) {
+            const bool in = u[t] > theta;
+            s2 = (T)(s2 + (in ? u[t] : (T)0));
+            c2 += in ? (CntT)1 : (CntT)0;
+        }
+        const bool changed = act && c2 != cprev && c2 > (CntT)0;
+        const T tn = div_exactish((T)(s2 - pj.z), (T)(c2 > (CntT)0 ? c2 : (CntT)1));
+        theta = changed ? tmax(theta, tn) : theta;  // thresholds never decrease: nested supports, guaranteed termination
+        cprev = changed ? c2 : cprev;
+        act = changed;
+    }
+    // ---- x, scatter, objective sums ----
+    T o32 = (T)0, q32 = (T)0, f32 = (T)0;
+    auto finish = [&](int t, T at, T ct, uint32_t rt, T ft) {
+        const T xg = relu((T)(u[t] - theta));
+        const T x = (vertex && u[t] > theta) ? pj.z : xg;  // vertex: exact z at the maximum, as the reference (xg is 0 at its other members)
+        const T ax = (T)(at * x);
+        if (ax != (T)0) {
+            if constexpr (HOT) {
+                if ((int64_t)rt < g.m_hot) scatter_fixed(w.gacc, rt, ax, w.scale);
+                else scatter_fixed(g.cold_grad, rt, ax, w.scale);
+            } else {
+                scatter_fixed(w.gacc, rt, ax, w.scale);
+            }
+        }
+        o32 = fma_exact(ct, x, o32);
+        q32 = fma_exact(x, x, q32);
+        if constexpr (FAIR) f32 = fma_exact(ft, x, f32);
+        return x;
+    };
+    const FusedArgs<T>& gk = kernarg_args(g);
+    T* xo = gk.x_out;
+    uint64_t k0 = 0;
+    if (xo && has_col) k0 = gk.sell_colstart[dense];
+    if constexpr (!RELOAD) {
+        // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
+        //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)
+#pragma unroll
+        for (int t = 0; t < HM; ++t) {
+            const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
+            if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
+        }
+    } else {
+#pragma unroll
+        for (int t0 = 0; t0 < HM; t0 += CH) {
+            T a8[CH], c8[CH], f8[CH];
+            uint32_t r8[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int t = t0 + q;
+                if (t < H) {
+                    a8[q] = __builtin_nontemporal_load(pa + 64 * t);
+                    c8[q] = __builtin_nontemporal_load(pc + 64 * t);
+                    r8[q] = (uint32_t)__builtin_nontemporal_load(pr + 64 * t);
+                    if constexpr (FAIR) f8[q] = __builtin_nontemporal_load(pf + 64 * t);
+                } else {
+                    a8[q] = (T)0;
+                    c8[q] = (T)0;
+                    r8[q] = 0u;
+                    f8[q] = (T)0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int t = t0 + q;
+                const T x = finish(t, a8[q], c8[q], r8[q], FAIR ? f8[q] : (T)0);
+                if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    obj += (double)o32;
+    ssq += (double)q32;
+    if constexpr (FAIR) fair += (double)f32;
+}
+
+// The slices of one wavefront: descriptors q0, q0 + S, ... (plain cyclic deal: the XCD-weighted deal of the window tiles, carried
+// into this loop, measured +2.5 ... 4.6 % on all-simplex maps whatever its table -- more scalar state across fourteen variants --
+// and the slices' own imbalance is small); the next descriptor travels while the current slice is processed.
+template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
+__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, double& obj, double& ssq, double& fair) {
+    const uint32_t n_sell = g.n_sell;
+    if (q0 >= n_sell) return;
+    const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
+    auto load_desc = [&](uint32_t q) -> uint32_t {
+        const uint32_t t = q < n_sell ? q : n_sell - 1u;
+        return byte_offset(g.sell_desc + (size_t)t * kSellDescWords, dlane * 4u)[0];
+    };
+    auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
+    uint32_t dv = load_desc(q0);
+    for (uint32_t q = q0; q < n_sell; q += S) {
+        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
+        dv = load_desc(q + S);
+        const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
+        const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
+        const bool has_col = lane < ncols;
+        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane : 0);
+        // columns are sorted by length: all but the slices at a length-class boundary hold columns of ONE length -- no length bytes
+        // are read for those (1 byte per column = 1 % of the slices' traffic, and a dependent load off the slice's critical path)
+        int len = has_col ? H : 0;
+        if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;  // wave-uniform
+        const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+        const int32_t* eq_row = nullptr;
+        if (pj.kind == DL_PROJ_SIMPLEX_EQ) {  // cold: the pointer is re-read from the kernel arguments
+            const int32_t* eqh = kernarg_args(g).eq_heights;
+            eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
+        }
+        const int hmin = ncols < 64 ? 0 : Hmin;  // a partly filled slice has empty lanes: every step needs the mask
+        // registers a step keeps across the passes when nothing is re-read: a, c, [f], row, u.  Variants whose columns would
+        // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
+        constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
+        constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
+#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break
+        // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
+        // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
+        // non-zeros per column that padding was ~13 % of the slices' vector instructions.  The others step by four.
+        constexpr bool kExact = sizeof(T) == 4 && !FAIR;
+        const int hv = (kExact && !(g.ablate & 64) && H > 4 && H <= 16) ? H : 4 * sell_chunks(H);  // (DUALIP_HIP_ABLATE=64: steps of four everywhere)
+        switch (hv) {
+            case 4: DL_SELL_CASE(4, R4);
+            case 5: DL_SELL_CASE(kExact ? 5 : 8, R8);
+            case 6: DL_SELL_CASE(kExact ? 6 : 8, R8);
+            case 7: DL_SELL_CASE(kExact ? 7 : 8, R8);
+            case 8: DL_SELL_CASE(8, R8);
+            case 9: DL_SELL_CASE(kExact ? 9 : 12, R12);
+            case 10: DL_SELL_CASE(kExact ? 10 : 12, R12);
+            case 11: DL_SELL_CASE(kExact ? 11 : 12, R12);
+            case 12: DL_SELL_CASE(12, R12);
+            case 13: DL_SELL_CASE(kExact ? 13 : 16, R16);
+            case 14: DL_SELL_CASE(kExact ? 14 : 16, R16);
+            case 15: DL_SELL_CASE(kExact ? 15 : 16, R16);
+            case 16: DL_SELL_CASE(16, R16);
+            default: DL_SELL_CASE(24, true);
+        }
+#undef DL_SELL_CASE
+    }
+}
+
+}  // namespace dl

@@ -1,0 +1,506 @@
+"""GPU edge cases of the fused matching pass against the CPU oracle (``-m gpu``): shapes the golden fixtures do not reach.
+
+  * more than 65 536 dual rows  -> 32-bit row indices, the dual vector and the gradient no longer fit the LDS (global-atomic plan)
+  * more than 255 projection entries -> entries beyond the LDS table are served by the single-column path
+  * value arrays that are not 16-byte aligned, and tiny problems -> the 64-wide tile layout
+  * columns longer than a 256-element window, empty columns, an all-empty problem, a column range of one operator inside another
+Tolerance: RTOL of tests/helpers.py (2e-4 fp32 / 1e-9 fp64, relative to the largest magnitude).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import agd_oracle
+from tests.helpers import NP_DT, RTOL, relerr, torch_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _random_problem(m, n, mean_deg, seed, long_cols=(), empty_every=0):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(mean_deg, n).astype(np.int64)
+    deg = np.minimum(deg, m)
+    for j, d in long_cols:
+        deg[j] = d
+    if empty_every:
+        deg[::empty_every] = 0
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    colptr[1:] = np.cumsum(deg)
+    rows = np.concatenate([np.sort(rng.choice(m, size=int(d), replace=False)) for d in deg]) if deg.sum() else np.zeros(0, dtype=np.int64)
+    nnz = int(colptr[-1])
+    a = rng.uniform(0.05, 1.0, nnz)
+    c = -rng.uniform(0.01, 0.5, nnz)
+    b = rng.uniform(0.5, 2.0, m)
+    return dict(m=m, n=n, colptr=colptr, rowidx=rows.astype(np.int64), a=a, c=c, b=b)
+
+
+def _compare(p, pm, entries, col_proj, gamma, dn, lam, scale=1.0):
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, pm, DEV), gamma=gamma)
+    td = torch.float32 if dn == "f32" else torch.float64
+    res = f.calculate(torch.from_numpy(lam).to(td).to(DEV), gamma=gamma, save_primal=True)
+    ax, obj0, ssq, x = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], p["a"], p["c"], lam, gamma, entries, col_proj=col_proj, dtype=NP_DT[dn])
+    grad, obj, reg, dvtg, mx, sm = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], gamma, NP_DT[dn])
+    assert relerr(res.dual_gradient.cpu().numpy(), grad) < RTOL[dn] * scale
+    assert relerr(res.primal_var.cpu().numpy(), x) < RTOL[dn] * scale
+    assert relerr([float(res.dual_objective), float(res.reg_penalty)], [obj, reg]) < RTOL[dn] * 10 * scale
+    return f
+
+
+@pytest.mark.parametrize("hot", [True, False])
+def test_more_than_65536_rows(hot, monkeypatch):
+    """32-bit row indices; the dual vector and the gradient do not fit the LDS: hot-rows plan, or (plan disabled) global atomics."""
+    import os
+
+    from dualip_amd.projections import create_projection_map
+
+    if not hot:
+        monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "0")
+    m, n = 70_000, 6_000
+    p = _random_problem(m, n, 9, seed=5)
+    lam = np.random.default_rng(1).uniform(0, 0.01, m)
+    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0})):
+            f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
+            info = f.info()
+            assert info["row_index_bytes"] == 4
+            if hot and not narrow:
+                assert info["hot_rows"] > 0 and info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1, info
+            else:
+                assert info["hot_rows"] == 0 and info["lambda_in_lds"] == 0 and info["grad_in_lds"] == 0, info
+
+
+def test_more_projection_entries_than_the_lds_table():
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 300, 6_000
+    p = _random_problem(m, n, 8, seed=9)
+    lam = np.random.default_rng(2).uniform(0, 0.02, m)
+    pm, entries, col_proj = {}, [], np.full(n, -1, dtype=np.int32)
+    per = 15  # 400 entries of 15 columns: box bounds / simplex radii that differ per entry
+    for e in range(n // per):
+        idx = list(range(e * per, (e + 1) * per))
+        if e % 3 == 0:
+            kind, params = "simplex", {"z": 0.5 + 0.01 * e}
+        elif e % 3 == 1:
+            kind, params = "box", {"lower": 0.0, "upper": 0.2 + 0.002 * e}
+        else:
+            kind, params = "cone", {"lower": 0.001 * e}
+        pm[f"e{e}"] = ProjectionEntry(kind, params, indices=idx)
+        entries.append((kind, params))
+        col_proj[idx] = e
+    for dn in ("f32", "f64"):
+        _compare(p, pm, entries, col_proj, 0.02, dn, lam)
+
+
+def test_unaligned_values_and_tiny_problems_take_the_narrow_layout():
+    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = _random_problem(120, 900, 7, seed=3, long_cols=((5, 100), (400, 90)), empty_every=37)
+    lam = np.random.default_rng(4).uniform(0, 0.05, p["m"])
+    pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
+    ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.05)
+    import os
+
+    forced_narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the whole suite is also run with the narrow layout forced)
+    assert ref.info()["layout"] == (1 if forced_narrow else 4)
+    want = ref.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
+    want_grad, want_x = want.dual_gradient.clone(), want.primal_var.clone()
+    # the same values one element into a larger buffer: 4-byte aligned, not 16-byte aligned
+    nnz = int(p["colptr"][-1])
+    a_buf = torch.zeros(nnz + 8, dtype=torch.float32, device=DEV)
+    c_buf = torch.zeros(nnz + 8, dtype=torch.float32, device=DEV)
+    a_buf[1 : nnz + 1] = torch.from_numpy(p["a"]).float().to(DEV)
+    c_buf[1 : nnz + 1] = torch.from_numpy(p["c"]).float().to(DEV)
+    colptr, rowidx = torch.from_numpy(p["colptr"]).to(DEV), torch.from_numpy(p["rowidx"]).to(DEV)
+    A = torch.sparse_csc_tensor(colptr, rowidx, a_buf[1 : nnz + 1], size=(p["m"], p["n"]), check_invariants=False)
+    C = torch.sparse_csc_tensor(colptr, rowidx, c_buf[1 : nnz + 1], size=(p["m"], p["n"]), check_invariants=False)
+    if A.values().data_ptr() % 16 != 0:  # (torch may copy the slice into a fresh, aligned allocation: then there is nothing to test)
+        f = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.from_numpy(p["b"]).float().to(DEV), equality_mask=None), gamma=0.05)
+        assert f.info()["layout"] == 1
+        got = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
+        assert relerr(got.dual_gradient.cpu().numpy(), want_grad.cpu().numpy()) < 1e-6
+        assert relerr(got.primal_var.cpu().numpy(), want_x.cpu().numpy()) < 1e-6
+    # fewer than 1024 non-zeros: narrow layout, same numbers as the oracle
+    q = _random_problem(40, 60, 6, seed=8, empty_every=7)
+    f = _compare(q, create_projection_map("simplex", {"z": 1.0}, q["n"]), [("simplex", {"z": 1.0})], None, 0.05, "f64",
+                 np.random.default_rng(6).uniform(0, 0.05, q["m"]))
+    assert f.info()["layout"] == 1
+
+
+def test_long_columns_empty_columns_and_nested_ranges():
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 2_000, 4_000
+    # columns longer than one 256-element window, next to ordinary and empty ones
+    p = _random_problem(m, n, 10, seed=21, long_cols=((1, 300), (17, 1500), (1999, 257), (3999, 700)), empty_every=11)
+    lam = np.random.default_rng(7).uniform(0, 0.01, m)
+    pm = {
+        "simplex_a": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(0, 1000))),
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 0.7}, indices=list(range(1000, 1800))),
+        "simplex_b": ProjectionEntry("simplex_eq", {"z": 2.0}, indices=list(range(2500, 4000))),
+        # 1800..2499: in no entry
+    }
+    entries = [("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.7}), ("simplex_eq", {"z": 2.0})]
+    col_proj = np.full(n, -1, dtype=np.int32)
+    col_proj[0:1000], col_proj[1000:1800], col_proj[2500:4000] = 0, 1, 2
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.03, dn, lam)
+        # (column 1999 is in no entry: point-wise columns of any length are part of the window stream, not single-column tiles)
+        assert f.info()["long_columns"] >= 3
+
+
+@pytest.mark.parametrize("host_pack", [False, True])
+def test_pointwise_windows_cut_through_columns(host_pack, monkeypatch):
+    """Box / cone / no-entry columns are streamed in windows of 256 non-zeros that ignore column boundaries (columns of 1 to 5000
+    non-zeros, entries changing mid-window, empty columns): same numbers as the oracle, and -- the gradient being summed in
+    integer fixed point -- the same BITS as a handle built with whole-column windows (DUALIP_HIP_FLAT=0)."""
+    import os
+
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
+        pytest.skip("the 64-wide layout has no windows")
+    if host_pack:
+        monkeypatch.setenv("DUALIP_HIP_HOST_PACK", "1")
+    m, n = 3_000, 5_000
+    p = _random_problem(m, n, 12, seed=77, long_cols=((0, 700), (3, 256), (4, 1), (900, 3000), (901, 2999), (2400, 255), (2401, 257), (4200, 1023), (4999, 300)),
+                        empty_every=9)
+    lam = np.random.default_rng(12).uniform(0, 0.02, m)
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.05, "upper": 0.6}, indices=list(range(0, 1500))),
+        "cone": ProjectionEntry("cone", {"lower": 0.1}, indices=list(range(1500, 2400))),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(2400, 3000))),
+        "box2": ProjectionEntry("box", {"lower": 0.0, "upper": 0.3}, indices=list(range(3000, 4000))),
+        # 4000..4999: in no entry
+    }
+    entries = [("box", {"lower": 0.05, "upper": 0.6}), ("cone", {"lower": 0.1}), ("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.3})]
+    col_proj = np.full(n, -1, dtype=np.int32)
+    col_proj[0:1500], col_proj[1500:2400], col_proj[2400:3000], col_proj[3000:4000] = 0, 1, 2, 3
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.04, dn, lam)
+        td = torch.float32 if dn == "f32" else torch.float64
+        lam_t = torch.from_numpy(lam).to(td).to(DEV)
+        got = f.calculate(lam_t, save_primal=True)
+        g1, x1 = got.dual_gradient.clone(), got.primal_var.clone()
+        monkeypatch.setenv("DUALIP_HIP_FLAT", "0")
+        whole = MatchingSolverDualObjectiveFunction(torch_args(p, dn, pm, DEV), gamma=0.04)
+        monkeypatch.delenv("DUALIP_HIP_FLAT")
+        assert whole.info()["long_columns"] > f.info()["long_columns"]
+        ref = whole.calculate(lam_t, save_primal=True)
+        assert torch.equal(ref.primal_var, x1)
+        assert torch.equal(ref.dual_gradient, g1)
+    # with the hot-rows plan (rows beyond the first 1024 gather / scatter through memory)
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "1024")
+    f = _compare(p, pm, entries, col_proj, 0.04, "f32", lam)
+    assert f.info()["hot_rows"] == 1024
+
+
+def test_all_columns_empty():
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = dict(m=50, n=30, colptr=np.zeros(31, dtype=np.int64), rowidx=np.zeros(0, dtype=np.int64), a=np.zeros(0), c=np.zeros(0), b=np.linspace(0.1, 1, 50))
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, 30), DEV), gamma=0.1)
+    lam = torch.rand(50, dtype=torch.float64, device=DEV)
+    res = f.calculate(lam, save_primal=True)
+    assert torch.allclose(res.dual_gradient, -torch.from_numpy(p["b"]).to(DEV))
+    assert abs(float(res.dual_objective) + float((lam.cpu() * torch.from_numpy(p["b"])).sum())) < 1e-12 and res.primal_var.numel() == 0
+
+
+@pytest.mark.parametrize("batching", [True, False])
+def test_simplex_eq_reference_padding_with_long_columns(batching):
+    """The padded-block mode through the single-column path (columns of 300-1500 non-zeros) and ordinary tiles, against the
+    oracle's padded blocks (one oracle entry per nnz-bucket / one for the whole map)."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import padded_eq_entries
+
+    m, n = 2_000, 3_000
+    p = _random_problem(m, n, 10, seed=33, long_cols=((1, 300), (17, 1500), (1999, 257)), empty_every=13)
+    lam = np.random.default_rng(8).uniform(0, 0.01, m)
+    zz = 400.0  # far above most clamped column sums: the padding decides the result
+    entries, _, col_proj = padded_eq_entries(p, zz, batching)
+    for dn in ("f32", "f64"):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map("simplex_eq", {"z": zz}, n), DEV), gamma=0.03, batching=batching,
+                                                simplex_eq_padding="reference")
+        td = torch.float32 if dn == "f32" else torch.float64
+        res = f.calculate(torch.from_numpy(lam).to(td).to(DEV), save_primal=True)
+        ax, obj0, ssq, x = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.03, entries, col_proj=col_proj, dtype=NP_DT[dn])
+        grad = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], 0.03, NP_DT[dn])[0]
+        assert relerr(res.primal_var.cpu().numpy(), x) < RTOL[dn]
+        assert relerr(res.dual_gradient.cpu().numpy(), grad) < RTOL[dn]
+
+
+def test_results_are_bit_reproducible():
+    """The gradient is accumulated in 64-bit fixed point (integer atomics are associative): repeated launches, and two
+    independently built handles, return identical bits -- the reference's scatter_add_ on a GPU does not."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections.base import ProjectionEntry
+
+    m, n = 500, 40_000
+    p = _random_problem(m, n, 10, seed=77)
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=range(0, n // 2)),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=range(n // 2, n)),
+    }
+    lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.02, m)).float().to(DEV)
+    outs = []
+    for _ in range(2):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.02)
+        for _ in range(3):
+            r = f.calculate(lam, save_primal=True)
+            outs.append((r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective)))
+    for g, x, o in outs[1:]:
+        assert torch.equal(g, outs[0][0]) and torch.equal(x, outs[0][1]) and o == outs[0][2]
+
+
+def _skewed_problem(m, n, mean_deg, seed):
+    """Rows drawn from a heavy-tailed popularity law (a few destinations get most of the edges)."""
+    rng = np.random.default_rng(seed)
+    w = rng.lognormal(0.0, 1.5, m)
+    w /= w.sum()
+    deg = np.minimum(rng.poisson(mean_deg, n), 64).astype(np.int64)
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    rows = []
+    for j in range(n):
+        r = np.unique(rng.choice(m, size=int(deg[j]), p=w)) if deg[j] else np.zeros(0, dtype=np.int64)
+        rows.append(r)
+        colptr[j + 1] = colptr[j] + r.size
+    rows = np.concatenate(rows).astype(np.int64)
+    nnz = rows.size
+    return dict(m=m, n=n, colptr=colptr, rowidx=rows, a=rng.uniform(0.05, 1.0, nnz), c=-rng.uniform(0.01, 0.5, nnz), b=rng.uniform(0.5, 2.0, m))
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_hot_rows_plan(forced, monkeypatch):
+    """Dual vector + gradient larger than the LDS: rows renumbered by frequency, the hot ones in LDS, the cold tail on L2
+    gathers / global atomics.  Natural case: 30 000 dual rows; forced case: a small problem with only 128 hot rows.
+    Checked: one calculate() (slab reduction with the inverse permutation) and a device-resident AGD run (stats kernel
+    reading the renumbered slabs) against the oracle."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if forced:
+        monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "128")
+        p = _skewed_problem(700, 5_000, 9, seed=41)
+    else:
+        p = _skewed_problem(30_000, 8_000, 12, seed=42)
+    m, n = p["m"], p["n"]
+    pm = {
+        "box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=list(range(0, n // 2))),
+        "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=list(range(n // 2, n))),
+    }
+    entries = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})]
+    col_proj = np.zeros(n, dtype=np.int32)
+    col_proj[n // 2 :] = 1
+    lam = np.random.default_rng(5).uniform(0, 0.02, m)
+    import os
+
+    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the plan belongs to the 256-wide layout; the numbers must agree anyway)
+    for dn in ("f32", "f64"):
+        f = _compare(p, pm, entries, col_proj, 0.05, dn, lam)
+        info = f.info()
+        if narrow:
+            assert info["hot_rows"] == 0
+            continue
+        assert info["hot_rows"] == (128 if forced else info["hot_rows"]) and 0 < info["hot_rows"] < m, info
+        assert info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1
+        if not forced:
+            assert info["hot_nnz_ppm"] > 500_000  # the frequent rows carry most of the non-zeros
+    # device-resident AGD over the renumbered slabs
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, DEV), gamma=0.05)
+    solver = AcceleratedGradientDescent(max_iter=40, gamma=0.05, initial_step_size=1e-4, max_step_size=1e-2, iteration_callback=False)
+    res = solver.maximize(f, torch.zeros(m, dtype=torch.float64, device=DEV))
+
+    def calc(lam_, gamma):
+        ax, obj0, ssq, _ = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam_, gamma, entries, col_proj=col_proj, dtype=np.float64, want_x=False)
+        grad, obj, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam_, p["b"], gamma, np.float64)
+        return grad, obj, None
+
+    want = agd_oracle.maximize(calc, np.zeros(m), 40, 0.05, initial_step_size=1e-4, max_step_size=1e-2, dtype=np.float64)
+    assert relerr(res.dual_objective_log, want["dual_obj_log"]) < 1e-8
+    assert relerr(res.dual_val.cpu().numpy(), want["dual_val"]) < 1e-8
+
+
+def test_hot_rows_with_single_column_tiles_and_primal(monkeypatch):
+    """Hot-rows plan together with columns longer than a window (their walker gathers / scatters cold rows too) and the
+    primal written out."""
+    from dualip_amd.projections import create_projection_map
+
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "192")
+    monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the single-column walker is the subject: keep long point-wise columns out of the window stream
+    p = _random_problem(900, 3_000, 10, seed=55, long_cols=((3, 400), (1500, 700), (2999, 260)), empty_every=17)
+    lam = np.random.default_rng(9).uniform(0, 0.02, p["m"])
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 0.5})):
+            entries = [(pt, pp)]
+            f = _compare(p, create_projection_map(pt, dict(pp), p["n"]), entries, None, 0.05, dn, lam)
+            info = f.info()
+            if info["layout"] == 4:
+                assert info["hot_rows"] == 192 and info["long_columns"] >= 3
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
+    """Columns of thousands of non-zeros are walked by all 16 wavefronts of a workgroup together (one wavefront alone would
+    set the critical path of the launch); ``forced`` lowers the threshold so that every single-column tile takes that path.
+    Simplex (several Newton passes over a 9 000-entry support), simplex_eq exact and padded, point-wise, columns in no
+    entry, with and without the hot-rows plan, primal written out."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.projections.base import ProjectionEntry
+    from tests.helpers import padded_eq_entries
+
+    if forced:
+        monkeypatch.setenv("DUALIP_HIP_XLONG_MIN", "256")
+    monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the walkers are the subject: keep long point-wise columns out of the window stream
+    m, n = 10_000, 3_000
+    long_cols = ((2, 9000), (700, 3000), (1500, 2049), (2999, 2048), (5, 600), (2000, 5000))
+    p = _random_problem(m, n, 10, seed=77, long_cols=long_cols, empty_every=19)
+    lam = np.random.default_rng(10).uniform(0, 0.01, m)
+    want = 6 if forced else 5  # columns of more than 1024 non-zeros
+    for dn in ("f32", "f64"):
+        for pt, pp in (("simplex", {"z": 1.0}), ("simplex", {"z": 40.0}), ("box", {"lower": 0.0, "upper": 0.5})):
+            f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
+            info = f.info()
+            assert info["long_columns"] >= 6 and (info["layout"] != 4 or info["workgroup_columns"] == want), info  # (DUALIP_HIP_LAYOUT=1 runs: one walker only)
+        # simplex_eq, exact mode (the oracle's padded blocks differ wherever a clamped column sums to less than z): every
+        # non-empty column sums to z, and columns without a deficit agree with the oracle
+        td = torch.float32 if dn == "f32" else torch.float64
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map("simplex_eq", {"z": 25.0}, n), DEV), gamma=0.05)
+        x = f.calculate(torch.from_numpy(lam).to(td).to(DEV), save_primal=True).primal_var.cpu().numpy().astype(np.float64)
+        _, _, _, xo = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.05, [("simplex_eq", {"z": 25.0})], dtype=NP_DT[dn])
+        v = p["a"] * (-lam / 0.05)[p["rowidx"]] - p["c"] / 0.05
+        assert x.min() >= 0
+        for j in range(n):
+            k0, k1 = int(p["colptr"][j]), int(p["colptr"][j + 1])
+            if k1 > k0:
+                assert abs(x[k0:k1].sum() - 25.0) < 25.0 * (1e-4 if dn == "f32" else 1e-10), j
+                if np.maximum(v[k0:k1], 0).sum() > 25.5:
+                    assert np.abs(x[k0:k1] - xo[k0:k1]).max() < RTOL[dn] * 25, j
+        pm = {
+            "s": ProjectionEntry("simplex", {"z": 3.0}, indices=list(range(0, 1000))),
+            "b": ProjectionEntry("box", {"lower": 0.0, "upper": 0.7}, indices=list(range(1000, 1800))),
+            "e": ProjectionEntry("simplex_eq", {"z": 2.0}, indices=list(range(2500, 3000))),
+        }
+        col_proj = np.full(n, -1, dtype=np.int32)
+        col_proj[0:1000], col_proj[1000:1800], col_proj[2500:3000] = 0, 1, 2
+        _compare(p, pm, [("simplex", {"z": 3.0}), ("box", {"lower": 0.0, "upper": 0.7}), ("simplex_eq", {"z": 2.0})], col_proj, 0.03, dn, lam)
+    # padded simplex_eq blocks through the workgroup walker
+    zz = 4000.0
+    entries, _, col_proj = padded_eq_entries(p, zz, True)
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex_eq", {"z": zz}, n), DEV), gamma=0.03, simplex_eq_padding="reference")
+    res = f.calculate(torch.from_numpy(lam).to(DEV), save_primal=True)
+    ax, obj0, ssq, x = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam, 0.03, entries, col_proj=col_proj, dtype=np.float64)
+    assert relerr(res.primal_var.cpu().numpy(), x) < RTOL["f64"]
+    # hot-rows plan: the walker gathers / scatters cold rows through memory
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "2048")
+    for dn in ("f32", "f64"):
+        f = _compare(p, create_projection_map("simplex", {"z": 1.0}, n), [("simplex", {"z": 1.0})], None, 0.05, dn, lam)
+        assert f.info()["layout"] != 4 or (f.info()["hot_rows"] == 2048 and f.info()["workgroup_columns"] == want)
+
+
+def test_hot_rows_state_survives_outside_calls_between_iterations(monkeypatch):
+    """The device-resident loop leaves the renumbered dual vector and the zeroed cold accumulators ready for its next fused
+    launch; a calculate() from outside on the same objective (here: from the iteration callback, with another dual vector)
+    must not be mistaken for that state, and neither must a second run on the same objective."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+
+    monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "128")
+    p = _skewed_problem(700, 5_000, 9, seed=43)
+    m = p["m"]
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), DEV), gamma=0.05)
+    if f.info()["layout"] == 4:
+        assert f.info()["hot_rows"] == 128
+    kw = dict(max_iter=30, gamma=0.05, initial_step_size=1e-4, max_step_size=1e-2)
+    zero = torch.zeros(m, dtype=torch.float64, device=DEV)
+    plain = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, zero)
+    other = torch.rand(m, dtype=torch.float64, device=DEV) * 0.05
+    seen = []
+
+    def intrude(it, result):
+        seen.append(float(f.calculate(other).dual_objective))
+
+    poked = AcceleratedGradientDescent(iteration_callback=intrude, **kw).maximize(f, zero)
+    again = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, zero)
+    assert len(seen) == 30 and max(seen) - min(seen) == 0.0
+    assert poked.dual_objective_log == plain.dual_objective_log and again.dual_objective_log == plain.dual_objective_log
+    assert torch.equal(poked.dual_val, plain.dual_val) and torch.equal(again.dual_val, plain.dual_val)
+    # a warm start from another vector on the same objective
+    warm = AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(f, other)
+    ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), DEV), gamma=0.05)
+    assert AcceleratedGradientDescent(iteration_callback=False, **kw).maximize(ref, other).dual_objective_log == warm.dual_objective_log
+
+
+def test_handles_on_two_devices_in_one_process():
+    """The opt-in to more than 64 KB of LDS is a per-device function attribute: a process that builds handles on two devices (the
+    reference's split_tensors_to_devices idiom) must get it on both (a per-process flag gave it to the first only)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import load, problem, torch_args
+
+    z = load("g1_syn2000.npz")
+    p = problem(z)
+    pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
+    out = []
+    for dev in ("cuda:0", "cuda:1"):
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, dev), 0.02)
+        out.append(f.calculate(torch.from_numpy(z["lam_small"]).to(dev), 0.02).dual_gradient.cpu())
+    assert torch.equal(out[0], out[1])
+
+
+def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
+    """The cyclic deal of window tiles to wavefronts with a per-workgroup number of rounds (csrc/fused_common.h: Deal), adapted from
+    the launches' stamps.  Only large problems adapt by default; here the threshold is lowered so that a 3M-entity mixed problem does.
+    Whatever table the timings produce, every tile keeps exactly one slot: the gradient (integer fixed point) and the primal
+    are bit-identical to a handle with the even deal, the floating-point objective sums agree to rounding."""
+    import os
+
+    from benchmark.synthetic import generate_matching_problem
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
+        pytest.skip("the 64-wide layout deals contiguous ranges")
+    n, m = 3_000_000, 2_000
+    prob = generate_matching_problem(n, m, 5e-3, seed=5, device=torch.device(DEV), dtype=torch.float32)
+    inp = prob["input_args"]
+    half = n // 2
+    inp.projection_map = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(0, half)),
+                          **create_projection_map("simplex", {"z": 1.0}, n, indices=range(half, n))}
+    lam = torch.rand(m, device=DEV) * 0.01
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE", "0")
+    even = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    assert even._lib.dl_matching_info(even._handle, 18) == -1
+    want = even.calculate(lam, save_primal=True)
+    wg, wx, wo = want.dual_gradient.clone(), want.primal_var.clone(), float(want.dual_objective)
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE", "1")
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS", "4")
+    f = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    info = f.info()
+    n_wg = info["workgroups"]
+    tables = set()
+    for it in range(12):  # the first 8 launches adapt the table
+        got = f.calculate(lam, save_primal=(it % 3 == 0))
+        tab = tuple(int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in range(n_wg))
+        tables.add(tab)
+        assert min(tab) >= 1 and max(tab) - min(tab) <= 64
+        assert sum(tab) * 16 >= info["tiles"] - info["long_columns"]
+        assert torch.equal(got.dual_gradient, wg)
+        if it % 3 == 0:
+            assert torch.equal(got.primal_var, wx)
+        assert abs(float(got.dual_objective) - wo) <= 1e-6 * abs(wo)
+    # (the timings of a real device are never perfectly even: the table moves; if it ever did not, the test still passed the invariants)
+    print("tables seen", len(tables))

@@ -11,9 +11,14 @@ generate_synthetic_data.py) at BASELINE.json's headline size -- 100M entities x 
 (gather, projection, scatter-add, reductions) + slab reduction + [RCCL sum-all-reduce of m+2 doubles when N > 1] +
 device-side step-size/AGD update.  Inputs are resident in HBM before the timed region.
 
+    python bench.py --gpus N            (WORLD_SIZE unset: re-executes itself under torch.distributed.run with N ranks)
+
 The JSON line carries, besides the contract fields:
-  roofline     -- HBM roofline of the fused kernel: algorithmic bytes per launch (12 E + 4 n + 16 m) /
-                  average launch duration measured with HIP events on the launch stream inside the timed region.
+  roofline     -- HBM roofline of the fused kernel from the bytes the launch PHYSICALLY moves (values, 2-byte row indices,
+                  descriptors, gradient slabs; counters when profiles/traffic.json has this configuration) / average launch
+                  duration measured with HIP events on the launch stream inside the timed region.  The figure from SURVEY.md
+                  8d's algorithmic bytes (12 E + 4 n + 16 m: 4-byte indices and column pointers the kernel does not read) is
+                  aux.algorithmic_roofline; it can exceed 1 for that reason and is not a physical fraction.
   cpu_baseline -- the CPU oracle (oracle/, OpenMP over all host cores) on a bounded sample of the same workload
                   (rank 0, N = 1 only), scaled to whole-problem iterations/s.  Reported baseline, not a target.
 """
@@ -60,7 +65,12 @@ def parse():
     ap.add_argument("--solve-iters", type=int, default=1000, help="iterations of the whole-solve leg (benchmark/config.py:16-18: 1000)")
     ap.add_argument("--local-blocks", type=int, default=1, help="N > 1 route: split every rank's shard into this many kernel handles (RCCL: the collectives of all but "
                     "the last overlap the next block's fused pass)")
-    ap.add_argument("--comm", choices=["auto", "p2p", "rccl"], default=None, help="exchange back-end of the N > 1 route (default: DUALIP_COMM or auto)")
+    ap.add_argument("--comm", choices=["auto", "p2p", "p2p-fenced", "rccl"], default=None, help="exchange back-end of the N > 1 route (default: DUALIP_COMM or auto)")
+    ap.add_argument("--partition", choices=["contiguous", "reference", "balanced"], default="contiguous", help="how the entities are split over the ranks.  contiguous: "
+                    "one contiguous column range per rank, as the reference (dist_utils.py:53-57), cut so that the ranks' COSTS are equal (a simplex column weighs "
+                    "dist_utils.PROJECTION_COST of a box column); reference: the reference's count-balanced contiguous cuts n // W (+1); balanced: every rank takes "
+                    "its share of every projection block (interleaved, not contiguous)")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="with --emulate-world: which rank's shard to hold (default: the most expensive one of the partition)")
     ap.add_argument("--force-sharded", action="store_true", help="take the N>1 code path (distributed objective + exchange) even with one rank")
     ap.add_argument("--emulate-world", type=int, default=0, help="developer aid: with --force-sharded and one rank, hold rank 0's shard of a W-rank run and "
                     "scale its partial sums by W in place of the all-reduce (per-rank cost of a W-GPU run; the printed value is NOT a result)")
@@ -78,15 +88,45 @@ def projection_blocks(kind, n_global, align):
     return [("box", {"lower": 0.0, "upper": 1.0}, 0, half), ("simplex", {"z": 1.0}, half, n_global)]
 
 
-def shard_plan(kind, n_global, world, rank, align):
-    """(column ranges of this rank, local projection map): every rank takes its share of EVERY projection block
-    (dualip_amd.utils.dist_utils.balanced_block_ranges), so all ranks carry the same operator mix."""
+def partition_table(kind, n_global, world, align):
+    """For every partition: the cut points (contiguous kinds) and the estimated per-rank cost in box-column units."""
+    from dualip_amd.utils.dist_utils import contiguous_cuts, projection_cost, shard_costs
+
+    blocks = projection_blocks(kind, n_global, align)
+    cost_blocks = [(lo, hi, projection_cost(ptype)) for ptype, _, lo, hi in blocks]
+    total = sum((hi - lo) * w for lo, hi, w in cost_blocks)
+    out = {}
+    for name in ("contiguous", "reference"):
+        cuts = contiguous_cuts(n_global, world, cost_blocks if name == "contiguous" else ())
+        costs = shard_costs(cuts, cost_blocks)
+        out[name] = {"cuts": cuts, "costs": costs, "imbalance": max(costs) / (total / world)}
+    out["balanced"] = {"cuts": None, "costs": [total / world] * world, "imbalance": 1.0}
+    return out
+
+
+def shard_plan(kind, n_global, world, rank, align, partition="contiguous"):
+    """(column ranges of this rank, local projection map).
+
+    contiguous / reference: ONE contiguous range [t_r, t_{r+1}) per rank (dualip_amd.utils.dist_utils.contiguous_cuts: cost-weighted
+    or the reference's count-balanced cuts); the local map is the global one re-based.
+    balanced: every rank takes its share of EVERY projection block (dist_utils.balanced_block_ranges)."""
     from dualip_amd.projections import create_projection_map
     from dualip_amd.utils.dist_utils import balanced_block_ranges
 
     ranges, pm, pos = [], {}, 0
-    for ptype, params, lo, hi in projection_blocks(kind, n_global, align):
-        for a, b in balanced_block_ranges([(lo, hi)], world, rank, align):
+    blocks = projection_blocks(kind, n_global, align)
+    if partition == "balanced":
+        for ptype, params, lo, hi in blocks:
+            for a, b in balanced_block_ranges([(lo, hi)], world, rank, align):
+                ranges.append((a, b))
+                pm.update(create_projection_map(ptype, params, None, indices=range(pos, pos + (b - a))))
+                pos += b - a
+        return ranges, pm
+    cuts = partition_table(kind, n_global, world, align)[partition]["cuts"]
+    t0, t1 = cuts[rank], cuts[rank + 1]
+    for ptype, params, lo, hi in blocks:
+        a, b = max(lo, t0), min(hi, t1)
+        if b > a:
             ranges.append((a, b))
             pm.update(create_projection_map(ptype, params, None, indices=range(pos, pos + (b - a))))
             pos += b - a
@@ -380,8 +420,55 @@ def verify_at_size(args, inp, pm_local, f, local, lam, rank, world, sharded, dev
     return out
 
 
+def _free_port():
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def respawn_under_torchrun(args):
+    """``python bench.py --gpus N`` with no launcher around it: run the same command line as N ranks under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) and hand its output through -- rank 0 prints the
+    ONE JSON line.  Returns the launcher's exit status."""
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def collective_selftest(comm, m, device, rank, world):
+    """Before anything is timed: this library's exchange (dl_allreduce_sum on the communicator the solve will use) against
+    torch.distributed's all_reduce of the same random vector, on every rank.  Returns a dict for aux.collective."""
+    out = {"backend": comm.backend if comm is not None else "torch.distributed", "selftest": None}
+    if comm is None:
+        return out
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    worst = 0.0
+    for rnd in range(4):  # (both mailbox parities, twice)
+        v = torch.randn(m + 2, dtype=torch.float64, generator=g).to(device)
+        ref = v.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        ours = comm.all_reduce_(v.clone())
+        comm.check()
+        worst = max(worst, float((ours - ref).abs().max() / ref.abs().max().clamp_min(1e-300)))
+    agree = torch.tensor([worst], dtype=torch.float64, device=device)
+    dist.all_reduce(agree, op=dist.ReduceOp.MAX)
+    worst = float(agree.item())
+    out["selftest"] = {"against": "torch.distributed.all_reduce", "rounds": 4, "max_rel_err_any_rank": worst, "ok": bool(worst <= 1e-12)}
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -415,7 +502,13 @@ def main():
     # chunk-aligned column ranges: this rank's share of every projection block of the SAME global problem
     emu = args.emulate_world if (args.emulate_world > 1 and world == 1 and sharded) else 0
     nb = max(1, args.local_blocks) if sharded else 1
-    vworld, vrank0 = (emu or world) * nb, rank * nb  # a split shard = nb consecutive virtual ranks
+    vworld = (emu or world) * nb  # a split shard = nb consecutive virtual ranks
+    ptable = partition_table(args.proj, n, vworld, CHUNK_COLS)
+    emu_rank = 0
+    if emu:  # hold the most expensive shard of the partition unless told otherwise
+        costs = ptable[args.partition]["costs"]
+        emu_rank = args.emulate_rank if 0 <= args.emulate_rank < emu else max(range(emu), key=lambda r: sum(costs[r * nb:(r + 1) * nb]))
+    vrank0 = (emu_rank if emu else rank) * nb
 
     def reduce_loads(v):
         if sharded:
@@ -425,7 +518,8 @@ def main():
     t_gen = time.perf_counter()
     block_inputs, nnz_local, loads, rho = [], 0, None, None
     for k in range(nb):  # (nb > 1: the shard as nb kernel handles, each with its share of every projection block)
-        ranges_k, pm_k = shard_plan(args.proj, n, vworld, vrank0 + k, CHUNK_COLS)
+        ranges_k, pm_k = shard_plan(args.proj, n, vworld, vrank0 + k, CHUNK_COLS, args.partition)
+        ranges_first = ranges_k if k == 0 else ranges_first
         prob_k = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_ranges=ranges_k)
         prob_k["input_args"].projection_map = pm_k
         block_inputs.append(prob_k["input_args"])
@@ -446,13 +540,17 @@ def main():
     total_nnz = int(nnz_t.item())
 
     t_setup = time.perf_counter()
-    comm = None
+    comm, collective = None, None
     if sharded:
         for bi in block_inputs:
             bi.b_vec = None
         f = MatchingSolverDualObjectiveFunctionDistributed(block_inputs if nb > 1 else block_inputs[0], b_vec, args.gamma, host_device=device, comm_backend=args.comm)
         local = f.local_objective
         comm = f.communicator()  # (None: no native exchange here -- torch.distributed from Python, aux.collective says why)
+        try:  # before anything is timed (and before the emulation factor is set)
+            collective = collective_selftest(comm, m, device, rank, world)
+        except Exception as exc:  # must show in the line, not kill the measurement
+            collective = {"backend": comm.backend if comm is not None else "torch.distributed", "selftest": {"ok": False, "error": f"{type(exc).__name__}: {exc}"}}
         if emu and comm is not None:
             comm.set_emulation(float(emu))
     else:
@@ -486,10 +584,30 @@ def main():
     phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + (lay["tiles"] - lay["long_columns"]) * desc_bytes \
         + lay["long_columns"] * (48 if lay["layout"] == 4 else 16) + lay.get("slices", 0) * 16 + lay.get("slice_mixed_columns", 0) + lay["workgroups"] * (m * 8 + 16)
 
+    # roofline.traffic: HBM bytes per launch from the PMC counters when profiles/traffic.json holds this configuration (collected
+    # by rocprofv3 --pmc passes of this command on an earlier run), else what the launch moves by construction (phys_bytes)
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and not sharded:  # (the recorded passes are single-GPU runs of the whole problem)
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.proj}_{args.entities}_{world}")
+        except Exception:
+            traffic = None
+    if traffic and abs(traffic - phys_bytes) > 0.1 * phys_bytes:  # not this launch (another layout / shard): fall back to the layout's bytes
+        traffic = None
+    if traffic:
+        traffic_source = "profiles/traffic.json: rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, gfx950 corrections) on an earlier run"
+    else:
+        traffic = float(phys_bytes)
+        traffic_source = "layout: bytes the launch moves by construction (no counter pass recorded for this configuration)"
+    roof_bytes = float(traffic)
+
     def roof(kernel_ms, launches):
+        """(average launch seconds, physical GB/s, algorithmic GB/s)"""
         avg_s = (kernel_ms / max(launches, 1)) * 1e-3
-        ach = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        return avg_s, ach
+        if avg_s <= 0:
+            return avg_s, 0.0, 0.0
+        return avg_s, roof_bytes / avg_s / 1e9, alg_bytes / avg_s / 1e9
 
     # ---- headline: W untimed iterations from zero duals, then exactly K timed ----------------------------------
     total_iters = args.warmup + args.steps
@@ -500,7 +618,7 @@ def main():
     elapsed, launches, kernel_ms, xn, xms = timed_window(run, local, comm, args.steps, fence, elapsed_max, stride)
     result = run.finish()
     run.close()
-    avg_kernel_s, achieved = roof(kernel_ms, launches)
+    avg_kernel_s, achieved, achieved_alg = roof(kernel_ms, launches)
 
     # ---- the reference's whole solve (benchmark/config.py:16-18: max_iter 1000) and its late window ----------------
     late, whole, lam_late = None, None, result.dual_val
@@ -520,14 +638,15 @@ def main():
         res2 = run2.finish()
         run2.close()
         lam_late = res2.dual_val
-        avgB, achB = roof(kB, lB)
+        avgB, achB, algB = roof(kB, lB)
         late = {"iterations": [w0 + 1, w1], "ms_per_step": tB / (w1 - w0) * 1e3, "kernel_avg_ms": avgB * 1e3, "achieved_GBps": achB, "frac": achB / HBM_PEAK_GBS,
-                "physical_frac": phys_bytes / avgB / 1e9 / HBM_PEAK_GBS if avgB > 0 else None}
+                "algorithmic_GBps": algB, "algorithmic_frac": algB / HBM_PEAK_GBS}
         if xnB:
             late["exchange_us"] = xmsB / xnB * 1e3
         gamma_end = float(solver2.gamma)
         whole = {"iterations": S, "gamma_continuation": bool(args.gamma_decay), "gamma_first": gamma0, "gamma_last": gamma_end, "seconds": tA + tB + tC, "iterations_per_s": S / (tA + tB + tC), "final_dual_objective": res2.dual_objective,
-                 "algorithmic_GBps": alg_bytes * S / (tA + tB + tC) / 1e9, "frac": alg_bytes * S / (tA + tB + tC) / 1e9 / HBM_PEAK_GBS}
+                 "physical_GBps": roof_bytes * S / (tA + tB + tC) / 1e9, "frac": roof_bytes * S / (tA + tB + tC) / 1e9 / HBM_PEAK_GBS,
+                 "algorithmic_GBps": alg_bytes * S / (tA + tB + tC) / 1e9}
 
     verified = None
     if not args.no_verify:
@@ -541,14 +660,6 @@ def main():
             okt = torch.tensor([1.0 if verified.get("ok") else 0.0], dtype=torch.float64, device=device)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             verified["ok_all_ranks"] = bool(okt.item() > 0.5)
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{args.proj}_{args.entities}_{world}")
-        except Exception:
-            traffic = None
 
     if rank == 0:
         out = {
@@ -572,6 +683,7 @@ def main():
                 "nnz": total_nnz,
                 "projection": args.proj,
                 "parallelism": f"column-shard x{world}" + (f", {nb} blocks per rank" if nb > 1 else ""),
+                "partition": args.partition if sharded else None,
             },
             "roofline": {
                 "bound": "hbm",
@@ -579,16 +691,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "bytes": "traffic (HBM bytes per launch: counters when recorded for this configuration, else the layout's) / kernel_avg_ms",
                 "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command on an earlier run; not measured in this run)" if traffic else None,
+                "traffic_source": traffic_source,
                 "kernel": "matching_fused_kernel4" if lay["layout"] == 4 else "matching_fused_kernel",
                 "kernel_avg_ms": avg_kernel_s * 1e3,
                 "kernel_launches": launches,
                 "event_stride": stride,
-                "algorithmic_bytes_per_launch": alg_bytes,
                 "physical_bytes_per_launch": phys_bytes,
-                "physical_frac": phys_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else None,
-                "physical_GBps": phys_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else None,
                 "window": [args.warmup + 1, args.warmup + args.steps],
             },
             "aux": {
@@ -596,22 +706,34 @@ def main():
                 "setup_s": t_setup,
                 "final_dual_objective": result.dual_objective,
                 "layout": lay,
-                "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
+                "algorithmic_roofline": {
+                    "note": "SURVEY.md 8d's figure: 12 E + 4 n + 16 m bytes per launch (4-byte row indices and column pointers, which this kernel does not read: it "
+                            "streams 2-byte indices and no pointers) / kernel_avg_ms; NOT a physical fraction -- it exceeds roofline.frac by algorithmic / physical bytes",
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "achieved_GBps": achieved_alg,
+                    "frac_of_peak": achieved_alg / HBM_PEAK_GBS,
+                    "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
+                },
+                "partition": {"kind": args.partition if sharded else None, "ranks": vworld,
+                              "cost_model": "columns x dist_utils.PROJECTION_COST (simplex 1.14, point-wise 1.0)",
+                              "estimated_imbalance_max_over_mean": {k: v["imbalance"] for k, v in ptable.items()},
+                              "cuts": ptable[args.partition]["cuts"] if sharded else None,
+                              "this_rank_columns": [list(r) for r in ranges_first]},
                 "late": late,
                 "whole_solve": whole,
                 "whole_solve_its_per_s": whole["iterations_per_s"] if whole else None,
                 "verified": verified,
-                "collective": None,
+                "collective": collective,
                 "copy_ceiling_GBps": copy_ceiling_gbps(device),
                 "read_ceiling_GBps": read_ceiling_gbps(device),
             },
         }
         if comm is not None:
-            out["aux"]["collective"] = {**comm.info(), "emulated_world": emu or None, "exchanges": comm.exchanges,
-                                        "us_per_exchange": (xms / xn * 1e3) if xn else None,
+            out["aux"]["collective"] = {**(collective or {}), **comm.info(), "emulated_world": emu or None, "emulated_rank": emu_rank if emu else None,
+                                        "exchanges": comm.exchanges, "us_per_exchange": (xms / xn * 1e3) if xn else None,
                                         "bracket": "end of the fused pass -> end of the step's first kernel (slab reduction + exchange + gradient statistics)"}
         elif sharded:
-            out["aux"]["collective"] = {"backend": "torch.distributed", "fallback_reason": getattr(f, "comm_fallback", None)}
+            out["aux"]["collective"] = {**(collective or {}), "backend": "torch.distributed", "fallback_reason": getattr(f, "comm_fallback", None)}
         if world == 1 and not args.no_cpu_baseline:
             inp.b_vec = b_vec
             out["cpu_baseline"] = cpu_baseline(args, inp, pm_local, total_nnz)

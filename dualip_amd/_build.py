@@ -69,6 +69,42 @@ def _object_hash(name: str) -> str:
     return h.hexdigest()[:20]
 
 
+_BLOCK = __import__("re").compile(r"^\.LBB\d+_\d+:")
+_KERNEL = __import__("re").compile(r"^(_Z\w+):")
+
+
+def _spill_defects(asm_path: str):
+    """Occurrences, in one device assembly file, of a VGPR spill store/reload that sits between the label of a basic block and the
+    `s_or_b64 exec, exec, ...` that re-enables the lanes which skipped the preceding branch.  SGPR spills (v_writelane, which
+    ignores exec) may legitimately stand there; a VGPR spill executes under the branch's partial exec mask, so wavefronts that
+    skipped the branch entirely store nothing and later reload whatever the scratch slot held.  hipcc 7.2.0 (clang 22.0.0git
+    roc-7.2.0) emitted exactly that in one instantiation of matching_fused_kernel4 (wrong results, then memory faults)."""
+    out, kernel = [], "?"
+    with open(asm_path, errors="replace") as fh:
+        lines = fh.read().split("\n")
+    i, n = 0, len(lines)
+    while i < n:
+        t = lines[i].strip()
+        m = _KERNEL.match(t)
+        if m:
+            kernel = m.group(1)
+        if _BLOCK.match(t):
+            j, spills = i + 1, []
+            while j < n:
+                u = lines[j].strip()
+                if not u or u.startswith(";") or u.startswith(("v_writelane_b32", "v_readlane_b32", "s_nop", "s_waitcnt")):
+                    j += 1
+                elif u.startswith(("scratch_store", "scratch_load", "buffer_store", "buffer_load", "v_accvgpr_write", "v_accvgpr_read")) and ("Spill" in u or "Reload" in u):
+                    spills.append(u.split(";")[0].strip())
+                    j += 1
+                else:
+                    break
+            if spills and j < n and lines[j].strip().startswith("s_or_b64 exec, exec,"):
+                out += [f"{kernel} {t} {u}" for u in spills]
+        i += 1
+    return out
+
+
 def _compile_objects(verbose: bool):
     """One object per source, compiled in parallel and kept by content hash: editing one file rebuilds one object."""
     from concurrent.futures import ThreadPoolExecutor
@@ -86,17 +122,31 @@ def _compile_objects(verbose: bool):
 
     def one(job):
         name, obj = job
-        tmp = f"{obj}.{os.getpid()}.tmp"
-        cmd = [hipcc, *cflags, "-c", "-o", tmp, os.path.join(CSRC, name)]
+        # the object is assembled from device assembly kept beside it for a moment (--save-temps): that text is screened for a
+        # code-generation defect of this compiler that once produced wrong results here (_spill_defects below)
+        work = f"{obj}.{os.getpid()}.d"
+        shutil.rmtree(work, ignore_errors=True)
+        os.makedirs(work)
+        tmp = os.path.join(work, "unit.o")
+        cmd = [hipcc, *cflags, "-c", "--save-temps=obj", "-o", tmp, os.path.join(CSRC, name)]
         if verbose:
             print(" ".join(cmd).replace(tmp, obj))
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-            return name, r.stdout + r.stderr
-        os.replace(tmp, obj)
-        return name, None
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                return name, r.stdout + r.stderr
+            found = []
+            for f in sorted(os.listdir(work)):
+                if f.endswith(".s") and "amdgcn" in f:
+                    found += _spill_defects(os.path.join(work, f))
+            if found and os.environ.get("DUALIP_BUILD_ALLOW_SPILL_DEFECT", "0") in ("", "0"):
+                return name, ("hipcc placed a VGPR spill ahead of the exec restore of a control-flow join (lanes that skipped the branch never store "
+                              "their value and reload garbage -- DESIGN.md section 8, tools/spill_exec_check.py):\n  " + "\n  ".join(found) +
+                              "\nchange the register pressure of that kernel (or set DUALIP_BUILD_ALLOW_SPILL_DEFECT=1 to build anyway)")
+            os.replace(tmp, obj)
+            return name, None
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:

@@ -432,7 +432,12 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     if constexpr (GRAD_LDS) {
         for (int64_t i = tid; i < m_lds; i += kFusedThreads) w.grad_s[i] = 0;
     }
-    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
+    // (a WAVE-UNIFORM branch -- `wave` is a scalar -- not `if (tid < kProjLds)`: the table is filled by whole wavefronts, and no
+    //  wavefront reaches the code after it with an empty exec mask; see DESIGN.md section 8 on the spill the compiler once placed
+    //  ahead of the exec restore of exactly this join)
+    static_assert(kProjLds % 64 == 0 && kProjLds <= kFusedThreads, "projection table filled by whole wavefronts");
+    if (wave < kProjLds / 64) {  // slot kProjLds-1 stays the identity (columns in no entry)
+        const int id = tid;
         w.proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
     }
     lmax = wave_allreduce(lmax, OpMax());

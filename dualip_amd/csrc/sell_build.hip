@@ -2,6 +2,7 @@
 // stable radix sort of the eligible columns by (entry, length), slice table, transposed copies of the value / row arrays.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -239,7 +240,27 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
     if (e == hipSuccess) e = own(&h->sell_a, vs * (size_t)n_elems);
     if (e == hipSuccess) e = own(&h->sell_c, vs * (size_t)n_elems);
     if (e == hipSuccess) e = own(&h->sell_r, (size_t)h->row_bytes * (size_t)n_elems);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->sell_desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, st);
+    // Order of the table = order of the kernel's cyclic deal (wavefront W of the S takes slices W, W + S, ...).  The slices ascend in
+    // height, so every full round is internally even -- but the LAST round is partly filled: N mod S wavefronts walk one more slice
+    // than the others, and in ascending order it is the tallest of all (24 steps against a mean of ten at the benchmark's shape).  The
+    // table is therefore rotated: the N mod S SHORTEST slices go to the end, everything else keeps its ascending order.  Matters when
+    // a wavefront has few rounds (a 12.5M-entity shard of an all-simplex block: 45 rounds, the odd one worth 2.4 of them).  A
+    // descriptor is self-contained (base, first column), so the build kernels below do not care about the order.
+    std::vector<uint32_t> rotated;
+    const uint32_t* desc_up = desc.data();
+    {
+        const char* te = getenv("DUALIP_HIP_SELL_TAIL");
+        const uint64_t S = (uint64_t)(h->n_wg > 0 ? h->n_wg : 1) * (uint64_t)kFusedWaves;
+        const uint64_t r = (uint64_t)n_slices % S;
+        if (!(te && te[0] == '0') && !sell_descending() && r > 0 && (uint64_t)n_slices > S) {
+            rotated.resize(desc.size());
+            const size_t head = (size_t)r * kSellDescWords;
+            std::copy(desc.begin() + head, desc.end(), rotated.begin());
+            std::copy(desc.begin(), desc.begin() + head, rotated.end() - head);
+            desc_up = rotated.data();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h->sell_desc, desc_up, sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, st);
     const unsigned sblocks = (n_slices + 3u) / 4u;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(sell_meta_kernel<IdxT>, dim3(sblocks), dim3(256), 0, st, n_slices, h->sell_desc, ids2, colptr, h->sell_len, h->sell_colstart);

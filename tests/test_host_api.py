@@ -353,3 +353,36 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     if out.returncode == 0:
         assert int(out.stdout.strip()) >= 1
+
+
+def test_build_screens_device_assembly_for_the_misplaced_spill():
+    """Regression guard for the build-dependent wrong result of round 2: hipcc placed a VGPR spill ahead of
+    the exec restore of a control-flow join, so wavefronts that skipped the branch reloaded garbage.  The in-tree build assembles
+    every object from device assembly it has screened for that pattern; the screen must flag the offending excerpt (kept as a
+    fixture, compiler output of this repository's own kernel) and pass its corrected form."""
+    from dualip_amd import _build
+
+    bad = os.path.join(ROOT, "tests", "golden", "spill_before_exec_restore.s")
+    found = _build._spill_defects(bad)
+    assert len(found) == 1 and "scratch_store_dword off, v70" in found[0] and "matching_fused_kernel4IfjLb0ELb0" in found[0], found
+    text = open(bad).read()
+    # the same block with the spill AFTER the exec restore (what a correct allocation looks like) is clean
+    fixed = text.replace("\tscratch_store_dword off, v70, off offset:24 ; 4-byte Folded Spill\n\ts_nop 0\n", "").replace(
+        "\ts_or_b64 exec, exec, s[2:3]\n", "\ts_or_b64 exec, exec, s[2:3]\n\tscratch_store_dword off, v70, off offset:24 ; 4-byte Folded Spill\n")
+    assert fixed != text
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
+        fh.write(fixed)
+    try:
+        assert _build._spill_defects(fh.name) == []
+    finally:
+        os.unlink(fh.name)
+    # SGPR spills (v_writelane ignores exec) in the same place are legitimate and must not be flagged
+    only_sgpr = text.replace("\tscratch_store_dword off, v70, off offset:24 ; 4-byte Folded Spill\n", "")
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
+        fh.write(only_sgpr)
+    try:
+        assert _build._spill_defects(fh.name) == []
+    finally:
+        os.unlink(fh.name)
