@@ -210,3 +210,27 @@ def test_miplib_instance_calculate_and_trace():
         assert relerr(log, want) < 2e-2, (dn, np.abs(log - want).max())
         assert abs(27 - out.dual_objective) < 1  # the driver's own sanity check (solve_miplib_dataset.py:74)
         assert abs(log[99] - want[99]) < 0.05 and abs(log[999] - want[999]) < 0.2 and abs(log[1999] - want[1999]) < 0.3
+
+
+def test_miplib_instance_from_the_mps_file():
+    """BASELINE config 5 from the shipped ``.mps.gz`` itself (solve_miplib_dataset.py:19-75: read_mps_file -> to_dualip_format ->
+    MIPLIBInputArgs -> run_solver): the reader of this package, then the same trace as the reference's (fixture G6)."""
+    import contextlib
+    import io
+    import os
+
+    from dualip_amd.objectives.miplib import MIPLIBInputArgs
+    from dualip_amd.run_solver import run_solver
+    from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
+    from dualip_amd.utils.read_mps_data import read_mps_file
+
+    z = load("g6_miplib_v150.npz")
+    data = read_mps_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "v150d30-2hopcds.mps.gz")).to_dualip_format()  # float32, as the driver
+    args = MIPLIBInputArgs(A=data.A, c=data.C, b_vec=data.b_vec, projection_map=data.projection_map, equality_mask=data.equality_mask)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = run_solver(args, SolverArgs(max_iter=2000, initial_step_size=1e-5, gamma=1e-3), ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="miplib2017"))
+    want = z["trace|f32|obj_log"]
+    log = np.array(out.dual_objective_log)
+    assert relerr(log[:25], want[:25]) < 2e-5 and relerr(log, want) < 2e-2
+    assert abs(27 - out.dual_objective) < 1  # the driver's own check
+    assert abs(log[99] - 23.13099) < 0.05 and abs(log[999] - 25.60996) < 0.2 and abs(log[1999] - 27.01548) < 0.3  # SURVEY.md 8c
