@@ -85,7 +85,7 @@ struct StatsArgs {
     int64_t m;
     // source of A x: either the integer slabs of the fused pass ...
     const long long* __restrict__ partial;
-    const double* __restrict__ partial_scal;
+    const long long* __restrict__ partial_scal;  // fixed point, exponent shift_in[1]
     const int* __restrict__ shift_in;
     int n_slabs, n_scal;
     int64_t mpad;
@@ -217,27 +217,27 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
         }
     }
     if (FROM_SLABS && blockIdx.x + 1 == gridDim.x) {  // the extra last block: scalar partial sums of the fused pass (c.x, sum x^2)
-        double o = 0.0, q = 0.0;
+        long long o = 0, q = 0;  // exact integer sums of the workgroups' fixed-point partials
         for (int w = tid; w < p.n_scal; w += kStatRows * kStatSlices) {
             o += p.partial_scal[2 * w];
             q += p.partial_scal[2 * w + 1];
         }
         o = wave_allreduce(o, OpAdd());
         q = wave_allreduce(q, OpAdd());
-        __shared__ double so[kStatRows * kStatSlices / 64], sq[kStatRows * kStatSlices / 64];
+        __shared__ long long so[kStatRows * kStatSlices / 64], sq[kStatRows * kStatSlices / 64];
         if ((tid & 63) == 0) {
             so[tid >> 6] = o;
             sq[tid >> 6] = q;
         }
         __syncthreads();
         if (tid == 0) {
-            double oo = 0.0, qq = 0.0;
+            long long oo = 0, qq = 0;
             for (int w = 0; w < kStatRows * kStatSlices / 64; ++w) {
                 oo += so[w];
                 qq += sq[w];
             }
-            p.packed_out[p.m] = oo;
-            p.packed_out[p.m + 1] = qq;
+            p.packed_out[p.m] = ldexp((double)oo, -p.shift_in[1]);
+            p.packed_out[p.m + 1] = ldexp((double)qq, -p.shift_in[1]);
         }
     }
 }

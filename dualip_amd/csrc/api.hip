@@ -682,7 +682,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const size_t slabs = h->grad_lds ? (size_t)(h->n_wg > 0 ? h->n_wg : 1) : 1;
     CK(owned_malloc(h, &h->partial, slabs * (size_t)h->mpad * sizeof(long long)));
     CK(owned_malloc(h, (void**)&h->shift_dev, 2 * sizeof(unsigned long long) + sizeof(int)));
-    CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(double) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    CK(owned_malloc(h, (void**)&h->partial_scal, sizeof(long long) * 2 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     if (h->m_hot > 0) {
         CK(owned_malloc(h, (void**)&h->row_inv, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, (void**)&h->row_perm, sizeof(int32_t) * (size_t)m));
@@ -729,7 +729,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     unsigned long long mx_host[2] = {0, 0};
     if (e == hipSuccess) e = hipMalloc((void**)&mx_dev, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(mx_dev, 0, 2 * sizeof(unsigned long long), st);
-    if (e == hipSuccess) e = hipMemsetAsync(h->shift_dev, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(h->shift_dev, 0, 2 * sizeof(int), st);
     if (e == hipSuccess && launch_absmax(val_dtype, nnz, a, mx_dev, st)) e = hipErrorUnknown;
     if (e == hipSuccess && launch_absmax(val_dtype, nnz, c, mx_dev + 1, st)) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemcpyAsync(mx_host, mx_dev, sizeof(mx_host), hipMemcpyDeviceToHost, st);

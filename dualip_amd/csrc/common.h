@@ -97,13 +97,13 @@ struct dl_matching {
     size_t lds_bytes = 0;
     int64_t mpad = 0;          // row stride of the partial slabs (elements)
     void* partial = nullptr;   // owned: int64 fixed point, [n_wg][mpad] (grad_lds) or [1][mpad] (global atomics)
-    int* shift_dev = nullptr;  // owned: fixed-point exponent of the latest launch
+    int* shift_dev = nullptr;  // owned: fixed-point exponents of the latest launch ([0] gradient rows, [1] scalar sums)
     double amax = 0.0, cmax = 0.0;      // max |a|, max |c| (read once at creation: A and c must not change afterwards)
     double xmax_bounded = 0.0;          // largest |x| a bounded projection in use can return
     double pmax_unbounded = 0.0;        // largest |bound| of the one-sided projections in use
     bool has_unbounded = false;         // cone / identity columns exist: |x| is bounded through |v| per launch
     int64_t row_count_max = 0;          // most non-zeros in one row
-    double* partial_scal = nullptr;  // owned: [n_wg][2]
+    long long* partial_scal = nullptr;  // owned: [n_wg][2], c.x and sum x^2 per workgroup in fixed point (exponent shift_dev[1])
     size_t owned_bytes = 0;
     bool use_dpp = true;
     int ablate = 0;  // developer-only timing ablations, see FusedArgs

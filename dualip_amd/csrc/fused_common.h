@@ -20,8 +20,8 @@ struct FusedArgs {
     T* __restrict__ x_out;
     const ProjDev* __restrict__ projs;
     long long* __restrict__ partial;     // [n_wg][mpad] (GRAD_LDS) or [mpad] (global atomics, pre-zeroed)
-    double* __restrict__ partial_scal;   // [n_wg][2]
-    int* __restrict__ shift_out;         // fixed-point exponent chosen for this launch
+    long long* __restrict__ partial_scal;  // [n_wg][2]: c.x and sum x^2 of the workgroup in 64-bit fixed point (exponent shift_out[1])
+    int* __restrict__ shift_out;         // fixed-point exponents chosen for this launch: [0] gradient rows, [1] the two scalar sums
     double gamma;
     double amax, cmax;                   // max |a|, max |c|
     double xmax_bounded;                 // max |x| any bounded projection present can return (box bounds, simplex z)
@@ -133,6 +133,51 @@ __device__ __forceinline__ long long to_fixed(float ax, double scale) {
     return __double_as_longlong(d) - __double_as_longlong(magic);
 }
 __device__ __forceinline__ long long to_fixed(double ax, double scale) { return __double2ll_rn(ax * scale); }
+
+// ---- c.x and sum x^2 in fixed point too ----
+// The gradient is summed in integers, so it does not depend on which wavefront walked which tile.  The two scalar sums used to be
+// per-lane doubles; since the deal of the window tiles adapts to measured timings (Deal, above) their last bits -- and with them
+// the logged dual objective -- followed the timings.  Now every tile / slice / long column contributes ONE rounded integer per
+// lane: the workgroup partials, and the totals the optimiser logs, are identical run to run and for any deal.
+// Exponent: |total| <= nnz * q with q = max(cmax * xmax, xmax^2) must stay below 2^62, and one contribution (at most 32 elements
+// of a lane: four slots of a window, 24 steps of a slice) below the 2^51 the 1.5 * 2^52 conversion trick holds.
+__device__ __forceinline__ int scalar_shift(double nnz, double cmax, double xmax) {
+    const double q = (cmax * xmax > xmax * xmax) ? cmax * xmax : xmax * xmax;
+    int e_tot = 0, e_one = 0;
+    const double tot = nnz * q, one = 32.0 * q;
+    if (tot > 0.0 && tot < 1e300) (void)frexp(tot, &e_tot);
+    if (one > 0.0 && one < 1e300) (void)frexp(one, &e_one);
+    int sh = 62 - e_tot;
+    sh = sh < 50 - e_one ? sh : 50 - e_one;
+    return sh > 1000 ? 1000 : (sh < -1000 ? -1000 : sh);
+}
+// The two accumulators of a lane.  A contribution is added as the RAW bit pattern of fma(v, 2^shift, 1.5 * 2^52) -- whose low 51 bits
+// are the rounded integer (|v * 2^shift| < 2^51 by the choice above) on top of the constant's own pattern -- and the constant is
+// taken off once, `n` times, when the lane hands its sums over (arithmetic mod 2^64): a conversion, a fused multiply-add and one
+// 64-bit add per sum and tile.  `n` counts the add sites passed; every lane of a wavefront passes the same ones, so it is a scalar.
+struct FxAcc {
+    long long obj = 0, ssq = 0;
+    uint32_t n = 0;
+};
+constexpr unsigned long long kFxMagicBits = 0x4338000000000000ull;  // bit pattern of 1.5 * 2^52
+template <class T>
+__device__ __forceinline__ void fx_add(FxAcc& acc, T o, T q, double scale2) {
+    const double magic = 6755399441055744.0;
+    acc.obj += __double_as_longlong(fma((double)o, scale2, magic));
+    acc.ssq += __double_as_longlong(fma((double)q, scale2, magic));
+    acc.n += 1u;
+}
+// a whole long column's sums of one lane (can be large: full conversion, no constant to take off)
+__device__ __forceinline__ void fx_add_wide(FxAcc& acc, double o, double q, double scale2) {
+    acc.obj += __double2ll_rn(o * scale2);
+    acc.ssq += __double2ll_rn(q * scale2);
+}
+__device__ __forceinline__ void fx_finish(FxAcc& acc) {
+    const unsigned long long off = (unsigned long long)acc.n * kFxMagicBits;
+    acc.obj = (long long)((unsigned long long)acc.obj - off);
+    acc.ssq = (long long)((unsigned long long)acc.ssq - off);
+    acc.n = 0;
+}
 
 template <class T>
 __device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax, double scale) {
@@ -347,6 +392,7 @@ struct WgCtx {
     long long* gacc;
     T s;           // -1/gamma rounded once to the working precision (matching.py:136)
     double scale;  // 2^shift of the fixed-point gradient
+    double scale2; // 2^shift of the fixed-point scalar sums (c.x, sum x^2)
 };
 
 // Prologue: carve LDS, stage -lambda/gamma, zero the private gradient, cache the projection table, choose the
@@ -447,7 +493,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     for (int q = 1; q < kFusedWaves; ++q) lmax = w.red_s[q] > lmax ? w.red_s[q] : lmax;
     __syncthreads();  // red_s is reused by the epilogue
     // every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
-    int shift;
+    int shift, shift2;
     {
         double xmax = g.xmax_bounded;
         if (g.has_unbounded) {
@@ -460,23 +506,29 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
         shift = FixedBits<T>::value - e;
         shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+        shift2 = scalar_shift((double)g.nnz, g.cmax, xmax);
     }
     w.scale = ldexp(1.0, shift);
-    if (wg == 0 && tid == 0) *g.shift_out = shift;
+    w.scale2 = ldexp(1.0, shift2);
+    if (wg == 0 && tid == 0) {
+        g.shift_out[0] = shift;
+        g.shift_out[1] = shift2;
+    }
     w.gacc = GRAD_LDS ? w.grad_s : g.partial;
     return w;
 }
 
-// Epilogue: scalar partials of the workgroup, then its private gradient slab.
+// Epilogue: scalar partials of the workgroup (integers: any order gives the same sums), then its private gradient slab.
 template <class T, bool GRAD_LDS, bool FAIR = false>
-__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, double obj, double ssq, int tid, int lane, int wave, int wg,
-                                               double fair = 0.0) {
-    obj = wave_allreduce(obj, OpAdd());
-    ssq = wave_allreduce(ssq, OpAdd());
+__device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCtx<T>& w, FxAcc acc, int tid, int lane, int wave, int wg, double fair = 0.0) {
+    fx_finish(acc);
+    const long long obj = wave_allreduce(acc.obj, OpAdd());
+    const long long ssq = wave_allreduce(acc.ssq, OpAdd());
     if constexpr (FAIR) fair = wave_allreduce(fair, OpAdd());
+    long long* red_i = reinterpret_cast<long long*>(w.red_s);
     if (lane == 0) {
-        w.red_s[2 * wave] = obj;
-        w.red_s[2 * wave + 1] = ssq;
+        red_i[2 * wave] = obj;
+        red_i[2 * wave + 1] = ssq;
         if constexpr (FAIR) w.red_s[2 * kFusedWaves + wave] = fair;
     }
     __syncthreads();
@@ -484,10 +536,10 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
         // (XCD balance: every wavefront of the workgroup has walked all its tiles by now)
         unsigned long long* bst = kernarg_args(g).bal_stamps;
         if (bst) bst[4 * (size_t)wg + 2] = wall_clock64();
-        double o = 0.0, q = 0.0;
+        long long o = 0, q = 0;
         for (int k = 0; k < kFusedWaves; ++k) {
-            o += w.red_s[2 * k];
-            q += w.red_s[2 * k + 1];
+            o += red_i[2 * k];
+            q += red_i[2 * k + 1];
         }
         g.partial_scal[2 * (int64_t)wg] = o;
         g.partial_scal[2 * (int64_t)wg + 1] = q;

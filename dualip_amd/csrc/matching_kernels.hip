@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
     __syncthreads();  // red_s is reused by the epilogue
     // fixed-point exponent: every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
     // (the same value in every workgroup; the slab reduction adds at most log2(#workgroups) <= 12 more bits)
-    int shift;
+    int shift, shift2;
     {
         double xmax = g.xmax_bounded;
         if (g.has_unbounded) {
@@ -89,9 +89,14 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
         if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
         shift = FixedBits<T>::value - e;
         shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
+        shift2 = scalar_shift((double)g.nnz, g.cmax, xmax);
     }
     const double scale = ldexp(1.0, shift);
-    if (wg == 0 && tid == 0) *g.shift_out = shift;
+    const double scale2 = ldexp(1.0, shift2);  // the two scalar sums leave this kernel in fixed point, like the 256-wide kernel's
+    if (wg == 0 && tid == 0) {
+        g.shift_out[0] = shift;
+        g.shift_out[1] = shift2;
+    }
 
     long long* gacc = GRAD_LDS ? grad_s : g.partial;
     double obj = 0.0, ssq = 0.0;
@@ -251,8 +256,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
             o += red_s[2 * w];
             q += red_s[2 * w + 1];
         }
-        g.partial_scal[2 * (int64_t)wg] = o;
-        g.partial_scal[2 * (int64_t)wg + 1] = q;
+        // (this layout's schedule is static -- contiguous tile ranges per workgroup -- so its double sums are the same run to run;
+        //  they are rounded to the fixed-point grid once per workgroup)
+        g.partial_scal[2 * (int64_t)wg] = __double2ll_rn(o * scale2);
+        g.partial_scal[2 * (int64_t)wg + 1] = __double2ll_rn(q * scale2);
     }
     if constexpr (GRAD_LDS) {
         long long* slab = g.partial + (int64_t)wg * g.mpad;
@@ -272,7 +279,7 @@ constexpr int kRedRows = 64;  // rows per block; 16 slab-slices per block
 // packed[i] when `accumulate`) goes to this rank's slot in EVERY rank's mailbox (comm.h: the P2P exchange) -- the slab
 // reduction is the pushing launch, no separate collective.
 template <int MODE>
-__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const double* __restrict__ partial_scal,
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long long* __restrict__ partial, const long long* __restrict__ partial_scal,
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
                                                                       const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
@@ -316,27 +323,28 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         if constexpr (MODE == 2) push_finish(push);
         return;
     }
-    {
-        double o = 0.0, q = 0.0;
+    {   // exact integer sums of the workgroups' fixed-point partials, scaled once
+        long long o = 0, q = 0;
         for (int w = tid; w < n_scal; w += kRedThreads) {
             o += partial_scal[2 * w];
             q += partial_scal[2 * w + 1];
         }
         o = wave_allreduce(o, OpAdd());
         q = wave_allreduce(q, OpAdd());
+        long long* shl = reinterpret_cast<long long*>(sh);
         if ((tid & 63) == 0) {
-            sh[2 * (tid >> 6)] = o;
-            sh[2 * (tid >> 6) + 1] = q;
+            shl[2 * (tid >> 6)] = o;
+            shl[2 * (tid >> 6) + 1] = q;
         }
         __syncthreads();
         if (tid == 0) {
-            double oo = 0.0, qq = 0.0;
+            long long oo = 0, qq = 0;
             for (int w = 0; w < kRedThreads / 64; ++w) {
-                oo += sh[2 * w];
-                qq += sh[2 * w + 1];
+                oo += shl[2 * w];
+                qq += shl[2 * w + 1];
             }
-            emit(m, oo);
-            emit(m + 1, qq);
+            emit(m, ldexp((double)oo, -shift_in[1]));
+            emit(m + 1, ldexp((double)qq, -shift_in[1]));
         }
         if constexpr (MODE == 2) push_finish(push);
     }
@@ -621,7 +629,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.balance = h->bal;
     // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
     //  slices get slower as the Newton passes multiply, the windows do not)
-    args.bal_stamps = (h->bal_stamps && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
+    // (not with the fairness stream: its sum f.x is a per-workgroup double, so an adapting deal would put the measured timings into the
+    //  last bits of the two dense rows; those handles keep the even deal and stay bit-reproducible like the others)
+    args.bal_stamps = (h->bal_stamps && !h->fair && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
     args.do_apply = 0;
     args.apply = ApplyArgs<T>();
     if (pending && pending->valid) {

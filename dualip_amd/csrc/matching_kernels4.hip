@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const int wg = blockIdx.x;
     stamp(g, wg, tid, 0);
     const LaneConst lc = make_lane_const(lane);
-    double obj = 0.0, ssq = 0.0, fair = 0.0;
+    FxAcc acc;  // c.x and sum x^2 of this lane in fixed point (fused_common.h)
+    double fair = 0.0;
 
     // ---- tile schedule ----
     // Descriptors are stored in SCHEDULE order (api.hip: schedule_tiles4) and dealt cyclically to the S = 16 * workgroups
@@ -132,8 +133,11 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     // than one whose sixteen wavefronts move through the phases together.  Same box, 100M mixed: iterations 801-900 1.603 -> 1.557
     // ms (-2.8 %), whole 1000-iteration solve 1.600 -> 1.567 s, iterations 6-35 unchanged.  (DUALIP_HIP_ABLATE=128: windows first
     // everywhere.  Wavefront 0, whose stamps feed the XCD balance, is windows-first.)
-    // (only for the plan with the dual vector and the gradient in LDS: the others are bound by their global gathers / atomics)
-    const bool sell_first = ((LAM_LDS && GRAD_LDS) || (g.ablate & 256)) && !(g.ablate & 128) && ((wave >> 2) & 1);  // (256: developer switch, every plan)
+    // Every LDS plan mixes the order (round 3; same box, 10M mixed: gradient-only plan 0.4575 -> 0.4168 ms per iteration, no-LDS plan
+    // 2.434 -> 2.346).  Round 2 had restricted it to the both-in-LDS plan after one build of the no-LDS plan returned wrong sums with
+    // it: that was a code-generation defect -- a VGPR spill placed ahead of an exec restore, DESIGN.md section 8 -- which the build now
+    // screens every object for (dualip_amd/_build.py: _spill_defects).
+    const bool sell_first = !(g.ablate & 128) && ((wave >> 2) & 1);
     Deal dealw;
     uint32_t kw = 0;                            // round
     uint32_t ti = n_tiles, ti_next = n_tiles;   // schedule slots of the current / next tile (n_tiles: none)
@@ -168,8 +172,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
             const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
-            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
+            double ol = 0.0, ql = 0.0;  // (this column's sums of this thread: one rounded integer each)
+            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
                                                       FAIR ? &fair : nullptr);
+            fx_add_wide(acc, ol, ql, w.scale2);
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
     }
@@ -181,8 +187,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
         const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
         const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
-        process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, obj, ssq, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
+        double ol = 0.0, ql = 0.0;
+        process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
                                             FAIR ? &fair : nullptr);
+        fx_add_wide(acc, ol, ql, w.scale2);
     }
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
     // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
@@ -255,8 +263,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             if constexpr (FAIR) f32 = fma_exact(cur.f.v[j], xq, f32);
             x[j] = xq;
         }
-        obj += (double)o32;
-        ssq += (double)q32;
+        fx_add(acc, o32, q32, w.scale2);
         if constexpr (FAIR) fair += (double)f32;
         if (g.x_out) {
             T* xw = g.x_out + window_of(cur.w0lo, cur.w0hi);
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         if (bst && tid == 0) bst[4 * (size_t)wg + 1] = wall_clock64();
     }
     {
-        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, obj, ssq, fair);
+        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, acc, fair);
     }
     if (sell_first) {
         open_windows();
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         __syncthreads();
         stamp(g, wg, tid, 2);
     }
-    fused_epilogue<T, GRAD_LDS, FAIR>(g, w, obj, ssq, tid, lane, wave, wg, fair);
+    fused_epilogue<T, GRAD_LDS, FAIR>(g, w, acc, tid, lane, wave, wg, fair);
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 3);

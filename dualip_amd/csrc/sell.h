@@ -32,7 +32,7 @@ __host__ __device__ inline int sell_chunks(int H) { return (H + 3) >> 2; }
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR>
 __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, uint64_t dense,
-                                           bool has_col, int lane, T sd, const int32_t* eq_row, double& obj, double& ssq, double& fair) {
+                                           bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
     const T s = w.s;
     // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
     const T* __restrict__ pa = byte_offset(g.sell_a + base, (uint32_t)lane * (uint32_t)sizeof(T));
@@ -225,8 +225,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    obj += (double)o32;
-    ssq += (double)q32;
+    fx_add(acc, o32, q32, w.scale2);  // (one rounded integer per lane, sum and slice: the totals do not depend on who walked what)
     if constexpr (FAIR) fair += (double)f32;
 }
 
@@ -234,7 +233,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
 // into this loop, measured +2.5 ... 4.6 % on all-simplex maps whatever its table -- more scalar state across fourteen variants --
 // and the slices' own imbalance is small); the next descriptor travels while the current slice is processed.
 template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
-__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, double& obj, double& ssq, double& fair) {
+__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, FxAcc& acc, double& fair) {
     const uint32_t n_sell = g.n_sell;
     if (q0 >= n_sell) return;
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
@@ -266,7 +265,7 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
         // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
-#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, obj, ssq, fair); break
+#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, acc, fair); break
         // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
         // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
         // non-zeros per column that padding was ~13 % of the slices' vector instructions.  The others step by four.

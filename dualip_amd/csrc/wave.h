@@ -55,6 +55,12 @@ __device__ __forceinline__ double bperm(int src_lane, double x) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ long long bperm(int src_lane, long long x) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)(unsigned long long)x);
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned int)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 

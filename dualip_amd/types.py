@@ -48,7 +48,8 @@ class ComputeArgs:
     host_device: str                # e.g. "cuda:0"
     compute_device_num: int = 1     # ranks of the process group (one per GPU)
     partition: str = "reference"    # (not in the reference) how run_solver cuts the entities over the ranks: "reference" = n // W (+1)
-                                    # contiguous blocks; "cost" = contiguous blocks of equal estimated cost (DUALIP_PARTITION overrides)
+                                    # contiguous blocks; "cost" = contiguous blocks of equal estimated cost; "balanced" = every rank
+                                    # takes its share of every block of the projection map (DUALIP_PARTITION overrides)
 
     @property
     def sharded(self) -> bool:

@@ -1,0 +1,125 @@
+"""BASELINE.json's configurations at 10M entities inside the driver-run suite (``-m gpu``): config 3 (all-simplex map, gamma
+continuation 35 / 0.7) and the mixed box / simplex map of config 4, both through the device-resident loop
+(``start_device_run``), each followed by the checks bench.py runs at the benchmark size (tests/helpers.verify_at_size: the oracle
+on slabs of columns inside every projection block / straddling the block boundary / at the end of the arrays, A x, c.x and
+sum x^2 recomputed in float64 from the primal, the sharded route against the single objective).  Plus: two solves of the same
+10M problem log IDENTICAL dual objectives while the deal of the window tiles adapts to measured timings (the scalar sums are
+integer sums since round 3), and the golden ``calculate`` cases under the alternative tile layout and without slices.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DEV = "cuda:0"
+N, M = 10_000_000, 10_000
+
+
+def _problem(kind):
+    from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
+    from dualip_amd.projections import create_projection_map
+
+    prob = generate_matching_problem(N, M, 1e-3, seed=42, device=DEV, dtype=torch.float32)
+    inp = prob["input_args"]
+    if kind == "simplex":
+        pm = create_projection_map("simplex", {"z": 1.0}, None, indices=range(N))
+    else:
+        half = (N // 2) // CHUNK_COLS * CHUNK_COLS
+        pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, None, indices=range(0, half)), **create_projection_map("simplex", {"z": 1.0}, None, indices=range(half, N))}
+    inp.projection_map = pm
+    return inp, pm
+
+
+def _solve(f, iters, gamma0, decay):
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+
+    kw = dict(gamma_decay_type="step", gamma_decay_params={"decay_steps": 35, "decay_factor": 0.7}) if decay else {}
+    solver = AcceleratedGradientDescent(max_iter=iters, gamma=gamma0, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False, **kw)
+    run = solver.start_device_run(f, torch.zeros(M, dtype=torch.float32, device=DEV))
+    run.advance(iters)
+    res = run.finish()
+    run.close()
+    return res, float(solver.gamma)
+
+
+@pytest.mark.parametrize("kind", ["simplex_continuation", "mixed"])
+def test_ten_million_entities_through_the_device_loop(kind):
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from tests.helpers import verify_at_size
+
+    decay = kind == "simplex_continuation"
+    inp, pm = _problem("simplex" if decay else "mixed")
+    iters = 200
+    gamma0 = 1e-3 / (0.7 ** (iters // 35)) if decay else 1e-3  # run_matching_benchmark.py:29-38: gamma ends at 1e-3
+    f = MatchingSolverDualObjectiveFunction(inp, gamma0)
+    res, gamma_end = _solve(f, iters, gamma0, decay)
+    log = np.array(res.dual_objective_log)
+    assert len(log) == iters and np.isfinite(log).all()
+    if decay:
+        assert abs(gamma_end - 1e-3) < 1e-15 * 10
+        assert len(set(np.round(res.step_size_log, 12))) > 2  # the continuation moved the step cap (agd.py:102-109)
+    assert log[-1] > log[5]  # dual ascent
+    out = verify_at_size("f32", gamma_end, inp, pm, f, f, res.dual_val, device=DEV)
+    bad = [c for c in out["checks"] if not c["ok"]]
+    assert out["ok"] and not bad, bad
+    names = " ".join(c["name"] for c in out["checks"])
+    assert "inside entry" in names and "last columns" in names and "recomputed from the primal" in names and "sharded route" in names
+    if not decay:
+        assert "straddling" in names
+    info = f.info()
+    assert info["layout"] == 4 and info["slices"] > 0  # the benchmark's kernel plan, not a fallback
+
+
+def test_logs_are_bit_identical_run_to_run_with_the_adaptive_deal():
+    """Two independent handles, two solves each, of the 10M mixed problem: the deal of the window tiles adapts to wall-clock stamps
+    (it does at this size: >= 40 rounds per wavefront), yet every logged dual objective, step size and the final duals agree bit
+    for bit -- gradient AND scalar sums are integer sums (fused_common.h)."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+
+    inp, pm = _problem("mixed")
+    outs = []
+    for _ in range(2):
+        f = MatchingSolverDualObjectiveFunction(inp, 1e-3)
+        assert f.info()["tiles"] / (16 * f.info()["workgroups"]) >= 40  # the balance is active at this size
+        for _ in range(2):
+            res, _g = _solve(f, 60, 1e-3, False)
+            outs.append((list(res.dual_objective_log), list(res.step_size_log), res.dual_val.clone(), res.objective_result.dual_gradient.clone()))
+        del f
+    for log, steps, lam, grad in outs[1:]:
+        assert log == outs[0][0] and steps == outs[0][1]
+        assert torch.equal(lam, outs[0][2]) and torch.equal(grad, outs[0][3])
+
+
+@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0")])
+def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
+    """The reference's golden ``calculate`` cases (fixture G1) with the 64-wide tile layout forced, and with the column-per-lane
+    slices switched off (every simplex column in window tiles): the plans a default run only reaches through unaligned or
+    tiny inputs."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import RTOL, SINGLE_MAPS, load, problem, relerr, torch_args
+
+    monkeypatch.setenv(*switch)
+    TD = {"f32": torch.float32, "f64": torch.float64}
+    for fixture in ("g1_syn2000.npz", "g1_long.npz"):
+        z = load(fixture)
+        p = problem(z)
+        objs = {}
+        for key in z["cases"]:
+            mk, g, ln, dn = str(key).split("|")
+            if mk not in SINGLE_MAPS:
+                continue
+            if (mk, dn) not in objs:
+                pt, pp = SINGLE_MAPS[mk]
+                objs[(mk, dn)] = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map(pt, dict(pp), p["n"]), DEV), float(g))
+                info = objs[(mk, dn)].info()
+                assert (info["layout"] == 1) if switch[0] == "DUALIP_HIP_LAYOUT" else (info["slices"] == 0), info
+            f = objs[(mk, dn)]
+            res = f.calculate(torch.from_numpy(z[f"lam_{ln}"]).to(TD[dn]).to(DEV), gamma=float(g), save_primal=True)
+            for got, name in ((res.dual_gradient.cpu().numpy(), "grad"), (res.primal_var.cpu().numpy(), "x")):
+                assert relerr(got, z[f"{key}|{name}"]) < RTOL[dn], (fixture, key, name)

@@ -88,3 +88,39 @@ def test_generator_shards_of_any_cut_are_slices_of_the_same_problem():
     lens = torch.cat([p["input_args"].A.ccol_indices()[1:] - p["input_args"].A.ccol_indices()[:-1] for p in parts])
     assert torch.equal(lens, A.ccol_indices()[1:] - A.ccol_indices()[:-1])
     assert torch.allclose(sum(p["loads_local"] for p in parts), full["loads_local"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("partition", ["reference", "cost", "balanced"])
+def test_run_solver_shards_cover_the_problem_with_re_based_maps(partition):
+    """run_solver's per-rank slice (run_solver._local_shard) for every partition: the ranks' shards hold every stored entry
+    exactly once, and each local column sits under the operator of its global column."""
+    from dualip_amd.objectives.matching import MatchingInputArgs
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.run_solver import _local_shard
+
+    m, n, cut = 7, 40, 24
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 4, n)
+    cp = np.zeros(n + 1, dtype=np.int64)
+    cp[1:] = np.cumsum(lens)
+    rows = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for k in lens]).astype(np.int64)
+    vals = torch.arange(len(rows), dtype=torch.float64)  # value = position: tells which global entry a local one is
+    A = torch.sparse_csc_tensor(torch.from_numpy(cp), torch.from_numpy(rows), vals, size=(m, n))
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, None, indices=range(0, cut)), **create_projection_map("simplex", {"z": 1.0}, None, indices=range(cut, n))}
+    args = MatchingInputArgs(A=A, c=A, projection_map=pm, b_vec=torch.zeros(m, dtype=torch.float64))
+    for world in (1, 3, 4):
+        seen = []
+        for r in range(world):
+            loc = _local_shard(args, r, world, "cpu", partition)
+            seen.append(loc.A.values())
+            assert sorted(i for e in loc.projection_map.values() for i in e.indices) == list(range(loc.A.size(1)))
+            ptr = loc.A.ccol_indices()
+            for key, e in loc.projection_map.items():
+                for j in e.indices:
+                    for v in loc.A.values()[int(ptr[j]) : int(ptr[j + 1])].tolist():
+                        col = int(np.searchsorted(cp, int(v), side="right") - 1)
+                        assert (col >= cut) == key.startswith("simplex"), (partition, key, col)
+            if partition != "balanced":
+                v = loc.A.values()
+                assert v.numel() == 0 or torch.equal(v, torch.arange(int(v[0]), int(v[0]) + v.numel(), dtype=v.dtype))  # contiguous
+        assert torch.equal(torch.cat(seen).sort().values, vals)
