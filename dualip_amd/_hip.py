@@ -41,6 +41,7 @@ _SIGNATURES = {
     ),
     "dl_matching_destroy": (_c_int, [_c_vp]),
     "dl_matching_update_costs": (_c_int, [_c_vp, _c_vp]),
+    "dl_matching_update_values": (_c_int, [_c_vp, _c_vp]),
     "dl_matching_set_fairness": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "dl_matching_info": (_c_i64, [_c_vp, _c_int]),
     "dl_matching_calculate": (_c_int, [_c_vp, _c_vp, _c_dbl, _c_vp, _c_vp, _c_vp]),

@@ -57,6 +57,7 @@ int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const
                 uint32_t** win_dev_out, int64_t* n_win_out, std::vector<uint32_t>& long_words, std::vector<uint8_t>& used, hipStream_t st);  // pack_build.hip
 int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
+int sell_refill_values(dl_matching* h, hipStream_t st);
 constexpr int kSellMaxLen = 24;  // sell.h: kSellMaxH
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
@@ -126,6 +127,7 @@ static void matching_free(dl_matching* h) {
     if (h->partial) (void)hipFree(h->partial);
     if (h->partial_scal) (void)hipFree(h->partial_scal);
     if (h->shift_dev) (void)hipFree(h->shift_dev);
+    if (h->absmax_dev) (void)hipFree(h->absmax_dev);
     if (h->timeline) (void)hipFree(h->timeline);
     if (h->eq_heights) (void)hipFree(h->eq_heights);
     if (h->row_inv) (void)hipFree(h->row_inv);
@@ -931,21 +933,42 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
     return 0;
 }
 
+// max |v| of one of the caller's value arrays into *out (host), through the handle's cached scratch word (no allocation per call)
+static int refresh_absmax(dl_matching* h, const void* values, double* out, hipStream_t st) {
+    if (!h->absmax_dev) {
+        int rc = owned_malloc(h, (void**)&h->absmax_dev, sizeof(unsigned long long));
+        if (rc) return rc;
+    }
+    unsigned long long bits = 0;
+    hipError_t e = hipMemsetAsync(h->absmax_dev, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess && launch_absmax(h->val_dtype, h->nnz, values, h->absmax_dev, st)) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, h->absmax_dev, sizeof(bits), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the bound travels to the kernel as an argument: the host needs it)
+    if (e != hipSuccess) return hip_fail(e, "value refresh");
+    memcpy(out, &bits, sizeof(double));
+    return 0;
+}
+
 int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
     hipStream_t st = (hipStream_t)stream;
     if (h->has_unbounded && h->nnz > 0) {  // max |c| bounds |v| (hence |x|) for projections that do not bound x themselves
-        unsigned long long* mx_dev = nullptr;
-        unsigned long long bits = 0;
-        DL_HIP(hipMalloc((void**)&mx_dev, sizeof(unsigned long long)));
-        hipError_t e = hipMemsetAsync(mx_dev, 0, sizeof(unsigned long long), st);
-        if (e == hipSuccess && launch_absmax(h->val_dtype, h->nnz, h->c, mx_dev, st)) e = hipErrorUnknown;
-        if (e == hipSuccess) e = hipMemcpyAsync(&bits, mx_dev, sizeof(bits), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(mx_dev);
-        if (e != hipSuccess) return hip_fail(e, "cost update");
-        memcpy(&h->cmax, &bits, sizeof(double));
+        int rc = refresh_absmax(h, h->c, &h->cmax, st);
+        if (rc) return rc;
     }
+    return sell_refill_costs(h, st);
+}
+
+int dl_matching_update_values(dl_matching* h, dl_stream_t stream) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->nnz > 0) {  // max |a| scales the fixed-point gradient; max |c| as in dl_matching_update_costs
+        int rc = refresh_absmax(h, h->a, &h->amax, st);
+        if (!rc) rc = refresh_absmax(h, h->c, &h->cmax, st);
+        if (rc) return rc;
+    }
+    int rc = sell_refill_values(h, st);
+    if (rc) return rc;
     return sell_refill_costs(h, st);
 }
 

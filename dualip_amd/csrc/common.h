@@ -97,6 +97,7 @@ struct dl_matching {
     size_t lds_bytes = 0;
     int64_t mpad = 0;          // row stride of the partial slabs (elements)
     void* partial = nullptr;   // owned: int64 fixed point, [n_wg][mpad] (grad_lds) or [1][mpad] (global atomics)
+    unsigned long long* absmax_dev = nullptr;  // owned: scratch word of dl_matching_update_costs / _values (allocated on first use)
     int* shift_dev = nullptr;  // owned: fixed-point exponents of the latest launch ([0] gradient rows, [1] scalar sums)
     double amax = 0.0, cmax = 0.0;      // max |a|, max |c| (read once at creation: A and c must not change afterwards)
     double xmax_bounded = 0.0;          // largest |x| a bounded projection in use can return

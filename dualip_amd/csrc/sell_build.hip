@@ -318,6 +318,12 @@ int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st) {
     return sell_fill_values(h, f_values, h->sell_f, st);
 }
 
+// the caller rewrote a in place (dl_matching_update_values): refresh the slices' copy
+int sell_refill_values(dl_matching* h, hipStream_t st) {
+    if (h->n_sell == 0) return 0;
+    return sell_fill_values(h, h->a, h->sell_a, st);
+}
+
 // the caller rewrote c in place (dl_matching_update_costs): refresh the slices' copy
 int sell_refill_costs(dl_matching* h, hipStream_t st) {
     if (h->n_sell == 0) return 0;

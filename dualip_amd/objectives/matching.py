@@ -280,6 +280,17 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
             return dual_val, dual_grad
         return dual_val / self.row_norms, dual_grad * self.row_norms
 
+    def values_changed(self) -> None:
+        """Tell the kernel handle that the values of ``A`` (and possibly ``c``) were rewritten in place, pattern unchanged.
+
+        CONTRACT (unlike the reference, which re-reads its tensors in every call): the handle BORROWS ``A.values()`` /
+        ``c.values()`` -- window tiles read them in every launch -- and OWNS transposed copies of the values of the columns it
+        keeps in column-per-lane slices, plus max |a| / max |c| for its fixed-point scales.  After an in-place change call
+        ``values_changed()`` (A, or both) or ``costs_changed()`` (c only) before the next ``calculate``; a changed sparsity
+        pattern needs a new objective."""
+        with torch.cuda.device(self.device):
+            _hip.check(self._lib.dl_matching_update_values(self._handle, _hip.stream_ptr(self.device)))
+
     def costs_changed(self) -> None:
         """Tell the kernel handle that the values of ``c`` were rewritten in place (same pattern): it refreshes what it
         derived from them.  ``A`` must stay as it was when the objective was built."""

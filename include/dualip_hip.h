@@ -97,6 +97,11 @@ int dl_matching_destroy(dl_matching* h);
  * fixed-point scale of the gradient is taken from it).  Use: re-solving with new costs on the same graph; the folded form of
  * the fairness objective (dualip_amd/objectives/matching_fairness.py) calls it every iteration. */
 int dl_matching_update_costs(dl_matching* h, dl_stream_t stream);
+/* The same after the caller rewrote the values of A (and possibly c) in place, pattern unchanged: max |a|, max |c| and the
+ * handle's transposed copies of both are refreshed.  CONTRACT: a handle borrows the caller's value arrays (window tiles read them
+ * in every launch) AND owns re-laid copies of the sliced columns' values -- after any in-place change of A or c one of these two
+ * calls must run before the next launch, or the two kinds of tiles see different data. */
+int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
 
 /* Size/introspection: what = 0 number of wave tiles, 1 workgroups used, 2 LDS bytes per workgroup,
  * 3 lambda staged in LDS (0/1), 4 gradient privatised in LDS (0/1), 5 bytes of owned device memory,

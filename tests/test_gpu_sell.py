@@ -165,6 +165,28 @@ def test_cost_update_refreshes_the_slices():
     assert relerr(f.calculate(lam, 0.05, save_primal=True).primal_var.cpu().numpy(), xo) < 1e-9
 
 
+def test_value_update_refreshes_the_slices():
+    """A and c rewritten in place (same pattern): ``values_changed()`` refreshes the handle's transposed copies and scales, so
+    sliced columns and window tiles see the same data again."""
+    from dualip_amd.projections import create_projection_map
+
+    p = _ragged(19, n=4000, m=200)
+    half = p["n"] // 2
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, p["n"], indices=range(half)), **create_projection_map("simplex", {"z": 1.0}, p["n"], indices=range(half, p["n"]))}
+    f = _objective(p, "f64", pm, 0.05)
+    lam = torch.full((p["m"],), 0.01, dtype=torch.float64, device=DEV)
+    f.A.values().mul_(2.5)
+    f.c.values().mul_(0.6)
+    f.values_changed()
+    col_proj = np.zeros(p["n"], dtype=np.int32)
+    col_proj[half:] = 1
+    ax, _, _, xo = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], p["a"] * 2.5, p["c"] * 0.6, lam.cpu().numpy(), 0.05,
+                                            [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})], col_proj=col_proj)
+    res = f.calculate(lam, 0.05, save_primal=True)
+    assert relerr(res.primal_var.cpu().numpy(), xo) < 1e-9
+    assert relerr(res.dual_gradient.cpu().numpy() + p["b"], ax) < 1e-9
+
+
 def test_bisection_entries_take_the_dense_block_route():
     """method="bisection_search" inside a matching objective: not substituted by the exact projection -- its columns go through
     the operator itself (dense blocks), so x equals what the reference's operator returns for them."""
