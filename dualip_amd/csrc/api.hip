@@ -58,7 +58,8 @@ int pack_device(int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const
 int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
 int sell_refill_values(dl_matching* h, hipStream_t st);
-constexpr int kSellMaxLen = 24;  // sell.h: kSellMaxH
+constexpr int kSellMaxLen = 24;        // sell.h: kSellMaxH
+constexpr int kSellMaxLenLanes = 255;  // sell.h: longest column of an entry sliced with K lanes per column (pid_sell == 2)
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
 constexpr int kReencLdsRows = 16384;  // rows whose histogram a workgroup keeps in LDS (64 KB)
@@ -306,7 +307,7 @@ static int pack_tiles4(int64_t n, int64_t nnz, const int64_t* colptr, const int3
         if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
         const bool sliced = pj != kNoProj && pj < pid_sell.size() && pid_sell[pj];
-        if (sliced && len <= kSellMaxLen) {
+        if (sliced && len <= (pid_sell[pj] == 2 ? kSellMaxLenLanes : kSellMaxLen)) {
             flush();  // (a window holds consecutive columns only)
             continue;
         }
@@ -441,7 +442,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     std::vector<uint32_t> sell_desc_h;
     if (h->layout == 4) {
         const char* se = getenv("DUALIP_HIP_SELL");
-        double min_share = 0.9;
+        double min_share = -1.0;  // default: 0.9, or none when columns of up to 255 non-zeros can be sliced (sell_build.hip)
         if (const char* ms = getenv("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
         if (!(se && se[0] == '0')) CK(sell_prepare(h, colptr, idx_dtype, col_proj, projs_host, n_proj, min_share, pid_sell, sell_desc_h, st));
     }
@@ -869,6 +870,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 15: return h->n_sell_nnz;
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
+        case 2000: return h->n_sell_lane_cols;
         default:
             if (what >= 18 && what < 18 + 1024) {  // rounds of workgroup (what - 18) in the window tiles' deal (synchronous read; -1: no table)
                 if (!h->bal_stamps || what - 18 >= h->n_wg) return -1;

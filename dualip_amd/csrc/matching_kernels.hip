@@ -574,9 +574,16 @@ __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restri
 // the step of the previous iteration CAN ride this handle's launches when every dual entry the kernel reads comes from the
 // workgroup's own LDS copy (256-wide layout, whole dual vector and gradient in LDS, no fairness stream)
 bool matching_can_fuse_apply(const dl_matching* h) {
-    const char* e = getenv("DUALIP_HIP_FUSE_APPLY");  // opt-in ("1"): measured neutral (fused_common.h), so every step is its own launch by default
-    const bool off = !(e && e[0] == '1');
-    return !off && h->layout == 4 && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
+    // DUALIP_HIP_FUSE_APPLY=1 / 0 forces it on / off.  Default: on for SMALL handles -- fewer than kFuseApplyRounds tiles per wavefront.
+    // The folded step saves one launch and its boundary (2.7 us, tools/gridsync_bench.hip) and costs the fused launch a second
+    // dependent memory latency at its head: measured -4.5 % per iteration at 1M entities (10 tiles per wavefront; 44.8 -> 42.8 us,
+    // four pairs on one box), +-1 % at 10M (95), neutral at 12.5M (fused_common.h: fused_prologue).
+    constexpr int64_t kFuseApplyRounds = 32;
+    const char* e = getenv("DUALIP_HIP_FUSE_APPLY");
+    bool on = h->n_wg > 0 && (h->n_tiles + h->n_sell) < kFuseApplyRounds * (int64_t)h->n_wg * kFusedWaves;
+    if (e && e[0] == '1') on = true;
+    if (e && e[0] == '0') on = false;
+    return on && h->layout == 4 && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
 }
 
 template <class T>

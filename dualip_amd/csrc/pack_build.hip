@@ -17,7 +17,8 @@
 namespace dl {
 
 constexpr int kPackChunk = 8192;   // columns per chunk (= per thread)
-constexpr int kPackSellMaxLen = 24;  // sell.h: kSellMaxH
+constexpr int kPackSellMaxLen = 24;        // sell.h: kSellMaxH
+constexpr int kPackSellMaxLenLanes = 255;  // sell.h: kSellMaxLenLanes (entries sliced with K lanes per column: flag bit 3)
 
 struct PackErr {
     int bad_colptr;      // a column pointer decreases
@@ -96,11 +97,11 @@ __device__ __forceinline__ void pack_chunk(int compact, int64_t j0, int64_t j1, 
             continue;
         }
         const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
-        const uint8_t fl = pid_sell[pj == kNoProj ? 255u : (pj < 255u ? pj : 254u)];  // bit 0: sliced entry, bit 1: point-wise entry (flat windows), bit 2: cut at multiples of 256
+        const uint8_t fl = pid_sell[pj == kNoProj ? 255u : (pj < 255u ? pj : 254u)];  // bit 0: sliced entry, bit 1: point-wise entry (flat windows), bit 2: cut at multiples of 256, bit 3: slices hold columns of up to 255
         const bool sliced = pj != kNoProj && pj < 255u && (fl & 1u);
         const bool flat = (pj == kNoProj || pj < 254u) && (fl & 2u);
         const bool flat_align = (fl & 4u) != 0;
-        if (sliced && len <= kPackSellMaxLen) {
+        if (sliced && len <= ((fl & 8u) ? kPackSellMaxLenLanes : kPackSellMaxLen)) {
             flush();  // (a window holds consecutive columns only)
             continue;
         }
@@ -193,7 +194,7 @@ static int pack_device_typed(int64_t n, int64_t nnz, const IdxT* colptr, const i
         if (!keep_win && win) (void)hipFree(win);
     };
     std::vector<uint8_t> flags_h(256, 0);
-    for (size_t q = 0; q < pid_sell_h.size() && q < 255; ++q) flags_h[q] = pid_sell_h[q] ? 1 : 0;
+    for (size_t q = 0; q < pid_sell_h.size() && q < 255; ++q) flags_h[q] = pid_sell_h[q] ? (pid_sell_h[q] == 2 ? 9 : 1) : 0;
     for (size_t q = 0; q < pid_flat_h.size() && q < 254; ++q) flags_h[q] |= pid_flat_h[q] ? (pid_flat_h[q] == 2 ? 6 : 2) : 0;
     if (!pid_flat_h.empty() && pid_flat_h.back()) flags_h[255] = pid_flat_h.back() == 2 ? 6 : 2;  // last element: columns with no projection entry
     PackErr err_h = {0, 0, (long long)n};

@@ -24,15 +24,58 @@ namespace dl {
 
 constexpr int kSellMaxH = 24;     // tallest slice (a column's clamped values stay in registers across the passes: 32 steps would
                                   // spill); longer columns stay on the window / single-column paths
-constexpr int kSellDescWords = 4; // { base[31:0] ; base[39:32] | H << 8 | Hmin << 16 | (ncols - 1) << 24 ; projection id ; dense0 }
+constexpr int kSellDescWords = 4; // { base[31:0] ; base[39:32] | H << 8 | Hmin << 16 | (ncols - 1) << 24 ; projection id | log2 K << 8 ; dense0 }
 
 __host__ __device__ inline int sell_chunks(int H) { return (H + 3) >> 2; }
 
+// ---- K lanes per column (round 3): columns of 25 .. 255 non-zeros ----
+// A column longer than the tallest slice is dealt to K = 2, 4, 8 or 16 ADJACENT lanes: element e of the column sits at lane
+// K * (column in slice) + (e mod K), step e / K -- the slice is still base + 64 t + lane, every load of a wavefront still one
+// contiguous run, and the per-lane recurrences are unchanged; each per-COLUMN quantity (maximum, sums and sizes of the supports) is
+// combined over the K lanes by log2 K butterfly steps on the DPP unit (quad_perm, row_half_mirror, row_mirror -- no LDS traffic),
+// after which all K lanes hold the same bits and take the same decisions.  K is the smallest power of two that brings the height
+// to <= 16 steps (the tallest variant that keeps its registers): 25-32 -> 2, 33-64 -> 4, 65-128 -> 8, 129-255 -> 16, so a slice is
+// 9 .. 16 steps high.  Before, such columns of a sliced entry were single-column tiles (one wavefront per column, latency bound)
+// and those of an unsliced entry went through the segmented window tile (instruction bound).
+constexpr int kSellMaxLenLanes = 255;  // longest column a slice can hold (the per-column length record is one byte)
+__host__ __device__ inline int sell_lanes_log(int len) { return len <= kSellMaxH ? 0 : (len <= 32 ? 1 : (len <= 64 ? 2 : (len <= 128 ? 3 : 4))); }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov0_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+// all-reduce over the 2^KLOG adjacent lanes of a column; commutative steps, so every lane of the group ends with identical bits
+template <int KLOG, class T>
+__device__ __forceinline__ T group_sum(T x) {
+    if constexpr (KLOG >= 1) x = (T)(x + dpp_mov0<DPP_QUAD_XOR1, 0xf>(x));
+    if constexpr (KLOG >= 2) x = (T)(x + dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
+    if constexpr (KLOG >= 3) x = (T)(x + dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
+    if constexpr (KLOG >= 4) x = (T)(x + dpp_mov0<DPP_ROW_MIRROR, 0xf>(x));
+    return x;
+}
+template <int KLOG>
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t x) {
+    if constexpr (KLOG >= 1) x += dpp_mov0_u32<DPP_QUAD_XOR1>(x);
+    if constexpr (KLOG >= 2) x += dpp_mov0_u32<DPP_QUAD_XOR2>(x);
+    if constexpr (KLOG >= 3) x += dpp_mov0_u32<DPP_ROW_HALF_MIRROR>(x);
+    if constexpr (KLOG >= 4) x += dpp_mov0_u32<DPP_ROW_MIRROR>(x);
+    return x;
+}
+template <int KLOG, class T>
+__device__ __forceinline__ T group_max_nonneg(T x) {
+    if constexpr (KLOG >= 1) x = max_nonneg(x, dpp_mov0<DPP_QUAD_XOR1, 0xf>(x));
+    if constexpr (KLOG >= 2) x = max_nonneg(x, dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
+    if constexpr (KLOG >= 3) x = max_nonneg(x, dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
+    if constexpr (KLOG >= 4) x = max_nonneg(x, dpp_mov0<DPP_ROW_MIRROR, 0xf>(x));
+    return x;
+}
+
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
-template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR>
-__device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, uint64_t dense,
-                                           bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
+// KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds
+// (KLOG = 0: the same), `Hmin` the least len_lane of the slice.
+template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR, int KLOG = 0>
+__device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, int len_lane,
+                                           uint64_t dense, bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
     const T s = w.s;
     // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
     const T* __restrict__ pa = byte_offset(g.sell_a + base, (uint32_t)lane * (uint32_t)sizeof(T));
@@ -106,10 +149,12 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         mx = max_nonneg(mx, u[t]);
         sall = (T)(sall + u[t]);
     }
+    mx = group_max_nonneg<KLOG>(mx);
+    sall = group_sum<KLOG>(sall);
     // slots past a column's own length (the slice's padding; none below Hmin) must not count as members
 #pragma unroll
     for (int t = 0; t < HM; ++t)
-        if (t >= Hmin) u[t] = t < len ? u[t] : NEG;
+        if (t >= Hmin) u[t] = t < len_lane ? u[t] : NEG;
     // first support {u > theta_0}, theta_0 = the larger of two lower bounds of the threshold: max - z (the reference's top-2
     // shortcut: only the maximum above it <=> vertex) and (sum of all - z) / length (Michelot's start).  Late in a solve, when
     // most of a column is in its support, the second one is close to the answer and saves a pass or two; a single member can
@@ -129,6 +174,8 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         sum = (T)(sum + (in ? u[t] : (T)0));
         cnt += in ? (CntT)1 : (CntT)0;
     }
+    sum = group_sum<KLOG>(sum);
+    cnt = group_sum_u32<KLOG>(cnt);
     // column state: theta (0 = keep the clamped values), vertex flag
     const bool ineq = pj.kind == DL_PROJ_SIMPLEX;
     const bool keep = ineq && !(sall > pj.ztol);  // feasible after the clamp (simplex.py:153-158: the sum of the whole column)
@@ -150,7 +197,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     theta = tmax(theta, keep ? (T)0 : theta0);  // (sum - z)/cnt >= theta_0 in exact arithmetic: keep it so under rounding (nested supports)
     theta = vertex ? theta0 : theta;  // (the threshold the single member was counted at)
     CntT cprev = cnt;
-    for (int it = 0; it < kSellMaxH + 2 && __any(act); ++it) {
+    for (int it = 0; it < (kSellMaxH << KLOG) + 2 && __any(act); ++it) {
         T s2 = (T)0;
         CntT c2 = (CntT)0;
 #pragma unroll
@@ -159,6 +206,8 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             s2 = (T)(s2 + (in ? u[t] : (T)0));
             c2 += in ? (CntT)1 : (CntT)0;
         }
+        s2 = group_sum<KLOG>(s2);
+        c2 = group_sum_u32<KLOG>(c2);
         const bool changed = act && c2 != cprev && c2 > (CntT)0;
         const T tn = div_exactish((T)(s2 - pj.z), (T)(c2 > (CntT)0 ? c2 : (CntT)1));
         theta = changed ? tmax(theta, tn) : theta;  // thresholds never decrease: nested supports, guaranteed termination
@@ -187,14 +236,14 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     const FusedArgs<T>& gk = kernarg_args(g);
     T* xo = gk.x_out;
     uint64_t k0 = 0;
-    if (xo && has_col) k0 = gk.sell_colstart[dense];
+    if (xo && has_col) k0 = gk.sell_colstart[dense] + (uint64_t)(lane & ((1 << KLOG) - 1));  // this lane's first element of the column
     if constexpr (!RELOAD) {
         // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
         //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
-            if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
+            if (xo && has_col && t < len_lane) xo[k0 + ((uint64_t)t << KLOG)] = x;
         }
     } else {
 #pragma unroll
@@ -220,7 +269,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             for (int q = 0; q < CH; ++q) {
                 const int t = t0 + q;
                 const T x = finish(t, a8[q], c8[q], r8[q], FAIR ? f8[q] : (T)0);
-                if (xo && has_col && t < len) xo[k0 + (uint64_t)t] = x;
+                if (xo && has_col && t < len_lane) xo[k0 + ((uint64_t)t << KLOG)] = x;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -244,15 +293,17 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     uint32_t dv = load_desc(q0);
     for (uint32_t q = q0; q < n_sell; q += S) {
-        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
+        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), w2 = rl(dv, 2), dense0 = rl(dv, 3);
         dv = load_desc(q + S);
+        const uint32_t pid = w2 & 0xFFu;
+        const int klog = (int)((w2 >> 8) & 7u);  // lanes per column = 1 << klog (wave-uniform; 0 for every slice of the benchmark's shape)
         const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
         const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
-        const bool has_col = lane < ncols;
-        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane : 0);
+        const bool has_col = (lane >> klog) < ncols;
+        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane >> klog : 0);
         // columns are sorted by length: all but the slices at a length-class boundary hold columns of ONE length -- no length bytes
         // are read for those (1 byte per column = 1 % of the slices' traffic, and a dependent load off the slice's critical path)
-        int len = has_col ? H : 0;
+        int len = has_col ? H << klog : 0;
         if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;  // wave-uniform
         const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
         const int32_t* eq_row = nullptr;
@@ -260,12 +311,28 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
             const int32_t* eqh = kernarg_args(g).eq_heights;
             eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
         }
-        const int hmin = ncols < 64 ? 0 : Hmin;  // a partly filled slice has empty lanes: every step needs the mask
+        const int hmin = ncols < (64 >> klog) ? 0 : Hmin;  // a partly filled slice has empty lanes: every step needs the mask
         // registers a step keeps across the passes when nothing is re-read: a, c, [f], row, u.  Variants whose columns would
         // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
-#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, dense, has_col, lane, sd, eq_row, acc, fair); break
+        if (klog != 0) {  // K lanes per column: heights 9 .. 16 by construction (sell_lanes_log), two variants per K
+            const int sub = lane & ((1 << klog) - 1);
+            const int len_lane = has_col ? (len - sub + (1 << klog) - 1) >> klog : 0;
+#define DL_SELL_LANES(K_) \
+    if (H <= 12) sell_slice<T, RowT, 12, R12, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
+    else sell_slice<T, RowT, 16, R16, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
+    break
+            switch (klog) {
+                case 1: DL_SELL_LANES(1);
+                case 2: DL_SELL_LANES(2);
+                case 3: DL_SELL_LANES(3);
+                default: DL_SELL_LANES(4);
+            }
+#undef DL_SELL_LANES
+            continue;
+        }
+#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, len, dense, has_col, lane, sd, eq_row, acc, fair); break
         // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
         // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
         // non-zeros per column that padding was ~13 % of the slices' vector instructions.  The others step by four.

@@ -12,30 +12,37 @@
 namespace dl {
 
 constexpr int kSellPidSlots = 256;  // projection ids that can own slices (the kernel's LDS projection table)
-constexpr int kSellBins = kSellMaxH + 2;  // histogram bins per entry: lengths 0 .. kSellMaxH, last = longer
+constexpr int kSellBins = kSellMaxLenLanes + 2;  // histogram bins per entry: lengths 0 .. kSellMaxLenLanes, last = longer
+constexpr int kSellHistLds = 32;                  // entries whose histogram is privatised in LDS (the others count in memory)
 
-// (entry, length) histogram, privatised in LDS: a single-entry map would otherwise put every column on 33 addresses
+// (entry, length) histogram, privatised in LDS for the first kSellHistLds entries: a single-entry map would otherwise put every
+// column on a few dozen addresses.  nnz_by_pid[2 q + 1]: non-zeros of entry q in columns longer than kSellMaxLenLanes.
 template <class IdxT>
 __global__ __launch_bounds__(256) void sell_hist_kernel(int64_t n, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj,
-                                                        unsigned long long* __restrict__ hist /* [256][kSellBins]: lengths 0..kSellMaxH, last = longer */,
-                                                        unsigned long long* __restrict__ nnz_by_pid /* [256][2]: short, long */) {
-    __shared__ unsigned int sh[kSellPidSlots * kSellBins];
-    __shared__ unsigned long long shl[kSellPidSlots];
-    for (int i = threadIdx.x; i < kSellPidSlots * kSellBins; i += 256) sh[i] = 0u;
-    for (int i = threadIdx.x; i < kSellPidSlots; i += 256) shl[i] = 0ull;
+                                                        unsigned long long* __restrict__ hist /* [256][kSellBins] */,
+                                                        unsigned long long* __restrict__ nnz_by_pid /* [256][2]: unused, longer */) {
+    __shared__ unsigned int sh[kSellHistLds * kSellBins];
+    __shared__ unsigned long long shl[kSellHistLds];
+    for (int i = threadIdx.x; i < kSellHistLds * kSellBins; i += 256) sh[i] = 0u;
+    for (int i = threadIdx.x; i < kSellHistLds; i += 256) shl[i] = 0ull;
     __syncthreads();
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t len = (int64_t)colptr[j + 1] - (int64_t)colptr[j];
         const int32_t pid = col_proj ? col_proj[j] : 0;
         if (pid < 0 || pid >= kSellPidSlots - 1 || len <= 0) continue;
-        const int b = len <= kSellMaxH ? (int)len : kSellMaxH + 1;
-        atomicAdd(&sh[pid * kSellBins + b], 1u);
-        if (len > kSellMaxH) atomicAdd(&shl[pid], (unsigned long long)len);
+        const int b = len <= kSellMaxLenLanes ? (int)len : kSellMaxLenLanes + 1;
+        if (pid < kSellHistLds) {
+            atomicAdd(&sh[pid * kSellBins + b], 1u);
+            if (len > kSellMaxLenLanes) atomicAdd(&shl[pid], (unsigned long long)len);
+        } else {
+            atomicAdd(&hist[(size_t)pid * kSellBins + b], 1ull);
+            if (len > kSellMaxLenLanes) atomicAdd(&nnz_by_pid[2 * pid + 1], (unsigned long long)len);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kSellPidSlots * kSellBins; i += 256)
+    for (int i = threadIdx.x; i < kSellHistLds * kSellBins; i += 256)
         if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
-    for (int i = threadIdx.x; i < kSellPidSlots; i += 256)
+    for (int i = threadIdx.x; i < kSellHistLds; i += 256)
         if (shl[i]) atomicAdd(&nnz_by_pid[2 * i + 1], shl[i]);
 }
 
@@ -45,8 +52,10 @@ __global__ __launch_bounds__(256) void sell_keys_kernel(int64_t n, const IdxT* _
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t len = (int64_t)colptr[j + 1] - (int64_t)colptr[j];
         const int32_t pid = col_proj ? col_proj[j] : 0;
-        const bool ok = pid >= 0 && pid < kSellPidSlots - 1 && pid_sell[pid] && len >= 1 && len <= kSellMaxH;
-        keys[j] = ok ? (uint16_t)(((uint32_t)pid << 6) | (uint32_t)(desc ? 63 - len : len)) : (uint16_t)0xFFFF;  // (desc: longest first inside an entry)
+        // pid_sell[q]: 0 = entry without slices, 1 = columns of <= kSellMaxH non-zeros, 2 = of <= kSellMaxLenLanes (K lanes per column)
+        const int64_t max_len = (pid >= 0 && pid < kSellPidSlots - 1) ? (pid_sell[pid] == 2 ? kSellMaxLenLanes : (pid_sell[pid] ? kSellMaxH : 0)) : 0;
+        const bool ok = len >= 1 && len <= max_len;
+        keys[j] = ok ? (uint16_t)(((uint32_t)pid << 8) | (uint32_t)(desc ? 255 - len : len)) : (uint16_t)0xFFFF;  // (desc: longest first inside an entry; pid <= 254)
         ids[j] = (uint32_t)j;
     }
 }
@@ -76,13 +85,18 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(uint32_t n_slices, const
     const uint32_t w0 = desc[(size_t)sl * kSellDescWords], w1 = desc[(size_t)sl * kSellDescWords + 1], dense0 = desc[(size_t)sl * kSellDescWords + 3];
     const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
     const int H = (int)((w1 >> 8) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
+    const int klog = (int)((desc[(size_t)sl * kSellDescWords + 2] >> 8) & 7u);  // lanes per column = 1 << klog: element e of a column at lane K col + e % K, step e / K
+    const int col = lane >> klog, sub = lane & ((1 << klog) - 1);
     int len = 0;
     uint64_t k0 = 0;
-    if (lane < ncols) {
-        len = (int)slen[(size_t)dense0 + lane];
-        k0 = colstart[(size_t)dense0 + lane];
+    if (col < ncols) {
+        len = (int)slen[(size_t)dense0 + col];
+        k0 = colstart[(size_t)dense0 + col];
     }
-    for (int t = 0; t < H; ++t) dst[base + (uint64_t)t * 64u + (uint32_t)lane] = t < len ? src[k0 + (uint64_t)t] : (V)0;
+    for (int t = 0; t < H; ++t) {
+        const int e = (t << klog) + sub;
+        dst[base + (uint64_t)t * 64u + (uint32_t)lane] = e < len ? src[k0 + (uint64_t)e] : (V)0;
+    }
 }
 
 // Decide which projection entries get slices and lay the slices out.  hist / nnz are host copies of sell_hist_kernel's output.
@@ -97,56 +111,68 @@ static bool sell_descending() {
 }
 
 static void sell_plan(const unsigned long long* hist, const unsigned long long* nnz, const dl_proj_desc* projs, int32_t n_proj, bool single_entry, double min_share,
-                      std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems, uint64_t* n_nnz) {
+                      bool lanes_on, std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems, uint64_t* n_nnz, uint64_t* n_lane_cols) {
     pid_sell.assign(kSellPidSlots, 0);
     desc.clear();
     *n_cols = 0;
     *n_elems = 0;
     *n_nnz = 0;
+    *n_lane_cols = 0;
     if (n_proj <= 0 || !projs) return;
     uint64_t dense = 0, base = 0;
+    const int max_len = lanes_on ? kSellMaxLenLanes : kSellMaxH;
+    // length classes by lanes per column (sell_lanes_log): K = 1 << k holds lengths lo[k] .. hi[k]
+    const int lo[5] = {1, kSellMaxH + 1, 33, 65, 129}, hi[5] = {kSellMaxH, 32, 64, 128, kSellMaxLenLanes};
+    const int n_classes = lanes_on ? 5 : 1;
+    const bool down = sell_descending();
     for (int pid = 0; pid < kSellPidSlots - 1 && pid < (single_entry ? 1 : n_proj); ++pid) {
         const int kind = projs[pid].kind;
         if (kind != DL_PROJ_SIMPLEX && kind != DL_PROJ_SIMPLEX_EQ) continue;
         if (projs[pid].flags & DL_PROJ_FLAG_NO_SLICES) continue;
-        double sh = 0.0;
-        for (int l = 1; l <= kSellMaxH; ++l) sh += (double)l * (double)hist[(size_t)pid * kSellBins + l];
-        const double lg = (double)nnz[pid * 2 + 1];
+        const unsigned long long* hp = hist + (size_t)pid * kSellBins;
+        double sh = 0.0, lg = (double)nnz[pid * 2 + 1];
+        for (int l = 1; l <= kSellMaxLenLanes; ++l) (l <= max_len ? sh : lg) += (double)l * (double)hp[l];
         if (sh <= 0.0 || sh < min_share * (sh + lg)) continue;
-        uint64_t cnt = 0;
-        for (int l = 1; l <= kSellMaxH; ++l) cnt += hist[(size_t)pid * kSellBins + l];
-        if (cnt == 0) continue;
-        pid_sell[pid] = 1;
+        pid_sell[pid] = lanes_on ? 2 : 1;
         *n_nnz += (uint64_t)sh;
-        // columns of this entry in sorted order: hist[l] columns of every length l, shortest first (see sell_descending)
-        const bool down = sell_descending();
-        const int l_first = down ? kSellMaxH : 1, l_last = down ? 1 : kSellMaxH, dl = down ? -1 : 1;
-        int l_lo = l_first;    // length of the column at the current position
-        uint64_t left_lo = hist[(size_t)pid * kSellBins + l_first];
-        auto advance = [&](int& l, uint64_t& left, uint64_t by) {  // move `by` columns forward
-            while (by > 0) {
-                while (left == 0 && l != l_last) left = hist[(size_t)pid * kSellBins + (l += dl)];
-                const uint64_t step = by < left ? by : left;
-                left -= step;
-                by -= step;
-                if (step == 0) break;
+        // columns of this entry in sorted order: class by class, hist[l] columns of every length l, shortest first (see sell_descending)
+        for (int kc = 0; kc < n_classes; ++kc) {
+            const int k = down ? n_classes - 1 - kc : kc;
+            const uint32_t per = 64u >> k;  // columns per slice
+            uint64_t cnt = 0;
+            for (int l = lo[k]; l <= hi[k]; ++l) cnt += hp[l];
+            if (cnt == 0) continue;
+            if (k > 0) *n_lane_cols += cnt;
+            const int l_first = down ? hi[k] : lo[k], l_last = down ? lo[k] : hi[k], dl = down ? -1 : 1;
+            int l_lo = l_first;    // length of the column at the current position
+            uint64_t left_lo = hp[l_first];
+            auto advance = [&](int& l, uint64_t& left, uint64_t by) {  // move `by` columns forward
+                while (by > 0) {
+                    while (left == 0 && l != l_last) left = hp[l += dl];
+                    const uint64_t step = by < left ? by : left;
+                    left -= step;
+                    by -= step;
+                    if (step == 0) break;
+                }
+                while (left == 0 && l != l_last) left = hp[l += dl];
+            };
+            advance(l_lo, left_lo, 0);
+            for (uint64_t pos = 0; pos < cnt; pos += per) {
+                const uint32_t ncols = (uint32_t)(cnt - pos < per ? cnt - pos : per);
+                int l_hi = l_lo;
+                uint64_t left_hi = left_lo;
+                advance(l_hi, left_hi, ncols - 1);  // the slice's last column
+                const int len_max = down ? l_lo : l_hi, len_min = down ? l_hi : l_lo;
+                const int H = (len_max + (1 << k) - 1) >> k;  // steps: the longest column's elements per lane
+                const int hmin = len_min >> k;                // the fewest elements any lane of a column holds
+                desc.push_back((uint32_t)base);
+                desc.push_back((uint32_t)(base >> 32) | ((uint32_t)H << 8) | ((uint32_t)hmin << 16) | ((ncols - 1u) << 24));
+                desc.push_back((uint32_t)pid | ((uint32_t)k << 8));
+                desc.push_back((uint32_t)dense);
+                base += (uint64_t)H * 64u;
+                dense += ncols;
+                advance(l_lo, left_lo, ncols);
             }
-            while (left == 0 && l != l_last) left = hist[(size_t)pid * kSellBins + (l += dl)];
-        };
-        advance(l_lo, left_lo, 0);
-        for (uint64_t pos = 0; pos < cnt; pos += 64) {
-            const uint32_t ncols = (uint32_t)(cnt - pos < 64 ? cnt - pos : 64);
-            int l_hi = l_lo;
-            uint64_t left_hi = left_lo;
-            advance(l_hi, left_hi, ncols - 1);  // the slice's last column
-            const int H = down ? l_lo : l_hi, hmin = down ? l_hi : l_lo;
-            desc.push_back((uint32_t)base);
-            desc.push_back((uint32_t)(base >> 32) | ((uint32_t)H << 8) | ((uint32_t)hmin << 16) | ((ncols - 1u) << 24));
-            desc.push_back((uint32_t)pid);
-            desc.push_back((uint32_t)dense);
-            base += (uint64_t)H * 64u;
-            dense += ncols;
-            advance(l_lo, left_lo, ncols);
         }
     }
     *n_cols = dense;
@@ -173,8 +199,15 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(stats);
     if (e != hipSuccess) return hip_fail(e, "slice statistics");
-    uint64_t n_cols = 0, n_elems = 0, n_nnz = 0;
-    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, pid_sell_out, desc, &n_cols, &n_elems, &n_nnz);
+    uint64_t n_cols = 0, n_elems = 0, n_nnz = 0, n_lane_cols = 0;
+    // K lanes per column for the columns of 25 .. 255 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0.  With them an entry's only
+    // leftovers are columns no window could hold either, so the share rule has nothing to protect: every simplex entry is sliced
+    // (min_share < 0: the caller did not set one).
+    const char* le = getenv("DUALIP_HIP_SELL_LANES");
+    const bool lanes_on = !(le && le[0] == '0');
+    if (min_share < 0.0) min_share = lanes_on ? 0.0 : 0.9;
+    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, lanes_on, pid_sell_out, desc, &n_cols, &n_elems,
+              &n_nnz, &n_lane_cols);
     if (n_cols == 0 || n_cols >= (1ull << 32) || desc.size() / kSellDescWords >= (1ull << 31)) {
         pid_sell_out.assign(kSellPidSlots, 0);
         desc.clear();
@@ -184,6 +217,7 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     h->n_sell_cols = (int64_t)n_cols;
     h->n_sell_elems = (int64_t)n_elems;
     h->n_sell_nnz = (int64_t)n_nnz;
+    h->n_sell_lane_cols = (int64_t)n_lane_cols;
     h->n_sell_mixed_cols = 0;
     for (size_t t = 0; t + kSellDescWords <= desc.size(); t += kSellDescWords) {
         const uint32_t w1 = desc[t + 1];

@@ -48,6 +48,69 @@ def _ragged(seed, n=6000, m=300, lens=None):
     return dict(m=m, n=len(lens), colptr=colptr, rowidx=rowidx, a=a, c=c, b=rng.uniform(0.5, 3.0, m))
 
 
+def _boundary_lengths(seed, n=3000, m=400):
+    """Column lengths that hit every class of the K-lanes-per-column slices and its edges (24|25, 32|33, 64|65, 128|129, 255|256),
+    the window limit (253) and columns past everything, plus a random filling of 0 .. 300."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 301, n)
+    edges = [1, 2, 23, 24, 25, 26, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 66, 96, 127, 128, 129, 130, 192, 252, 253, 254, 255, 256, 257, 300, 399]
+    lens[: 3 * len(edges)] = np.repeat(edges, 3)
+    rng.shuffle(lens)
+    lens[::97] = 0
+    return lens
+
+
+@pytest.mark.parametrize("dn", ["f32", "f64"])
+@pytest.mark.parametrize("kind", ["simplex", "simplex_eq", "mixed"])
+def test_lane_slices_every_length_class(kind, dn):
+    """Columns of 25 .. 255 non-zeros are dealt to K = 2 .. 16 lanes each (csrc/sell.h): x, gradient and objective against the
+    oracle and against the same handle without slices, at every class edge; the primal comes back in the caller's order."""
+    from dualip_amd.projections import create_projection_map
+
+    p = _ragged(23, m=400, lens=_boundary_lengths(29))
+    n, m = p["n"], p["m"]
+    lens = np.diff(p["colptr"])
+    if kind == "mixed":
+        cut = n // 3
+        pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, n, indices=range(cut)), **create_projection_map("simplex", {"z": 2.0}, n, indices=range(cut, n))}
+        projs, col_proj, in_entry = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 2.0})], np.r_[np.zeros(cut, np.int32), np.ones(n - cut, np.int32)], lens[cut:]
+    else:
+        pm = create_projection_map(kind, {"z": 2.0}, n)
+        projs, col_proj, in_entry = [(kind, {"z": 2.0})], None, lens
+    gamma = 0.05
+    ctor = dict(batching=False, simplex_eq_padding="reference") if kind == "simplex_eq" else None
+    f = _objective(p, dn, pm, gamma, ctor=ctor)
+    f0 = _objective(p, dn, pm, gamma, sell=False, ctor=ctor)
+    f1 = _objective(p, dn, pm, gamma, ctor=ctor, DUALIP_HIP_SELL_LANES=0)  # one lane per column only: the longer columns walk alone
+    info, info1 = f.info(), f1.info()
+    assert info["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 255)).sum())
+    assert info["slice_lane_columns"] == int(((in_entry >= 25) & (in_entry <= 255)).sum())
+    assert info["long_columns"] >= int((in_entry > 255).sum())
+    assert info1["slice_lane_columns"] == 0 and info1["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 24)).sum())
+    rng = np.random.default_rng(7)
+    for scale in (0.0, 0.02, 0.5):
+        lam = torch.from_numpy(rng.uniform(0, scale, m) if scale else np.zeros(m)).to(TD[dn]).to(DEV)
+        r, r0, r1 = (g.calculate(lam, gamma, save_primal=True) for g in (f, f0, f1))
+        ax, obj0, ssq, xo = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam.cpu().numpy(), gamma, projs, col_proj=col_proj, dtype=NP_DT[dn])
+        x = r.primal_var.cpu().numpy()
+        assert relerr(x, xo) < RTOL[dn]
+        assert relerr(r.dual_gradient.cpu().numpy(), ax - p["b"]) < RTOL[dn]
+        for other in (r0, r1):
+            assert relerr(x, other.primal_var.cpu().numpy()) < RTOL[dn]
+            assert relerr(r.dual_gradient.cpu().numpy(), other.dual_gradient.cpu().numpy()) < RTOL[dn]
+            assert abs(float(r.dual_objective) - float(other.dual_objective)) <= RTOL[dn] * 10 * max(1.0, abs(float(other.dual_objective)))
+        assert torch.equal(f.calculate(lam, gamma, save_primal=True).primal_var, r.primal_var)  # bit-reproducible
+        if kind == "simplex":  # every projected column sums to z or less, and to z where the clamped column exceeded it
+            sums = np.add.reduceat(x, p["colptr"][:-1][lens > 0])
+            assert (sums <= 2.0 * (1 + (1e-5 if dn == "f32" else 1e-10))).all()
+    if kind == "simplex_eq":  # exact mode
+        fe = _objective(p, dn, pm, gamma)
+        lam = torch.from_numpy(rng.uniform(0, 0.3, m)).to(TD[dn]).to(DEV)
+        xe = fe.calculate(lam, gamma, save_primal=True).primal_var.cpu().numpy()
+        sums = np.add.reduceat(xe, p["colptr"][:-1][lens > 0])
+        assert np.allclose(sums, 2.0, atol=2e-4 if dn == "f32" else 1e-9)
+
+
 @pytest.mark.parametrize("dn", ["f32", "f64"])
 @pytest.mark.parametrize("kind", ["simplex", "simplex_eq", "mixed"])
 def test_slices_against_oracle_and_window_tiles(kind, dn):
@@ -71,8 +134,8 @@ def test_slices_against_oracle_and_window_tiles(kind, dn):
     info = f.info()
     lens = np.diff(p["colptr"])
     in_entry = lens[n // 3 :] if kind == "mixed" else lens
-    assert info["slices"] > 0 and info["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 24)).sum())
-    assert info["long_columns"] >= int((in_entry > 24).sum())  # the entry's longer columns walk alone
+    assert info["slices"] > 0 and info["slice_columns"] == int((in_entry >= 1).sum())  # (lengths up to 40: one lane per column to 24, two / four beyond)
+    assert info["slice_lane_columns"] == int((in_entry > 24).sum())
     assert f0.info()["slices"] == 0
     rng = np.random.default_rng(5)
     for scale in (0.0, 0.02, 0.5):
