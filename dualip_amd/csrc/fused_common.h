@@ -57,7 +57,9 @@ struct FusedArgs {
     const T* __restrict__ sell_c;
     const void* __restrict__ sell_r;
     const T* __restrict__ sell_f;
-    uint32_t n_sell;
+    uint32_t n_sell;               // one-lane-per-column slices (sell_desc)
+    const uint32_t* sell_lane_desc;  // slices with K = 2 .. 16 lanes per column (sell.h: sell_lanes_loop), their own table ...
+    uint32_t n_sell_lanes;           // ... and count (cold: read from the kernel arguments)
     // the previous iteration's optimiser step, applied in this launch's prologue (agd_step.h): do_apply != 0 => `lambda` is not read,
     // every workgroup forms the new iterate from apply.{x, g_new, y} and stages THAT; workgroup 0 also stores it (and the state / log)
     int do_apply;

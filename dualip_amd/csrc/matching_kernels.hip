@@ -409,8 +409,14 @@ static int launch_fused_rt(const dl_matching* h, const FusedArgs<T>& args, hipSt
 
 int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4.hip
 int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
-static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) { return launch_fused4_f32(h, args, st); }
-static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) { return launch_fused4_f64(h, args, st); }
+int launch_fused4_f32_lanes(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4_lanes.hip: + the K-lanes-per-column slices
+int launch_fused4_f64_lanes(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
+static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {
+    return h->n_sell_lane_slices > 0 ? launch_fused4_f32_lanes(h, args, st) : launch_fused4_f32(h, args, st);
+}
+static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) {
+    return h->n_sell_lane_slices > 0 ? launch_fused4_f64_lanes(h, args, st) : launch_fused4_f64(h, args, st);
+}
 
 template <class T>
 __global__ void permute_vector_kernel(int64_t m, const T* __restrict__ src, const int32_t* __restrict__ inv, T* __restrict__ dst) {
@@ -625,14 +631,16 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.lambda_orig = static_cast<const T*>(lambda);
     args.partial_fair = h->partial_fair;
     args.fair_max = h->fair ? h->fair_max : 0.0;
-    args.sell_desc = h->sell_desc;
+    args.sell_desc = h->sell_desc ? h->sell_desc + (size_t)h->n_sell_lane_slices * 4 : nullptr;  // (the one-lane slices follow the K-lane ones in the table)
+    args.sell_lane_desc = h->sell_desc;
+    args.n_sell_lanes = (uint32_t)h->n_sell_lane_slices;
     args.sell_len = h->sell_len;
     args.sell_colstart = h->sell_colstart;
     args.sell_a = static_cast<const T*>(h->sell_a);
     args.sell_c = static_cast<const T*>(h->sell_c);
     args.sell_r = h->sell_r;
     args.sell_f = static_cast<const T*>(h->sell_f);
-    args.n_sell = (uint32_t)h->n_sell;
+    args.n_sell = (uint32_t)(h->n_sell - h->n_sell_lane_slices);
     args.balance = h->bal;
     // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
     //  slices get slower as the Newton passes multiply, the windows do not)

@@ -293,17 +293,15 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     uint32_t dv = load_desc(q0);
     for (uint32_t q = q0; q < n_sell; q += S) {
-        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), w2 = rl(dv, 2), dense0 = rl(dv, 3);
+        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
         dv = load_desc(q + S);
-        const uint32_t pid = w2 & 0xFFu;
-        const int klog = (int)((w2 >> 8) & 7u);  // lanes per column = 1 << klog (wave-uniform; 0 for every slice of the benchmark's shape)
         const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
         const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
-        const bool has_col = (lane >> klog) < ncols;
-        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane >> klog : 0);
+        const bool has_col = lane < ncols;
+        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane : 0);
         // columns are sorted by length: all but the slices at a length-class boundary hold columns of ONE length -- no length bytes
         // are read for those (1 byte per column = 1 % of the slices' traffic, and a dependent load off the slice's critical path)
-        int len = has_col ? H << klog : 0;
+        int len = has_col ? H : 0;
         if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;  // wave-uniform
         const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
         const int32_t* eq_row = nullptr;
@@ -311,27 +309,11 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
             const int32_t* eqh = kernarg_args(g).eq_heights;
             eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
         }
-        const int hmin = ncols < (64 >> klog) ? 0 : Hmin;  // a partly filled slice has empty lanes: every step needs the mask
+        const int hmin = ncols < 64 ? 0 : Hmin;  // a partly filled slice has empty lanes: every step needs the mask
         // registers a step keeps across the passes when nothing is re-read: a, c, [f], row, u.  Variants whose columns would
         // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
-        if (klog != 0) {  // K lanes per column: heights 9 .. 16 by construction (sell_lanes_log), two variants per K
-            const int sub = lane & ((1 << klog) - 1);
-            const int len_lane = has_col ? (len - sub + (1 << klog) - 1) >> klog : 0;
-#define DL_SELL_LANES(K_) \
-    if (H <= 12) sell_slice<T, RowT, 12, R12, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
-    else sell_slice<T, RowT, 16, R16, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
-    break
-            switch (klog) {
-                case 1: DL_SELL_LANES(1);
-                case 2: DL_SELL_LANES(2);
-                case 3: DL_SELL_LANES(3);
-                default: DL_SELL_LANES(4);
-            }
-#undef DL_SELL_LANES
-            continue;
-        }
 #define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, len, dense, has_col, lane, sd, eq_row, acc, fair); break
         // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
         // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
@@ -355,6 +337,59 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
             default: DL_SELL_CASE(24, true);
         }
 #undef DL_SELL_CASE
+    }
+}
+
+// The slices with K = 2 .. 16 lanes per column (descriptors g.sell_lane_desc[0 .. g.n_sell_lanes): the columns of 25 .. 255 non-zeros),
+// walked in their OWN loop ahead of the other phases.  Two reasons: they are the most expensive slices (9 .. 16 steps, more Newton
+// passes), so they must not end a launch; and with their eight variants inside sell_loop the code of the one-lane variants changed
+// enough to cost the benchmark's shapes 6 % at 10M entities (same box, DUALIP_HIP_SELL_LANES=0 on the same binary no faster: the code,
+// not the slices).  Heights are 9 .. 16 by construction (sell_lanes_log): two variants per K.
+template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
+__device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, FxAcc& acc, double& fair) {
+    const uint32_t n_sell = kernarg_args(g).n_sell_lanes;
+    if (q0 >= n_sell) return;
+    const uint32_t* __restrict__ table = kernarg_args(g).sell_lane_desc;
+    const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
+    auto load_desc = [&](uint32_t q) -> uint32_t {
+        const uint32_t t = q < n_sell ? q : n_sell - 1u;
+        return byte_offset(table + (size_t)t * kSellDescWords, dlane * 4u)[0];
+    };
+    auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
+    uint32_t dv = load_desc(q0);
+    for (uint32_t q = q0; q < n_sell; q += S) {
+        const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), w2 = rl(dv, 2), dense0 = rl(dv, 3);
+        dv = load_desc(q + S);
+        const uint32_t pid = w2 & 0xFFu;
+        const int klog = (int)((w2 >> 8) & 7u);  // lanes per column = 1 << klog (wave-uniform)
+        const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
+        const int H = (int)((w1 >> 8) & 0xFFu), Hmin = (int)((w1 >> 16) & 0xFFu), ncols = (int)((w1 >> 24) & 0xFFu) + 1;
+        const bool has_col = (lane >> klog) < ncols;
+        const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane >> klog : 0);
+        int len = has_col ? H << klog : 0;  // (one length in the slice, a multiple of K: no length bytes read)
+        if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;
+        const int sub = lane & ((1 << klog) - 1);
+        const int len_lane = has_col ? (len - sub + (1 << klog) - 1) >> klog : 0;
+        const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
+        const int32_t* eq_row = nullptr;
+        if (pj.kind == DL_PROJ_SIMPLEX_EQ) {
+            const int32_t* eqh = kernarg_args(g).eq_heights;
+            eq_row = eqh ? eqh + (size_t)pid * kEqBuckets : nullptr;
+        }
+        const int hmin = ncols < (64 >> klog) ? 0 : Hmin;
+        constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
+        constexpr bool R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
+#define DL_SELL_LANES(K_) \
+    if (H <= 12) sell_slice<T, RowT, 12, R12, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
+    else sell_slice<T, RowT, 16, R16, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
+    break
+        switch (klog) {
+            case 1: DL_SELL_LANES(1);
+            case 2: DL_SELL_LANES(2);
+            case 3: DL_SELL_LANES(3);
+            default: DL_SELL_LANES(4);
+        }
+#undef DL_SELL_LANES
     }
 }
 

@@ -111,7 +111,7 @@ static bool sell_descending() {
 }
 
 static void sell_plan(const unsigned long long* hist, const unsigned long long* nnz, const dl_proj_desc* projs, int32_t n_proj, bool single_entry, double min_share,
-                      bool lanes_on, std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems, uint64_t* n_nnz, uint64_t* n_lane_cols) {
+                      bool lanes_on, double lane_share, std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, uint64_t* n_cols, uint64_t* n_elems, uint64_t* n_nnz, uint64_t* n_lane_cols) {
     pid_sell.assign(kSellPidSlots, 0);
     desc.clear();
     *n_cols = 0;
@@ -120,20 +120,28 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
     *n_lane_cols = 0;
     if (n_proj <= 0 || !projs) return;
     uint64_t dense = 0, base = 0;
-    const int max_len = lanes_on ? kSellMaxLenLanes : kSellMaxH;
     // length classes by lanes per column (sell_lanes_log): K = 1 << k holds lengths lo[k] .. hi[k]
     const int lo[5] = {1, kSellMaxH + 1, 33, 65, 129}, hi[5] = {kSellMaxH, 32, 64, 128, kSellMaxLenLanes};
-    const int n_classes = lanes_on ? 5 : 1;
     const bool down = sell_descending();
     for (int pid = 0; pid < kSellPidSlots - 1 && pid < (single_entry ? 1 : n_proj); ++pid) {
         const int kind = projs[pid].kind;
         if (kind != DL_PROJ_SIMPLEX && kind != DL_PROJ_SIMPLEX_EQ) continue;
         if (projs[pid].flags & DL_PROJ_FLAG_NO_SLICES) continue;
         const unsigned long long* hp = hist + (size_t)pid * kSellBins;
-        double sh = 0.0, lg = (double)nnz[pid * 2 + 1];
-        for (int l = 1; l <= kSellMaxLenLanes; ++l) (l <= max_len ? sh : lg) += (double)l * (double)hp[l];
-        if (sh <= 0.0 || sh < min_share * (sh + lg)) continue;
-        pid_sell[pid] = lanes_on ? 2 : 1;
+        // An entry gets K-lane slices when its columns of 25 .. 255 non-zeros hold at least `lane_share` of its non-zeros: a handle with
+        // such slices runs the second binary of the fused kernel (fused4_kernel.h), and a handful of long columns -- the benchmark's
+        // Poisson(10) columns: one non-zero in 10^4 -- is not worth leaving the first.  Such an entry is sliced whatever the share of its
+        // short columns (its only leftovers are columns no window could hold either); otherwise the share rule of the one-lane slices
+        // applies (min_share < 0: the caller set none -- 0.9).
+        double sh = 0.0, sh_lanes = 0.0, lg = (double)nnz[pid * 2 + 1];
+        for (int l = 1; l <= kSellMaxLenLanes; ++l) (l <= kSellMaxH ? sh : sh_lanes) += (double)l * (double)hp[l];
+        const bool lanes_entry = lanes_on && sh_lanes > 0.0 && sh_lanes >= lane_share * (sh + sh_lanes + lg);
+        if (lanes_entry) sh += sh_lanes;
+        else lg += sh_lanes;
+        const double ms = min_share < 0.0 ? (lanes_entry ? 0.0 : 0.9) : min_share;
+        if (sh <= 0.0 || sh < ms * (sh + lg)) continue;
+        const int n_classes = lanes_entry ? 5 : 1;
+        pid_sell[pid] = lanes_entry ? 2 : 1;
         *n_nnz += (uint64_t)sh;
         // columns of this entry in sorted order: class by class, hist[l] columns of every length l, shortest first (see sell_descending)
         for (int kc = 0; kc < n_classes; ++kc) {
@@ -200,14 +208,14 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     (void)hipFree(stats);
     if (e != hipSuccess) return hip_fail(e, "slice statistics");
     uint64_t n_cols = 0, n_elems = 0, n_nnz = 0, n_lane_cols = 0;
-    // K lanes per column for the columns of 25 .. 255 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0.  With them an entry's only
-    // leftovers are columns no window could hold either, so the share rule has nothing to protect: every simplex entry is sliced
-    // (min_share < 0: the caller did not set one).
+    // K lanes per column for the columns of 25 .. 255 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0, for the entries in which they
+    // hold at least DUALIP_HIP_SELL_LANES_MIN_SHARE (default 1 %) of the non-zeros (sell_plan).
     const char* le = getenv("DUALIP_HIP_SELL_LANES");
     const bool lanes_on = !(le && le[0] == '0');
-    if (min_share < 0.0) min_share = lanes_on ? 0.0 : 0.9;
-    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, lanes_on, pid_sell_out, desc, &n_cols, &n_elems,
-              &n_nnz, &n_lane_cols);
+    double lane_share = 0.01;
+    if (const char* ls = getenv("DUALIP_HIP_SELL_LANES_MIN_SHARE")) lane_share = atof(ls);
+    sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, lanes_on, lane_share, pid_sell_out, desc, &n_cols,
+              &n_elems, &n_nnz, &n_lane_cols);
     if (n_cols == 0 || n_cols >= (1ull << 32) || desc.size() / kSellDescWords >= (1ull << 31)) {
         pid_sell_out.assign(kSellPidSlots, 0);
         desc.clear();
@@ -280,19 +288,32 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
     // table is therefore rotated: the N mod S SHORTEST slices go to the end, everything else keeps its ascending order.  Matters when
     // a wavefront has few rounds (a 12.5M-entity shard of an all-simplex block: 45 rounds, the odd one worth 2.4 of them).  A
     // descriptor is self-contained (base, first column), so the build kernels below do not care about the order.
+    // The slices of K > 1 lanes per column come FIRST in the table, tallest class first: the kernel walks them in their own loop
+    // (sell.h: sell_lanes_loop) ahead of everything else; the one-lane slices follow, and the rotation above applies to THEIR deal.
     std::vector<uint32_t> rotated;
     const uint32_t* desc_up = desc.data();
     {
         const char* te = getenv("DUALIP_HIP_SELL_TAIL");
         const uint64_t S = (uint64_t)(h->n_wg > 0 ? h->n_wg : 1) * (uint64_t)kFusedWaves;
-        const uint64_t r = (uint64_t)n_slices % S;
-        if (!(te && te[0] == '0') && !sell_descending() && r > 0 && (uint64_t)n_slices > S) {
-            rotated.resize(desc.size());
-            const size_t head = (size_t)r * kSellDescWords;
-            std::copy(desc.begin() + head, desc.end(), rotated.begin());
-            std::copy(desc.begin(), desc.begin() + head, rotated.end() - head);
-            desc_up = rotated.data();
+        std::vector<uint32_t> lanes, plain;
+        for (size_t t = 0; t + kSellDescWords <= desc.size(); t += kSellDescWords) {
+            std::vector<uint32_t>& dst = ((desc[t + 2] >> 8) & 7u) ? lanes : plain;
+            dst.insert(dst.end(), desc.begin() + (ptrdiff_t)t, desc.begin() + (ptrdiff_t)(t + kSellDescWords));
         }
+        h->n_sell_lane_slices = (int64_t)(lanes.size() / kSellDescWords);
+        const uint64_t n_plain = plain.size() / kSellDescWords;
+        const uint64_t r = n_plain % S;
+        const bool rotate = !(te && te[0] == '0') && !sell_descending() && r > 0 && n_plain > S;
+        rotated.reserve(desc.size());
+        if (sell_descending()) {
+            rotated.insert(rotated.end(), lanes.begin(), lanes.end());
+        } else {
+            for (size_t t = lanes.size(); t >= (size_t)kSellDescWords; t -= kSellDescWords) rotated.insert(rotated.end(), lanes.begin() + (ptrdiff_t)(t - kSellDescWords), lanes.begin() + (ptrdiff_t)t);
+        }
+        const size_t head = rotate ? (size_t)r * kSellDescWords : 0;
+        rotated.insert(rotated.end(), plain.begin() + (ptrdiff_t)head, plain.end());
+        rotated.insert(rotated.end(), plain.begin(), plain.begin() + (ptrdiff_t)head);
+        desc_up = rotated.data();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h->sell_desc, desc_up, sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, st);
     const unsigned sblocks = (n_slices + 3u) / 4u;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # round-3 GPU session 6: K-lanes-per-column slices -- suite, then HEAD (_ab_head) against the tree on the standard shapes (must not
 # move), on columns of ~40 non-zeros and on the MovieLens-like shape (should)
-cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/s6
-( time timeout 1500 python -m pytest tests -m gpu -x -q --timeout 900 --durations=8 ) > gpurun_out/s6/pytest.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/s6/pytest.log
-tail -30 gpurun_out/s6/pytest.log
+cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/s12
+( time timeout 1500 python -m pytest tests -m gpu -x -q --timeout 900 --durations=8 ) > gpurun_out/s12/pytest.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/s12/pytest.log
+tail -30 gpurun_out/s12/pytest.log
 line() { python -c "
 import sys,json
 for l in sys.stdin:
@@ -15,19 +15,19 @@ for l in sys.stdin:
 for rep in 1 2; do
   for arm in head tree; do
     dir=/root/repo; [ $arm = head ] && dir=/root/repo/_ab_head
-    ( cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-verify --steps 60 --warmup 10 2>/dev/null | line "100m_mixed $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 10000000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_mixed $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 10000000 --proj simplex --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_simplex $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 12500000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "12.5m_mixed $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 1000000 --proj box --no-cpu-baseline --no-verify --steps 400 --warmup 40 2>/dev/null | line "1m_box $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 2500000 --sparsity 0.004 --proj simplex --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | line "2.5m_x40_simplex $arm" ) >> gpurun_out/s6/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 1000000 --sparsity 0.01 --proj simplex --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | line "1m_x100_simplex $arm" ) >> gpurun_out/s6/ab.log
+    ( cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-verify --steps 60 --warmup 10 2>/dev/null | line "100m_mixed $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 10000000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_mixed $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 10000000 --proj simplex --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_simplex $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 12500000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "12.5m_mixed $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 1000000 --proj box --no-cpu-baseline --no-verify --steps 400 --warmup 40 2>/dev/null | line "1m_box $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 2500000 --sparsity 0.004 --proj simplex --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | line "2.5m_x40_simplex $arm" ) >> gpurun_out/s12/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 1000000 --sparsity 0.01 --proj simplex --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | line "1m_x100_simplex $arm" ) >> gpurun_out/s12/ab.log
   done
 done
-sort gpurun_out/s6/ab.log
+sort gpurun_out/s12/ab.log
 cd /tmp
 run() { rm -rf /tmp/pm; (cd $1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -o t -- python benchmark/movielens_like.py --max-iter 300 > /tmp/pm.log 2>&1); f=$(find /tmp/pm -name "*kernel_stats.csv" | head -1); python3 -c "
 import csv,sys
 r=[x for x in csv.DictReader(open('$f')) if 'matching_fused' in x['Name']][0]
 print('movielens_like $1', '::', 'avg us', round(float(r['AverageNs'])/1e3,1), 'min', round(float(r['MinNs'])/1e3,1), 'max', round(float(r['MaxNs'])/1e3,1))"; tail -3 /tmp/pm.log; }
-( for rep in 1 2; do run /root/repo/_ab_head; run /root/repo; done ) 2>&1 | tee /root/repo/gpurun_out/s6/ml.log
+( for rep in 1 2; do run /root/repo/_ab_head; run /root/repo; done ) 2>&1 | tee /root/repo/gpurun_out/s12/ml.log

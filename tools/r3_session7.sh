@@ -1,0 +1,29 @@
+#!/bin/bash
+# round-3 GPU session 7/8: lane slices in their own loop ahead of the other phases; arms: HEAD copy, tree, tree with DUALIP_HIP_SELL_LANES=0
+cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/s9
+line() { python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; a=d['aux']; la=a.get('late') or {}; w=a.get('whole_solve') or {}; lay=a['layout']
+        print('$1', 'ms/step %.4f kernel %.4f phys %.3f | late %.4f kernel %.4f | whole it/s %.1f | slices %d lane cols %s long %d tiles %d' % (d['ms_per_step'], r['kernel_avg_ms'], r.get('frac',0), la.get('ms_per_step',0), la.get('kernel_avg_ms',0), w.get('iterations_per_s',0), lay.get('slices',0), lay.get('slice_lane_columns'), lay.get('long_columns',0), lay.get('tiles',0)))
+"; }
+for rep in 1 2; do
+  for arm in head tree tree_nolanes; do
+    dir=/root/repo; [ $arm = head ] && dir=/root/repo/_ab_head
+    ln=1; [ $arm = tree_nolanes ] && ln=0
+    ( cd $dir && DUALIP_HIP_SELL_LANES=$ln timeout 600 python bench.py --entities 10000000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_mixed $arm" ) >> gpurun_out/s9/ab.log
+    ( cd $dir && DUALIP_HIP_SELL_LANES=$ln timeout 600 python bench.py --entities 10000000 --proj simplex --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_simplex $arm" ) >> gpurun_out/s9/ab.log
+    ( cd $dir && DUALIP_HIP_SELL_LANES=$ln timeout 600 python bench.py --entities 12500000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "12.5m_mixed $arm" ) >> gpurun_out/s9/ab.log
+    ( cd $dir && DUALIP_HIP_SELL_LANES=$ln timeout 600 python bench.py --no-cpu-baseline --no-verify --steps 60 --warmup 10 2>/dev/null | line "100m_mixed $arm" ) >> gpurun_out/s9/ab.log
+    ( cd $dir && DUALIP_HIP_SELL_LANES=$ln timeout 600 python bench.py --entities 2500000 --sparsity 0.004 --proj simplex --no-cpu-baseline --no-verify --steps 100 --warmup 10 2>/dev/null | line "2.5m_x40_simplex $arm" ) >> gpurun_out/s9/ab.log
+  done
+done
+sort gpurun_out/s9/ab.log
+timeout 600 python -m pytest tests/test_gpu_sell.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+cd /tmp
+run() { rm -rf /tmp/pm; (cd $1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -o t -- python benchmark/movielens_like.py --max-iter 300 > /tmp/pm.log 2>&1); f=$(find /tmp/pm -name "*kernel_stats.csv" | head -1); python3 -c "
+import csv,sys
+r=[x for x in csv.DictReader(open('$f')) if 'matching_fused' in x['Name']][0]
+print('movielens_like $1', '::', 'avg us', round(float(r['AverageNs'])/1e3,1), 'min', round(float(r['MinNs'])/1e3,1), 'max', round(float(r['MaxNs'])/1e3,1))"; }
+( for rep in 1 2 3; do run /root/repo/_ab_head; run /root/repo; done ) 2>&1 | grep movielens_like | tee /root/repo/gpurun_out/s9/ml.log
