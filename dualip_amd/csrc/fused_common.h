@@ -204,7 +204,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
     auto all_sum = [&](double x) -> double {
-        x = wave_allreduce(x, OpAdd());
+        x = wave_allreduce_dpp(x, OpAdd());
         if constexpr (WG) {
             __syncthreads();  // the previous reduction's readers are done
             if ((lane & 63) == 0) red[lane >> 6] = x;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
         return x;
     };
     auto all_max = [&](double x) -> double {
-        x = wave_allreduce(x, OpMax());
+        x = wave_allreduce_dpp(x, OpMax());
         if constexpr (WG) {
             __syncthreads();
             if ((lane & 63) == 0) red[lane >> 6] = x;
@@ -296,8 +296,8 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             S = (T)all_sum((double)S);
             v1 = (T)all_max((double)v1);
         } else {
-            S = wave_allreduce(S, OpAdd());
-            v1 = wave_allreduce(v1, OpMax());
+            S = wave_allreduce_dpp(S, OpAdd());
+            v1 = wave_allreduce_dpp(v1, OpMax());
         }
         projected = (pj.kind == DL_PROJ_SIMPLEX_EQ) || S > pj.ztol;
         const bool padded = eq_row && pj.kind == DL_PROJ_SIMPLEX_EQ && S < pj.z;
@@ -337,8 +337,8 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
                     sumA = (T)all_sum((double)sumA);
                     cntw = (long long)all_sum((double)cntl);
                 } else {
-                    sumA = wave_allreduce(sumA, OpAdd());
-                    cntw = (long long)wave_allreduce((double)cntl, OpAdd());
+                    sumA = wave_allreduce_dpp(sumA, OpAdd());
+                    cntw = (long long)wave_allreduce_dpp((uint32_t)cntl, OpAdd());  // (a lane counts at most the column's strides: 32 bits)
                 }
                 if (it == 0 && cntw == 1) {
                     onehot = true;

@@ -42,7 +42,6 @@ __host__ __device__ inline int sell_lanes_log(int len) { return len <= kSellMaxH
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov0_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
-constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
 // all-reduce over the 2^KLOG adjacent lanes of a column; commutative steps, so every lane of the group ends with identical bits
 template <int KLOG, class T>
 __device__ __forceinline__ T group_sum(T x) {

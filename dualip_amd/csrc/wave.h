@@ -61,6 +61,7 @@ __device__ __forceinline__ long long bperm(int src_lane, long long x) {
     return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
 }
 
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;  // butterflies inside a row of 16
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
@@ -157,6 +158,33 @@ __device__ __forceinline__ T wave_allreduce(T x, Op op) {
         x = op(x, t);
     }
     return x;
+}
+
+// The same on the DPP unit: a butterfly inside every row of 16 lanes (quad_perm xor 1, xor 2, half-row mirror, row mirror -- every
+// lane has a valid source, commutative steps, so all 16 end with identical bits), then the four row results are read into scalar
+// registers and combined in one fixed order.  ~12 vector instructions against six ds_bpermute round trips: the single-column
+// walker's Newton passes are two such reductions each and nothing else of substance (round 3).
+__device__ __forceinline__ float readlane_t(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double readlane_t(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ uint32_t readlane_t(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov0_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_any(float x) { return dpp_mov0<CTRL, 0xf>(x); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_any(double x) { return dpp_mov0<CTRL, 0xf>(x); }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_any(uint32_t x) { return dpp_mov0_u<CTRL>(x); }
+template <class T, class Op>
+__device__ __forceinline__ T wave_allreduce_dpp(T x, Op op) {
+    x = op(x, dpp_any<DPP_QUAD_XOR1>(x));
+    x = op(x, dpp_any<DPP_QUAD_XOR2>(x));
+    x = op(x, dpp_any<DPP_ROW_HALF_MIRROR>(x));
+    x = op(x, dpp_any<DPP_ROW_MIRROR>(x));
+    const T r0 = readlane_t(x, 0), r1 = readlane_t(x, 16), r2 = readlane_t(x, 32), r3 = readlane_t(x, 48);
+    return op(op(op(r0, r1), r2), r3);
 }
 
 }  // namespace dl
