@@ -139,6 +139,7 @@ static void matching_free(dl_matching* h) {
     if (h->cold_grad) (void)hipFree(h->cold_grad);
     if (h->bal) (void)hipFree(h->bal);
     if (h->bal_stamps) (void)hipFree(h->bal_stamps);
+    if (h->sell_lane_begin) (void)hipFree(h->sell_lane_begin);
     for (void* p : {(void*)h->sell_desc, (void*)h->sell_len, (void*)h->sell_colstart, h->sell_a, h->sell_c, h->sell_r, h->sell_f})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_start) (void)hipEventDestroy(e);
@@ -572,6 +573,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         for (size_t t = 0; t < tile_pid4.size(); ++t) {
             const bool is_long = (words4[t * 12 + 1] & (1u << 19)) != 0;
             const uint64_t len = ((uint64_t)words4[t * 12 + 3] << 32) | words4[t * 12 + 2];
+            if (is_long && len <= xlong_min) h->long_nnz += (int64_t)len;  // non-zeros walked one wavefront per column
             std::vector<uint32_t>& wv = !is_long ? short_words : (len > xlong_min ? xlong_words : long_words);
             std::vector<uint32_t>& pv = !is_long ? short_pid : (len > xlong_min ? xlong_pid : long_pid);
             wv.insert(wv.end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
@@ -579,14 +581,18 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         }
         // longest first, dealt in snake order (wavefront W takes slots W, W + S, ...: reversing every other round pairs the
         // longest columns with the shortest ones); the workgroup-walked ones likewise over the workgroups
-        auto snake = [](std::vector<uint32_t>& wv, std::vector<uint32_t>& pv, size_t width) {
+        // (handles of the fused kernel's second binary -- K-lane slices, or >= 1 % of the non-zeros in single-column tiles; same rule
+        //  as matching_kernels.hip: wants_lanes_binary -- deal these tiles to the wavefronts of a workgroup dynamically: plain descending order)
+        bool lanes_binary = h->long_nnz > 0 && h->long_nnz * 100 >= nnz;
+        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !lanes_binary; t += 4) lanes_binary = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
+        auto snake = [lanes_binary](std::vector<uint32_t>& wv, std::vector<uint32_t>& pv, size_t width) {
             const size_t nt = pv.size();
             if (nt < 2 || width == 0) return;
             std::vector<size_t> order(nt);
             for (size_t i = 0; i < nt; ++i) order[i] = i;
             auto len_of = [&](size_t t) { return ((uint64_t)wv[t * 12 + 3] << 32) | wv[t * 12 + 2]; };
             std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return len_of(x) > len_of(y); });
-            for (size_t r0 = width; r0 < nt; r0 += 2 * width) std::reverse(order.begin() + (ptrdiff_t)r0, order.begin() + (ptrdiff_t)std::min(r0 + width, nt));
+            for (size_t r0 = width; r0 < nt && !lanes_binary; r0 += 2 * width) std::reverse(order.begin() + (ptrdiff_t)r0, order.begin() + (ptrdiff_t)std::min(r0 + width, nt));
             std::vector<uint32_t> w2(wv.size()), p2(nt);
             for (size_t i = 0; i < nt; ++i) {
                 std::copy(wv.begin() + (ptrdiff_t)(order[i] * 12), wv.begin() + (ptrdiff_t)(order[i] * 12 + 12), w2.begin() + (ptrdiff_t)(i * 12));
@@ -600,6 +606,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             snake(xlong_words, xlong_pid, (size_t)h->n_wg);
         }
         h->n_xlong = (int64_t)xlong_pid.size();
+        // what the workgroup-walked columns cost their workgroups, in slice slots (calibrated on the MovieLens-shaped problem: 13 us per
+        // ~1800 non-zeros against 0.72 us of workgroup time per 900-slot slice): the K-lane slices are dealt around it (sell_build.hip)
+        h->wg_preload.assign((size_t)(h->n_wg > 0 ? h->n_wg : 1), 0);
+        for (size_t t = 0; t < xlong_pid.size() && h->n_wg > 0; ++t)
+            h->wg_preload[t % (size_t)h->n_wg] += 9ull * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]);
         long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
         long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
         if (!dev_pack && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);

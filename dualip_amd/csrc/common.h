@@ -130,6 +130,9 @@ struct dl_matching {
     // column-per-lane slices (sell.h): short columns of simplex entries, sorted by length, 64 per slice, transposed copies of
     // their values and row indices owned by the handle
     int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0, n_sell_nnz = 0;  // slices, their columns, slots (with padding), non-zeros
+    std::vector<uint64_t> wg_preload;  // per workgroup: cost (in slice slots) of the whole-workgroup columns it walks first
+    uint32_t* sell_lane_begin = nullptr;  // owned: [n_wg + 1] ranges of the K-lane slice table, one per workgroup
+    int64_t long_nnz = 0;             // non-zeros in single-column tiles walked by one wavefront each
     int64_t n_sell_lane_slices = 0;   // slices with K > 1 lanes per column: the FIRST n of sell_desc (walked by their own loop)
     int64_t n_sell_lane_cols = 0;     // columns dealt to K > 1 lanes each (25 .. 255 non-zeros; sell.h)
     int64_t n_sell_mixed_cols = 0;    // columns of slices that hold more than one length (the only ones whose length bytes are read)

@@ -162,7 +162,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     // are older than the prologue's, so waiting for lambda does not wait for tile data)
     if (!sell_first) open_windows();
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
-    stamp(g, wg, tid, 1);
+    // (developer aid, second binary only: DUALIP_HIP_ABLATE = 4096 / 8192 / 12288 moves stamp 1 behind the workgroup-walked columns /
+    //  the single-column tiles / the K-lane slices -- with a workgroup barrier, so it is the slowest wavefront's time)
+    const int stamp_at = LANES ? ((g.ablate >> 12) & 3) : 0;
+    if (stamp_at == 0) stamp(g, wg, tid, 1);
     unsigned long long* bst = kernarg_args(g).bal_stamps;
     if (bst && tid == 0) bst[4 * (size_t)wg] = wall_clock64();
     const T s = w.s;
@@ -187,26 +190,105 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
     }
+    if constexpr (LANES) {
+        if (stamp_at == 1 && kernarg_args(g).timeline) {
+            __syncthreads();
+            stamp(g, wg, tid, 1);
+        }
+    }
     // (slot -> wavefront TRANSPOSED: slot q of a round goes to wavefront q / G of workgroup q mod G.  The tiles are listed longest
     //  first: the G longest then sit on G different CUs instead of sixteen to a CU, and a handful of them no longer all land on
     //  workgroup 0)
     //  (... counted from the LAST wavefront of a workgroup down: wavefront 0's stamps feed the balance of the window tiles)
-    for (uint32_t lt = (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + (uint32_t)wg; lt < g.n_long; lt += S) {
+    auto walk_long = [&](uint32_t dvl) __attribute__((always_inline)) {
         const FusedArgs<T>& gk = kernarg_args(g);
-        const uint32_t dvl = byte_offset(gk.long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0];
         const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
         const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
         const uint64_t k0 = (((uint64_t)w0hi << 32) | w0lo) & ((1ull << 40) - 1);
         const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
         const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
+        if constexpr (LANES) {
+            // a simplex column of up to 1024 non-zeros as ONE slice of one column, read in place (sell.h, KLOG = 6): every load in
+            // flight at once, the values kept in registers, straight-line passes, reductions on the DPP unit
+            if (is_simplex_kind(pl.kind) && len <= 1024 && !(gk.ablate & 1024)) {
+                const int L = (int)len, H = (L + 63) >> 6, Hmin = L >> 6;
+                const int len_lane = (L - lane + 63) >> 6;
+                constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
+                switch ((H + 3) >> 2) {
+                    case 1: sell_slice<T, RowT, 4, (4 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
+                    case 2: sell_slice<T, RowT, 8, (8 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
+                    case 3: sell_slice<T, RowT, 12, (12 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
+                    default: sell_slice<T, RowT, 16, (16 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
+                }
+                return;
+            }
+        }
         double ol = 0.0, ql = 0.0;
         process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
                                             FAIR ? &fair : nullptr);
         fx_add_wide(acc, ol, ql, w.scale2);
+    };
+    // The second binary deals single-column tiles and K-lane slices to WORKGROUPS statically (workgroup w owns slots w, w + G, ...
+    // of a list in descending cost) and to the wavefronts of a workgroup DYNAMICALLY: a wavefront claims its workgroup's next slot
+    // from a counter in LDS (one ds_add per tile, against 5-15 us of work per tile).  With two to four such tiles per wavefront a
+    // static deal left one wavefront in sixteen a whole tile behind the others (MovieLens-shaped problem: workgroups busy 68 us on
+    // average, the launch 101).  wg_ctr: two words at the end of the reduction scratch nothing else uses.
+    uint32_t* wg_ctr = reinterpret_cast<uint32_t*>(w.red_s + 56);
+    // (with the fairness stream the deal stays static -- wavefront v takes its workgroup's slots v, v + 16, ...: that stream's sum
+    //  f.x is a per-wavefront double, and a deal that follows the timing would put the timing into its last bits)
+    uint32_t static_next = (uint32_t)wave;
+    auto claim = [&](uint32_t* ctr) -> uint32_t {
+        if constexpr (FAIR) {
+            const uint32_t v = static_next;
+            static_next += (uint32_t)kFusedWaves;
+            return v;
+        } else {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(ctr, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        }
+    };
+    if constexpr (LANES) {
+        if (tid == 0) {
+            wg_ctr[0] = 0u;
+            wg_ctr[1] = 0u;
+        }
+        __syncthreads();
+        const uint32_t n_long = g.n_long, G = gridDim.x;
+        auto desc_of = [&](uint32_t j) -> uint32_t {
+            const uint64_t q = (uint64_t)j * G + (uint32_t)wg;
+            return byte_offset(kernarg_args(g).long32 + (size_t)(q < n_long ? q : (n_long ? n_long - 1u : 0u)) * kDesc4Words, dlane * 4u)[0];
+        };
+        if (n_long) {
+            uint32_t j = claim(&wg_ctr[0]);
+            uint32_t dvl = desc_of(j);
+            while ((uint64_t)j * G + (uint32_t)wg < n_long) {
+                const uint32_t jn = claim(&wg_ctr[0]);
+                const uint32_t dvn = desc_of(jn);  // (travels while the current column is walked)
+                walk_long(dvl);
+                j = jn;
+                dvl = dvn;
+            }
+        }
+    } else {
+        for (uint32_t lt = (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + (uint32_t)wg; lt < g.n_long; lt += S)
+            walk_long(byte_offset(kernarg_args(g).long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0]);
     }
     // the slices of the long columns (K lanes per column), every wavefront, ahead of everything cheap (sell.h)
     // (dealt like the single-column tiles above: one per workgroup before any workgroup gets a second)
-    if constexpr (LANES) sell_lanes_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + (uint32_t)wg, S, lane, sd, acc, fair);
+    if constexpr (LANES) {
+        if (stamp_at == 2 && kernarg_args(g).timeline) {
+            __syncthreads();
+            stamp(g, wg, tid, 1);
+        }
+    }
+    if constexpr (LANES) sell_lanes_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg, (uint32_t)gridDim.x, &wg_ctr[1], wave, lane, sd, acc, fair);
+    if constexpr (LANES) {
+        if (stamp_at == 3 && kernarg_args(g).timeline) {
+            __syncthreads();
+            stamp(g, wg, tid, 1);
+        }
+    }
     // One schedule step: `cur` holds the tile whose loads were issued a step ago; the next tile's loads go into `nxt`.
     // The loop below alternates the two register sets explicitly -- a rotating copy of freshly loaded registers would
     // force a full memory wait at the end of every step.
@@ -306,7 +388,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         if (bst && tid == 0) bst[4 * (size_t)wg + 1] = wall_clock64();
     }
     {
-        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, acc, fair);
+        // (second binary: its handles may have few one-lane slices -- one per workgroup before any workgroup gets a second)
+        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, LANES ? (uint32_t)wave * (uint32_t)gridDim.x + (uint32_t)wg : (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, acc, fair);
     }
     if (sell_first) {
         open_windows();

@@ -60,6 +60,7 @@ struct FusedArgs {
     uint32_t n_sell;               // one-lane-per-column slices (sell_desc)
     const uint32_t* sell_lane_desc;  // slices with K = 2 .. 16 lanes per column (sell.h: sell_lanes_loop), their own table ...
     uint32_t n_sell_lanes;           // ... and count (cold: read from the kernel arguments)
+    const uint32_t* sell_lane_begin; // [workgroups + 1]: workgroup w walks table entries sell_lane_begin[w] .. sell_lane_begin[w + 1]
     // the previous iteration's optimiser step, applied in this launch's prologue (agd_step.h): do_apply != 0 => `lambda` is not read,
     // every workgroup forms the new iterate from apply.{x, g_new, y} and stages THAT; workgroup 0 also stores it (and the state / log)
     int do_apply;
@@ -552,8 +553,13 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
         }
     }
     if constexpr (GRAD_LDS) {
-        long long* slab = g.partial + (int64_t)wg * g.mpad;
-        const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;
+        // (the slab's address is formed from the kernel arguments RE-READ here, not from values carried in scalar registers since the
+        //  kernel's first instructions: one build of the double-precision second binary carried the 64-bit row stride through an SGPR
+        //  spill whose high half the compiler had meanwhile reused for gridDim.x -- the stride came back as 157 * 2^32 + 320 and the flush
+        //  faulted; found with rocgdb's precise memory mode, tools/gdb_fault.sh)
+        const FusedArgs<T>& gk = kernarg_args(g);
+        long long* slab = gk.partial + (int64_t)wg * gk.mpad;
+        const int64_t m_lds = gk.m_hot > 0 ? gk.m_hot : gk.m;
         for (int64_t i = tid; i < m_lds; i += kFusedThreads) slab[i] = w.grad_s[i];
     }
 }

@@ -411,11 +411,18 @@ int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStr
 int launch_fused4_f64(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
 int launch_fused4_f32_lanes(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4_lanes.hip: + the K-lanes-per-column slices
 int launch_fused4_f64_lanes(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
+// the second binary: handles with K-lane slices, or with >= 1 % of their non-zeros in single-column tiles (which it walks as
+// one-column slices, sell.h) -- the benchmark's shapes have neither
+static bool wants_lanes_binary(const dl_matching* h) {
+    if (h->n_sell_lane_slices > 0) return true;  // (only the second binary walks them)
+    if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) return e[0] == '1';  // testing: either binary on any handle without K-lane slices
+    return h->long_nnz > 0 && h->long_nnz * 100 >= h->nnz;
+}
 static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {
-    return h->n_sell_lane_slices > 0 ? launch_fused4_f32_lanes(h, args, st) : launch_fused4_f32(h, args, st);
+    return wants_lanes_binary(h) ? launch_fused4_f32_lanes(h, args, st) : launch_fused4_f32(h, args, st);
 }
 static int launch_fused4(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) {
-    return h->n_sell_lane_slices > 0 ? launch_fused4_f64_lanes(h, args, st) : launch_fused4_f64(h, args, st);
+    return wants_lanes_binary(h) ? launch_fused4_f64_lanes(h, args, st) : launch_fused4_f64(h, args, st);
 }
 
 template <class T>
@@ -634,6 +641,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.sell_desc = h->sell_desc ? h->sell_desc + (size_t)h->n_sell_lane_slices * 4 : nullptr;  // (the one-lane slices follow the K-lane ones in the table)
     args.sell_lane_desc = h->sell_desc;
     args.n_sell_lanes = (uint32_t)h->n_sell_lane_slices;
+    args.sell_lane_begin = h->sell_lane_begin;
     args.sell_len = h->sell_len;
     args.sell_colstart = h->sell_colstart;
     args.sell_a = static_cast<const T*>(h->sell_a);

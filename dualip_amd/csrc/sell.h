@@ -43,8 +43,13 @@ __host__ __device__ inline int sell_lanes_log(int len) { return len <= kSellMaxH
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov0_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 // all-reduce over the 2^KLOG adjacent lanes of a column; commutative steps, so every lane of the group ends with identical bits
+struct OpMaxNonNegT {
+    template <class T>
+    __device__ __forceinline__ T operator()(T a, T b) const { return max_nonneg(a, b); }
+};
 template <int KLOG, class T>
 __device__ __forceinline__ T group_sum(T x) {
+    if constexpr (KLOG == 6) return wave_allreduce_dpp(x, OpAdd());  // one column per wavefront
     if constexpr (KLOG >= 1) x = (T)(x + dpp_mov0<DPP_QUAD_XOR1, 0xf>(x));
     if constexpr (KLOG >= 2) x = (T)(x + dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
     if constexpr (KLOG >= 3) x = (T)(x + dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
@@ -53,6 +58,7 @@ __device__ __forceinline__ T group_sum(T x) {
 }
 template <int KLOG>
 __device__ __forceinline__ uint32_t group_sum_u32(uint32_t x) {
+    if constexpr (KLOG == 6) return wave_allreduce_dpp(x, OpAdd());
     if constexpr (KLOG >= 1) x += dpp_mov0_u32<DPP_QUAD_XOR1>(x);
     if constexpr (KLOG >= 2) x += dpp_mov0_u32<DPP_QUAD_XOR2>(x);
     if constexpr (KLOG >= 3) x += dpp_mov0_u32<DPP_ROW_HALF_MIRROR>(x);
@@ -61,6 +67,7 @@ __device__ __forceinline__ uint32_t group_sum_u32(uint32_t x) {
 }
 template <int KLOG, class T>
 __device__ __forceinline__ T group_max_nonneg(T x) {
+    if constexpr (KLOG == 6) return wave_allreduce_dpp(x, OpMaxNonNegT());
     if constexpr (KLOG >= 1) x = max_nonneg(x, dpp_mov0<DPP_QUAD_XOR1, 0xf>(x));
     if constexpr (KLOG >= 2) x = max_nonneg(x, dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
     if constexpr (KLOG >= 3) x = max_nonneg(x, dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
@@ -72,15 +79,31 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds
 // (KLOG = 0: the same), `Hmin` the least len_lane of the slice.
+// KLOG = 6: ONE column per wavefront, read IN PLACE from the caller's arrays -- element e of a column at lane e mod 64, step e / 64 is
+// the CSC order itself, so `base` is the column's offset in g.a / g.c / g.rowidx and nothing is copied: the single-column tiles of up
+// to 64 HM non-zeros walked as one slice (all loads in flight at once, values kept in registers, straight-line passes) instead of by
+// process_long_tile's batched loops.
 template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR, int KLOG = 0>
 __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, int len_lane,
                                            uint64_t dense, bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
     const T s = w.s;
     // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
-    const T* __restrict__ pa = byte_offset(g.sell_a + base, (uint32_t)lane * (uint32_t)sizeof(T));
-    const T* __restrict__ pc = byte_offset(g.sell_c + base, (uint32_t)lane * (uint32_t)sizeof(T));
-    const RowT* __restrict__ pr = byte_offset(reinterpret_cast<const RowT*>(g.sell_r) + base, (uint32_t)lane * (uint32_t)sizeof(RowT));
-    const T* __restrict__ pf = FAIR ? byte_offset(g.sell_f + base, (uint32_t)lane * (uint32_t)sizeof(T)) : nullptr;
+    constexpr bool ORIG = KLOG == 6;
+    const T* __restrict__ pa = byte_offset((ORIG ? g.a : g.sell_a) + base, (uint32_t)lane * (uint32_t)sizeof(T));
+    const T* __restrict__ pc = byte_offset((ORIG ? g.c : g.sell_c) + base, (uint32_t)lane * (uint32_t)sizeof(T));
+    const RowT* __restrict__ pr = byte_offset(reinterpret_cast<const RowT*>(ORIG ? g.rowidx : g.sell_r) + base, (uint32_t)lane * (uint32_t)sizeof(RowT));
+    const T* __restrict__ pf = FAIR ? byte_offset((ORIG ? g.fair : g.sell_f) + base, (uint32_t)lane * (uint32_t)sizeof(T)) : nullptr;
+    // ORIG: the column's last, partly filled step must not read past the column (it may end the arrays): its lanes beyond the end
+    // re-read the column's last element, and their values are dropped below
+    const int lane_t = (ORIG && (len & 63)) ? (lane < (len & 63) ? lane : (len & 63) - 1) : lane;
+    const T* __restrict__ pa_t = ORIG ? byte_offset(g.a + base, (uint32_t)lane_t * (uint32_t)sizeof(T)) : pa;
+    const T* __restrict__ pc_t = ORIG ? byte_offset(g.c + base, (uint32_t)lane_t * (uint32_t)sizeof(T)) : pc;
+    const RowT* __restrict__ pr_t = ORIG ? byte_offset(reinterpret_cast<const RowT*>(g.rowidx) + base, (uint32_t)lane_t * (uint32_t)sizeof(RowT)) : pr;
+    const T* __restrict__ pf_t = (ORIG && FAIR) ? byte_offset(g.fair + base, (uint32_t)lane_t * (uint32_t)sizeof(T)) : pf;
+    auto PA = [&](int t) { return ((ORIG && t >= Hmin) ? pa_t : pa) + 64 * t; };
+    auto PC = [&](int t) { return ((ORIG && t >= Hmin) ? pc_t : pc) + 64 * t; };
+    auto PR = [&](int t) { return ((ORIG && t >= Hmin) ? pr_t : pr) + 64 * t; };
+    auto PF = [&](int t) { return ((ORIG && t >= Hmin) ? pf_t : pf) + 64 * t; };
     constexpr int KEEP = RELOAD ? 1 : HM;
     constexpr int CH = 4;  // steps per batch of the RELOAD variants (loads of a batch are in flight together)
     T a[KEEP], c[KEEP], f[FAIR ? KEEP : 1], u[HM];
@@ -95,10 +118,10 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             if (t < H) {  // wave-uniform
-                a[t] = __builtin_nontemporal_load(pa + 64 * t);
-                c[t] = __builtin_nontemporal_load(pc + 64 * t);
-                r[t] = (uint32_t)__builtin_nontemporal_load(pr + 64 * t);
-                if constexpr (FAIR) f[t] = __builtin_nontemporal_load(pf + 64 * t);
+                a[t] = __builtin_nontemporal_load(PA(t));
+                c[t] = __builtin_nontemporal_load(PC(t));
+                r[t] = (uint32_t)__builtin_nontemporal_load(PR(t));
+                if constexpr (FAIR) f[t] = __builtin_nontemporal_load(PF(t));
             } else {
                 a[t] = (T)0;
                 c[t] = (T)0;
@@ -111,6 +134,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             T v = (T)((T)(a[t] * lam_of(r[t])) + (T)(s * c[t]));
             if constexpr (FAIR) v = (T)(v + (T)(sd * f[t]));
             u[t] = relu_finite(v);
+            if constexpr (ORIG) u[t] = (t < Hmin || t < len_lane) ? u[t] : (T)0;
         }
     } else {
 #pragma unroll
@@ -121,10 +145,10 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             for (int q = 0; q < CH; ++q) {
                 const int t = t0 + q;
                 if (t < H) {
-                    a8[q] = pa[64 * t];  // (cached loads: the second pass re-reads them)
-                    c8[q] = pc[64 * t];
-                    r8[q] = (uint32_t)pr[64 * t];
-                    if constexpr (FAIR) f8[q] = pf[64 * t];
+                    a8[q] = *PA(t);  // (cached loads: the second pass re-reads them)
+                    c8[q] = *PC(t);
+                    r8[q] = (uint32_t)*PR(t);
+                    if constexpr (FAIR) f8[q] = *PF(t);
                 } else {
                     a8[q] = (T)0;
                     c8[q] = (T)0;
@@ -137,6 +161,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                 T v = (T)((T)(a8[q] * lam_of(r8[q])) + (T)(s * c8[q]));
                 if constexpr (FAIR) v = (T)(v + (T)(sd * f8[q]));
                 u[t0 + q] = relu_finite(v);
+                if constexpr (ORIG) u[t0 + q] = (t0 + q < Hmin || t0 + q < len_lane) ? u[t0 + q] : (T)0;
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: hoisting every chunk's loads would cost the registers this variant exists to save
         }
@@ -235,7 +260,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     const FusedArgs<T>& gk = kernarg_args(g);
     T* xo = gk.x_out;
     uint64_t k0 = 0;
-    if (xo && has_col) k0 = gk.sell_colstart[dense] + (uint64_t)(lane & ((1 << KLOG) - 1));  // this lane's first element of the column
+    if (xo && has_col) k0 = (ORIG ? base : gk.sell_colstart[dense]) + (uint64_t)(lane & ((1 << KLOG) - 1));  // this lane's first element of the column
     if constexpr (!RELOAD) {
         // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
         //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)
@@ -253,10 +278,10 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             for (int q = 0; q < CH; ++q) {
                 const int t = t0 + q;
                 if (t < H) {
-                    a8[q] = __builtin_nontemporal_load(pa + 64 * t);
-                    c8[q] = __builtin_nontemporal_load(pc + 64 * t);
-                    r8[q] = (uint32_t)__builtin_nontemporal_load(pr + 64 * t);
-                    if constexpr (FAIR) f8[q] = __builtin_nontemporal_load(pf + 64 * t);
+                    a8[q] = __builtin_nontemporal_load(PA(t));
+                    c8[q] = __builtin_nontemporal_load(PC(t));
+                    r8[q] = (uint32_t)__builtin_nontemporal_load(PR(t));
+                    if constexpr (FAIR) f8[q] = __builtin_nontemporal_load(PF(t));
                 } else {
                     a8[q] = (T)0;
                     c8[q] = (T)0;
@@ -345,20 +370,39 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
 // enough to cost the benchmark's shapes 6 % at 10M entities (same box, DUALIP_HIP_SELL_LANES=0 on the same binary no faster: the code,
 // not the slices).  Heights are 9 .. 16 by construction (sell_lanes_log): two variants per K.
 template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
-__device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, FxAcc& acc, double& fair) {
-    const uint32_t n_sell = kernarg_args(g).n_sell_lanes;
-    if (q0 >= n_sell) return;
+__device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t wg, uint32_t G, uint32_t* ctr, int wave, int lane, T sd, FxAcc& acc, double& fair) {
+    // workgroup wg owns the table entries sell_lane_begin[wg] .. sell_lane_begin[wg + 1] (dealt by cost on the host, sell_build.hip, in
+    // descending cost); its wavefronts claim them one at a time from `ctr` (LDS)
+    if (kernarg_args(g).n_sell_lanes == 0u) return;
     const uint32_t* __restrict__ table = kernarg_args(g).sell_lane_desc;
+    const uint32_t first = kernarg_args(g).sell_lane_begin[wg], n_sell = kernarg_args(g).sell_lane_begin[wg + 1u];
+    if (first >= n_sell) return;
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
-    auto load_desc = [&](uint32_t q) -> uint32_t {
-        const uint32_t t = q < n_sell ? q : n_sell - 1u;
-        return byte_offset(table + (size_t)t * kSellDescWords, dlane * 4u)[0];
+    auto slot = [&](uint32_t j) -> uint64_t { return (uint64_t)first + j; };
+    auto load_desc = [&](uint32_t j) -> uint32_t {
+        const uint64_t q = slot(j);
+        return byte_offset(table + (size_t)(q < n_sell ? q : n_sell - 1u) * kSellDescWords, dlane * 4u)[0];
+    };
+    uint32_t static_next = (uint32_t)wave;  // (fairness stream: static deal, see fused4_kernel.h)
+    auto claim = [&]() -> uint32_t {
+        if constexpr (FAIR) {
+            const uint32_t v = static_next;
+            static_next += (uint32_t)kFusedWaves;
+            return v;
+        } else {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(ctr, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        }
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
-    uint32_t dv = load_desc(q0);
-    for (uint32_t q = q0; q < n_sell; q += S) {
+    uint32_t j = claim();
+    uint32_t dv = load_desc(j);
+    while (slot(j) < n_sell) {
+        const uint32_t jn = claim();
         const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), w2 = rl(dv, 2), dense0 = rl(dv, 3);
-        dv = load_desc(q + S);
+        dv = load_desc(jn);
+        j = jn;
         const uint32_t pid = w2 & 0xFFu;
         const int klog = (int)((w2 >> 8) & 7u);  // lanes per column = 1 << klog (wave-uniform)
         const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;

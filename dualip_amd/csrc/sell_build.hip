@@ -3,6 +3,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <functional>
+#include <queue>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -305,10 +307,47 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
         const uint64_t r = n_plain % S;
         const bool rotate = !(te && te[0] == '0') && !sell_descending() && r > 0 && n_plain > S;
         rotated.reserve(desc.size());
-        if (sell_descending()) {
-            rotated.insert(rotated.end(), lanes.begin(), lanes.end());
-        } else {
-            for (size_t t = lanes.size(); t >= (size_t)kSellDescWords; t -= kSellDescWords) rotated.insert(rotated.end(), lanes.begin() + (ptrdiff_t)(t - kSellDescWords), lanes.begin() + (ptrdiff_t)t);
+        // K-lane slices: descending cost (tallest class first), then dealt to the WORKGROUPS longest-processing-time first -- each to the
+        // workgroup with the least work so far, which starts at what its whole-workgroup columns cost (h->wg_preload) -- and listed
+        // workgroup by workgroup; sell_lane_begin[w .. w + 1] is workgroup w's range, whose wavefronts claim from it dynamically.
+        if (!sell_descending()) {
+            std::vector<uint32_t> rev;
+            rev.reserve(lanes.size());
+            for (size_t t = lanes.size(); t >= (size_t)kSellDescWords; t -= kSellDescWords) rev.insert(rev.end(), lanes.begin() + (ptrdiff_t)(t - kSellDescWords), lanes.begin() + (ptrdiff_t)t);
+            lanes.swap(rev);
+        }
+        const size_t G = (size_t)(h->n_wg > 0 ? h->n_wg : 1);
+        std::vector<uint32_t> lane_begin(G + 1, 0);
+        if (!lanes.empty()) {
+            typedef std::pair<uint64_t, uint32_t> Load;  // (work so far, workgroup)
+            std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+            for (size_t wgi = 0; wgi < G; ++wgi) heap.push(Load(wgi < h->wg_preload.size() ? h->wg_preload[wgi] : 0, (uint32_t)wgi));
+            const size_t n_lane = lanes.size() / kSellDescWords;
+            std::vector<uint32_t> owner(n_lane);
+            for (size_t t = 0; t < n_lane; ++t) {
+                const uint32_t Hs = (lanes[t * kSellDescWords + 1] >> 8) & 0xFFu;
+                Load l = heap.top();
+                heap.pop();
+                owner[t] = l.second;
+                ++lane_begin[l.second + 1];
+                l.first += (uint64_t)(Hs + 2u) * 64u;
+                heap.push(l);
+            }
+            for (size_t wgi = 0; wgi < G; ++wgi) lane_begin[wgi + 1] += lane_begin[wgi];
+            std::vector<uint32_t> cursor(lane_begin.begin(), lane_begin.end() - 1);
+            rotated.resize(lanes.size());
+            for (size_t t = 0; t < n_lane; ++t) {
+                const size_t at = (size_t)cursor[owner[t]]++;
+                std::copy(lanes.begin() + (ptrdiff_t)(t * kSellDescWords), lanes.begin() + (ptrdiff_t)((t + 1) * kSellDescWords), rotated.begin() + (ptrdiff_t)(at * kSellDescWords));
+            }
+        }
+        {
+            hipError_t eb = hipMalloc((void**)&h->sell_lane_begin, sizeof(uint32_t) * (G + 1));
+            if (eb == hipSuccess) {
+                h->owned_bytes += sizeof(uint32_t) * (G + 1);
+                eb = hipMemcpy(h->sell_lane_begin, lane_begin.data(), sizeof(uint32_t) * (G + 1), hipMemcpyHostToDevice);
+            }
+            if (eb != hipSuccess && e == hipSuccess) e = eb;
         }
         const size_t head = rotate ? (size_t)r * kSellDescWords : 0;
         rotated.insert(rotated.end(), plain.begin() + (ptrdiff_t)head, plain.end());

@@ -95,11 +95,12 @@ def test_logs_are_bit_identical_run_to_run_with_the_adaptive_deal():
         assert torch.equal(lam, outs[0][2]) and torch.equal(grad, outs[0][3])
 
 
-@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0")])
+@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0")])
 def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
     """The reference's golden ``calculate`` cases (fixture G1) with the 64-wide tile layout forced, and with the column-per-lane
     slices switched off (every simplex column in window tiles): the plans a default run only reaches through unaligned or
-    tiny inputs."""
+    tiny inputs; with the fused kernel's second binary (K-lane slices, in-place single-column slices, dynamic deal inside a workgroup)
+    forced on and off for the handles free to use either; and with one lane per column only."""
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
     from tests.helpers import RTOL, SINGLE_MAPS, load, problem, relerr, torch_args
@@ -118,7 +119,12 @@ def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
                 pt, pp = SINGLE_MAPS[mk]
                 objs[(mk, dn)] = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map(pt, dict(pp), p["n"]), DEV), float(g))
                 info = objs[(mk, dn)].info()
-                assert (info["layout"] == 1) if switch[0] == "DUALIP_HIP_LAYOUT" else (info["slices"] == 0), info
+                if switch[0] == "DUALIP_HIP_LAYOUT":
+                    assert info["layout"] == 1, info
+                elif switch[0] == "DUALIP_HIP_SELL":
+                    assert info["slices"] == 0, info
+                elif switch[0] == "DUALIP_HIP_SELL_LANES":
+                    assert info["slice_lane_columns"] == 0, info
             f = objs[(mk, dn)]
             res = f.calculate(torch.from_numpy(z[f"lam_{ln}"]).to(TD[dn]).to(DEV), gamma=float(g), save_primal=True)
             for got, name in ((res.dual_gradient.cpu().numpy(), "grad"), (res.primal_var.cpu().numpy(), "x")):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU session 13: the single-column walker's reductions on the DPP unit; HEAD copy against the tree
-cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/s13
-timeout 900 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_parity.py tests/test_gpu_sell.py tests/test_gpu_fairness.py -m gpu -x -q 2>&1 | tail -3
+cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/s16
+timeout 900 python -m pytest tests -m gpu -x -q --timeout 900 2>&1 | tail -3
 line() { python -c "
 import sys,json
 for l in sys.stdin:
@@ -12,15 +12,16 @@ for l in sys.stdin:
 for rep in 1 2; do
   for arm in head tree; do
     dir=/root/repo; [ $arm = head ] && dir=/root/repo/_ab_head
-    ( cd $dir && timeout 600 python bench.py --entities 10000000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_mixed $arm" ) >> gpurun_out/s13/ab.log
-    ( cd $dir && timeout 600 python bench.py --entities 10000000 --proj simplex --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_simplex $arm" ) >> gpurun_out/s13/ab.log
-    ( cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-verify --steps 60 --warmup 10 2>/dev/null | line "100m_mixed $arm" ) >> gpurun_out/s13/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 10000000 --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_mixed $arm" ) >> gpurun_out/s16/ab.log
+    ( cd $dir && timeout 600 python bench.py --entities 10000000 --proj simplex --no-cpu-baseline --no-verify --steps 200 --warmup 20 2>/dev/null | line "10m_simplex $arm" ) >> gpurun_out/s16/ab.log
+    ( cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-verify --steps 60 --warmup 10 2>/dev/null | line "100m_mixed $arm" ) >> gpurun_out/s16/ab.log
   done
 done
-sort gpurun_out/s13/ab.log
+sort gpurun_out/s16/ab.log
 cd /tmp
 run() { rm -rf /tmp/pm; (cd $1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -o t -- python benchmark/movielens_like.py --max-iter 300 > /tmp/pm.log 2>&1); f=$(find /tmp/pm -name "*kernel_stats.csv" | head -1); python3 -c "
 import csv,sys
 r=[x for x in csv.DictReader(open('$f')) if 'matching_fused' in x['Name']][0]
 print('movielens_like $1', '::', 'avg us', round(float(r['AverageNs'])/1e3,1), 'min', round(float(r['MinNs'])/1e3,1), 'max', round(float(r['MaxNs'])/1e3,1))"; grep "generated\|objective built" /tmp/pm.log | cut -c1-600; }
-( for rep in 1 2 3; do run /root/repo/_ab_head; run /root/repo; done ) 2>&1 | tee /root/repo/gpurun_out/s13/ml.log
+( for rep in 1 2 3; do run /root/repo/_ab_head; run /root/repo; done ) 2>&1 | tee /root/repo/gpurun_out/s16/ml.log
+cd /root/repo; for ab in 0 8192 12288; do echo "== stamp 1 position $ab"; DUALIP_HIP_ABLATE=$ab timeout 300 python tools/timeline_ml.py 60 2>&1 | tail -5; done | tee gpurun_out/s16/timeline.log
