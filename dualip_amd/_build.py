@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdualip_hip.so")
-SOURCES = ["api.hip", "matching_kernels.hip", "matching_kernels4.hip", "matching_kernels4_lanes.hip", "agd_kernels.hip", "lp_kernels.hip", "comm.hip", "sell_build.hip", "csc_ops.hip", "pack_build.hip"]
+SOURCES = ["api.hip", "matching_kernels.hip", "matching_kernels4.hip", "matching_kernels4_f64.hip", "matching_kernels4_lanes.hip", "matching_kernels4_lanes_f64.hip", "agd_kernels.hip", "lp_kernels.hip", "comm.hip", "sell_build.hip", "csc_ops.hip", "pack_build.hip"]
 HEADERS = ["common.h", "wave.h", "simplex.h", "simplex4.h", "fused_common.h", "comm.h", "sell.h", "fused4_kernel.h", "agd_step.h", os.path.join("..", "..", "include", "dualip_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950",

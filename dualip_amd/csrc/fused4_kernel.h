@@ -1,6 +1,6 @@
 // fused4_kernel.h -- the fused pass with 256-wide tiles: FOUR consecutive non-zeros per lane.
 //
-// Included by two translation units: matching_kernels4.hip (DL_FUSED4_LANES 0) and matching_kernels4_lanes.hip (DL_FUSED4_LANES 1).
+// Included by four translation units: matching_kernels4[_f64].hip (DL_FUSED4_LANES 0) and matching_kernels4_lanes[_f64].hip (DL_FUSED4_LANES 1).
 // The second carries, in addition, the loop over the slices with K = 2 .. 16 lanes per column (sell.h: sell_lanes_loop) and is
 // launched for the handles that have such slices.  Two binaries of one source, because the eight extra slice variants inside the
 // kernel cost the handles WITHOUT such slices 2 % per launch (10M entities, all-box map included: same box, HEAD 0.1670 ms,
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         __syncthreads();
         stamp(g, wg, tid, 2);
     }
-    fused_epilogue<T, GRAD_LDS, FAIR>(g, w, acc, tid, lane, wave, wg, fair);
+    fused_epilogue<T, GRAD_LDS, FAIR, LANES>(g, w, acc, tid, lane, wave, wg, fair);
     if (kernarg_args(g).timeline) {
         __syncthreads();
         stamp(g, wg, tid, 3);
@@ -437,11 +437,15 @@ static int launch_fused4_rt(const dl_matching* h, const FusedArgs<T>& args, hipS
 #else
 #define DL_F4_NAME(x) x
 #endif
-int DL_F4_NAME(launch_fused4_f32)(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {
-    return h->row_bytes == 2 ? launch_fused4_rt<float, uint16_t>(h, args, st) : launch_fused4_rt<float, uint32_t>(h, args, st);
-}
+// (one value type per translation unit -- DL_FUSED4_F64 0 / 1 -- so that the four compile side by side)
+#if DL_FUSED4_F64
 int DL_F4_NAME(launch_fused4_f64)(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st) {
     return h->row_bytes == 2 ? launch_fused4_rt<double, uint16_t>(h, args, st) : launch_fused4_rt<double, uint32_t>(h, args, st);
 }
+#else
+int DL_F4_NAME(launch_fused4_f32)(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {
+    return h->row_bytes == 2 ? launch_fused4_rt<float, uint16_t>(h, args, st) : launch_fused4_rt<float, uint32_t>(h, args, st);
+}
+#endif
 
 }  // namespace dl

@@ -422,9 +422,22 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
         const int hmin = ncols < (64 >> klog) ? 0 : Hmin;
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
+        // fp32 without the fairness stream: one variant per height 9 .. 16 (a step past the slice's height costs every pass its full
+        // instruction count; at 40 non-zeros per column the mean height is 10 and the 12-step variant wasted a fifth); else 12 / 16
+        constexpr bool kExact = sizeof(T) == 4 && !FAIR;
+        const int hv = kExact ? (H < 9 ? 9 : (H > 16 ? 16 : H)) : (H <= 12 ? 12 : 16);
+#define DL_SELL_LANES_H(K_, HM_) sell_slice<T, RowT, HM_, (HM_ * kPer > 64), LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); break
 #define DL_SELL_LANES(K_) \
-    if (H <= 12) sell_slice<T, RowT, 12, R12, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
-    else sell_slice<T, RowT, 16, R16, LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); \
+    switch (hv) { \
+        case 9: DL_SELL_LANES_H(K_, (kExact ? 9 : 12)); \
+        case 10: DL_SELL_LANES_H(K_, (kExact ? 10 : 12)); \
+        case 11: DL_SELL_LANES_H(K_, (kExact ? 11 : 12)); \
+        case 12: DL_SELL_LANES_H(K_, 12); \
+        case 13: DL_SELL_LANES_H(K_, (kExact ? 13 : 16)); \
+        case 14: DL_SELL_LANES_H(K_, (kExact ? 14 : 16)); \
+        case 15: DL_SELL_LANES_H(K_, (kExact ? 15 : 16)); \
+        default: DL_SELL_LANES_H(K_, 16); \
+    } \
     break
         switch (klog) {
             case 1: DL_SELL_LANES(1);
@@ -432,6 +445,7 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
             case 3: DL_SELL_LANES(3);
             default: DL_SELL_LANES(4);
         }
+#undef DL_SELL_LANES_H
 #undef DL_SELL_LANES
     }
 }

@@ -146,14 +146,24 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
         pid_sell[pid] = lanes_entry ? 2 : 1;
         *n_nnz += (uint64_t)sh;
         // columns of this entry in sorted order: class by class, hist[l] columns of every length l, shortest first (see sell_descending)
+        // An entry with K-lane slices and only a FEW short columns (fewer one-lane slices than a launch has wavefronts) puts those into
+        // the two-lane class as well: a handful of one-lane slices would form a phase of their own at the end of the launch, one slice per
+        // wavefront with nothing to overlap it (MovieLens-shaped problem: 343 such slices, 15 us of an 87 us launch), while the K-lane
+        // table is dealt by cost and claimed dynamically.  (Heights below 9 run the 9-step variant: a few slices' worth of padding.)
+        uint64_t n_short = 0;
+        for (int l = 1; l <= kSellMaxH; ++l) n_short += hp[l];
+        const char* me = getenv("DUALIP_HIP_SELL_MERGE_SHORT");  // 0: never (testing: both kinds of slices in one small handle)
+        const bool merge_short = lanes_entry && n_short <= 64ull * 4096ull && !(me && me[0] == '0');
         for (int kc = 0; kc < n_classes; ++kc) {
             const int k = down ? n_classes - 1 - kc : kc;
+            if (merge_short && k == 0) continue;
+            const int lo_k = (merge_short && k == 1) ? 1 : lo[k];
             const uint32_t per = 64u >> k;  // columns per slice
             uint64_t cnt = 0;
-            for (int l = lo[k]; l <= hi[k]; ++l) cnt += hp[l];
+            for (int l = lo_k; l <= hi[k]; ++l) cnt += hp[l];
             if (cnt == 0) continue;
             if (k > 0) *n_lane_cols += cnt;
-            const int l_first = down ? hi[k] : lo[k], l_last = down ? lo[k] : hi[k], dl = down ? -1 : 1;
+            const int l_first = down ? hi[k] : lo_k, l_last = down ? lo_k : hi[k], dl = down ? -1 : 1;
             int l_lo = l_first;    // length of the column at the current position
             uint64_t left_lo = hp[l_first];
             auto advance = [&](int& l, uint64_t& left, uint64_t by) {  // move `by` columns forward

@@ -124,8 +124,9 @@ def test_unaligned_values_and_tiny_problems_take_the_narrow_layout():
         f = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.from_numpy(p["b"]).float().to(DEV), equality_mask=None), gamma=0.05)
         assert f.info()["layout"] == 1
         got = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
-        assert relerr(got.dual_gradient.cpu().numpy(), want_grad.cpu().numpy()) < 1e-6
-        assert relerr(got.primal_var.cpu().numpy(), want_x.cpu().numpy()) < 1e-6
+        # (two kernel plans in fp32: the thresholds of a column are summed in different orders -- 16 fp32 ulps)
+        assert relerr(got.dual_gradient.cpu().numpy(), want_grad.cpu().numpy()) < 2e-6
+        assert relerr(got.primal_var.cpu().numpy(), want_x.cpu().numpy()) < 4e-6
     # fewer than 1024 non-zeros: narrow layout, same numbers as the oracle
     q = _random_problem(40, 60, 6, seed=8, empty_every=7)
     f = _compare(q, create_projection_map("simplex", {"z": 1.0}, q["n"]), [("simplex", {"z": 1.0})], None, 0.05, "f64",

@@ -60,11 +60,14 @@ def _boundary_lengths(seed, n=3000, m=400):
     return lens
 
 
+@pytest.mark.parametrize("merge", [0, 1])
 @pytest.mark.parametrize("dn", ["f32", "f64"])
 @pytest.mark.parametrize("kind", ["simplex", "simplex_eq", "mixed"])
-def test_lane_slices_every_length_class(kind, dn):
+def test_lane_slices_every_length_class(kind, dn, merge):
     """Columns of 25 .. 255 non-zeros are dealt to K = 2 .. 16 lanes each (csrc/sell.h): x, gradient and objective against the
-    oracle and against the same handle without slices, at every class edge; the primal comes back in the caller's order."""
+    oracle and against the same handle without slices, at every class edge; the primal comes back in the caller's order.
+    merge = 1 (the default for a handle this small): the few short columns join the two-lane class; merge = 0: they keep their one-lane
+    slices, so both slice loops of the second binary run in one launch."""
     from dualip_amd.projections import create_projection_map
 
     p = _ragged(23, m=400, lens=_boundary_lengths(29))
@@ -79,12 +82,12 @@ def test_lane_slices_every_length_class(kind, dn):
         projs, col_proj, in_entry = [(kind, {"z": 2.0})], None, lens
     gamma = 0.05
     ctor = dict(batching=False, simplex_eq_padding="reference") if kind == "simplex_eq" else None
-    f = _objective(p, dn, pm, gamma, ctor=ctor)
+    f = _objective(p, dn, pm, gamma, ctor=ctor, DUALIP_HIP_SELL_MERGE_SHORT=merge)
     f0 = _objective(p, dn, pm, gamma, sell=False, ctor=ctor)
     f1 = _objective(p, dn, pm, gamma, ctor=ctor, DUALIP_HIP_SELL_LANES=0)  # one lane per column only: the longer columns walk alone
     info, info1 = f.info(), f1.info()
     assert info["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 255)).sum())
-    assert info["slice_lane_columns"] == int(((in_entry >= 25) & (in_entry <= 255)).sum())
+    assert info["slice_lane_columns"] == int(((in_entry >= (1 if merge else 25)) & (in_entry <= 255)).sum())
     assert info["long_columns"] >= int((in_entry > 255).sum())
     assert info1["slice_lane_columns"] == 0 and info1["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 24)).sum())
     rng = np.random.default_rng(7)
@@ -135,7 +138,7 @@ def test_slices_against_oracle_and_window_tiles(kind, dn):
     lens = np.diff(p["colptr"])
     in_entry = lens[n // 3 :] if kind == "mixed" else lens
     assert info["slices"] > 0 and info["slice_columns"] == int((in_entry >= 1).sum())  # (lengths up to 40: one lane per column to 24, two / four beyond)
-    assert info["slice_lane_columns"] == int((in_entry > 24).sum())
+    assert info["slice_lane_columns"] == int((in_entry >= 1).sum())  # (a handle this small: the short columns join the two-lane class)
     assert f0.info()["slices"] == 0
     rng = np.random.default_rng(5)
     for scale in (0.0, 0.02, 0.5):
