@@ -386,3 +386,22 @@ def test_build_screens_device_assembly_for_the_misplaced_spill():
         assert _build._spill_defects(fh.name) == []
     finally:
         os.unlink(fh.name)
+
+
+def test_build_lists_cover_every_source_and_header():
+    """The build hashes SOURCES + HEADERS to decide staleness and compiles exactly SOURCES: a file added under csrc/ but not
+    listed would be silently left out of the library (or of the staleness check)."""
+    import os
+
+    from dualip_amd import _build
+
+    on_disk = sorted(os.listdir(_build.CSRC))
+    hips = [f for f in on_disk if f.endswith(".hip")]
+    headers = [f for f in on_disk if f.endswith(".h")]
+    assert sorted(_build.SOURCES) == hips
+    listed_headers = sorted(os.path.basename(h) for h in _build.HEADERS if not h.startswith(".."))
+    assert listed_headers == headers
+    # the four translation units of the 256-wide fused kernel are one header compiled with two switches
+    for name, lanes, f64 in (("matching_kernels4.hip", 0, 0), ("matching_kernels4_f64.hip", 0, 1), ("matching_kernels4_lanes.hip", 1, 0), ("matching_kernels4_lanes_f64.hip", 1, 1)):
+        text = open(os.path.join(_build.CSRC, name)).read()
+        assert f"#define DL_FUSED4_LANES {lanes}" in text and f"#define DL_FUSED4_F64 {f64}" in text and '#include "fused4_kernel.h"' in text
