@@ -95,12 +95,16 @@ def test_logs_are_bit_identical_run_to_run_with_the_adaptive_deal():
         assert torch.equal(lam, outs[0][2]) and torch.equal(grad, outs[0][3])
 
 
-@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0")])
+@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0"),
+                                    ("DUALIP_HIP_FLAT", "0"), ("DUALIP_HIP_FLAT", "1"), ("DUALIP_HIP_COMPACT", "0"), ("DUALIP_HIP_HOST_PACK", "1"), ("DUALIP_HIP_ROW32", "1"),
+                                    ("DUALIP_HIP_XCD_BALANCE", "0"), ("DUALIP_HIP_LDS_MODE", "grad"), ("DUALIP_HIP_LDS_MODE", "none"), ("DUALIP_HIP_HOT_ROWS", "64")])
 def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
     """The reference's golden ``calculate`` cases (fixture G1) with the 64-wide tile layout forced, and with the column-per-lane
     slices switched off (every simplex column in window tiles): the plans a default run only reaches through unaligned or
     tiny inputs; with the fused kernel's second binary (K-lane slices, in-place single-column slices, dynamic deal inside a workgroup)
-    forced on and off for the handles free to use either; and with one lane per column only."""
+    forced on and off for the handles free to use either; with one lane per column only; and under every other layout switch of
+    INTEGRATION.md (whole-column / unaligned point-wise windows, 12-dword descriptors, host packing, 32-bit rows, the even deal, the
+    smaller LDS plans, a forced hot-rows plan)."""
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
     from tests.helpers import RTOL, SINGLE_MAPS, load, problem, relerr, torch_args
