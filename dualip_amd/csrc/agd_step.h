@@ -49,7 +49,8 @@ struct ApplyArgs {
 
 // The scalars of the step, identical in every wavefront that calls it: sums the stats partials in a fixed order (no LDS, no
 // barrier; four rows per lane are loaded before the first is used), runs calculate_step_size (agd_utils.py:65-89) with the
-// Lipschitz ring held one entry per lane, and returns the step.  `writer` (one workgroup of the launch) stores the next
+// Lipschitz ring held one entry per lane, and returns the step.  (The six sums are reduced on the DPP unit, wave.h: 72 double-width
+// ds_bpermute round trips before round 3.)  `writer` (one workgroup of the launch) stores the next
 // optimiser state and the log row; tid = thread index inside that workgroup.
 template <class T>
 __device__ __forceinline__ double agd_step_scalars(const ApplyArgs<T>& p, int lane, bool writer, int tid) {
@@ -80,12 +81,12 @@ __device__ __forceinline__ double agd_step_scalars(const ApplyArgs<T>& p, int la
                 dy2 += in[u] ? o[u][5] : 0.0;
             }
         }
-        dvtg = wave_allreduce(dvtg, OpAdd());
-        gmax = wave_allreduce(gmax, OpMax());
-        spos = wave_allreduce(spos, OpAdd());
-        g2 = wave_allreduce(g2, OpAdd());
-        dg2 = wave_allreduce(dg2, OpAdd());
-        dy2 = wave_allreduce(dy2, OpAdd());
+        dvtg = wave_allreduce_dpp(dvtg, OpAdd());
+        gmax = wave_allreduce_dpp(gmax, OpMax());
+        spos = wave_allreduce_dpp(spos, OpAdd());
+        g2 = wave_allreduce_dpp(g2, OpAdd());
+        dg2 = wave_allreduce_dpp(dg2, OpAdd());
+        dy2 = wave_allreduce_dpp(dy2, OpAdd());
     }
     int n_lips = si.n_lips, head = si.head, slot = -1;
     double L = 0.0;
@@ -108,7 +109,7 @@ __device__ __forceinline__ double agd_step_scalars(const ApplyArgs<T>& p, int la
         // builtins.max over the list, oldest first: NaN if the oldest entry is NaN, else the maximum of the non-NaN entries
         const double first = bperm(head, ring_new);
         const double cand_l = (lane < kLipsMax && !isnan(ring_new)) ? ring_new : -INFINITY;
-        const double mx = wave_allreduce(cand_l, OpMax());
+        const double mx = wave_allreduce_dpp(cand_l, OpMax());
         const double lmax = isnan(first) ? first : mx;
         if (isnan(lmax) || isinf(lmax)) step = si.initial_step;
         else {

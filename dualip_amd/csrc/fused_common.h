@@ -430,8 +430,9 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         a_bb = (T)bt;
         a_omb = (T)(float)(1.0f - bt);
     }
-    {   // latency bound (every workgroup pulls the whole dual vector from L2): four loads in flight per thread
-        constexpr int kU = 4;
+    {   // latency bound (every workgroup pulls the whole dual vector from L2): twelve loads in flight per thread -- the benchmark's
+        // 10^4 duals in ONE round trip instead of three
+        constexpr int kU = 12;
         for (int64_t i0 = tid; i0 < g.m; i0 += (int64_t)kU * kFusedThreads) {
             T l[kU];
             if (!applying) {
