@@ -130,14 +130,14 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     double ax = 0.0;
     if constexpr (FROM_SLABS) {
         long long acc = 0;
-        {   // latency bound: eight slabs in flight before the first is added (slabs past the end re-read the last one)
+        {   // latency bound: sixteen slabs in flight before the first is added (slabs past the end re-read the last one)
             const int64_t rc = live ? col : p.m - 1;
             const bool in_slabs = !p.inv || rc < p.m_hot;
             if (!in_slabs && ws == 0) {
                 acc = p.cold[rc];
                 if (p.cold_zero && live) p.cold_zero[rc] = 0;  // consumed: ready for the next fused launch (no memset launch)
             }
-            constexpr int kU = 8;
+            constexpr int kU = 16;  // (256 slabs / 16 slices: every load of a thread in flight at once)
             for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
                 long long v[kU];
 #pragma unroll
@@ -200,12 +200,12 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     }
     // wave 0 holds all 64 rows of the block (ws == 0 <=> tid < 64)
     if (tid < 64) {
-        dvtg = wave_allreduce(dvtg, OpAdd());
-        gmax = wave_allreduce(gmax, OpMax());
-        spos = wave_allreduce(spos, OpAdd());
-        g2 = wave_allreduce(g2, OpAdd());
-        dg2 = wave_allreduce(dg2, OpAdd());
-        dy2 = wave_allreduce(dy2, OpAdd());
+        dvtg = wave_allreduce_dpp(dvtg, OpAdd());
+        gmax = wave_allreduce_dpp(gmax, OpMax());
+        spos = wave_allreduce_dpp(spos, OpAdd());
+        g2 = wave_allreduce_dpp(g2, OpAdd());
+        dg2 = wave_allreduce_dpp(dg2, OpAdd());
+        dy2 = wave_allreduce_dpp(dy2, OpAdd());
         if (tid == 0) {
             double* o = p.partial_stats + (int64_t)blockIdx.x * kStatCols;
             o[0] = dvtg;
@@ -250,11 +250,22 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
 template <class T>
 __global__ __launch_bounds__(kApplyThreads) void agd_apply_kernel(ApplyArgs<T> p) {
     const int tid = threadIdx.x;
-    const double step = agd_step_scalars(p, tid & 63, blockIdx.x == 0, tid);
     const int64_t mine = (int64_t)blockIdx.x * kApplyThreads + tid;
+    // this thread's row is requested BEFORE the scalars are derived (two dependent memory latencies -> one; the row does not depend on the step)
+    const int64_t ic = mine < p.m ? mine : (p.m > 0 ? p.m - 1 : 0);
+    T rx = (T)0, rg = (T)0, ry = (T)0;
+    bool req = false;
+    if (p.m > 0) {
+        rx = p.x[ic];
+        rg = p.g_new[ic];
+        ry = p.y[ic];
+        req = p.eq_mask && p.eq_mask[ic];
+    }
+    const float bt = p.beta[p.iter - 1];
+    const double step = agd_step_scalars(p, tid & 63, blockIdx.x == 0, tid);
     if (mine < p.m) {
         T yn, xn;
-        agd_update_row(p, step, mine, yn, xn);
+        agd_update_values(rx, rg, ry, req, (T)step, (T)bt, (T)(float)(1.0f - bt), yn, xn);
         p.y_new[mine] = yn;
         p.x_next[mine] = xn;
         if (p.x_perm) p.x_perm[p.perm[mine]] = xn;  // hot-rows plan of the matching handle: next launch's dual vector, renumbered
