@@ -59,7 +59,7 @@ int sell_fill_fair(dl_matching* h, const void* f_values, hipStream_t st);
 int sell_refill_costs(dl_matching* h, hipStream_t st);
 int sell_refill_values(dl_matching* h, hipStream_t st);
 constexpr int kSellMaxLen = 24;        // sell.h: kSellMaxH
-constexpr int kSellMaxLenLanes = 255;  // sell.h: longest column of an entry sliced with K lanes per column (pid_sell == 2)
+constexpr int kSellMaxLenLanes = 512;  // sell.h: longest column of an entry sliced with K lanes per column (pid_sell == 2)
 
 // ---- row index re-encoding: caller's int32/int64 -> uint16 (m <= 65536) or uint32 ----
 constexpr int kReencLdsRows = 16384;  // rows whose histogram a workgroup keeps in LDS (64 KB)

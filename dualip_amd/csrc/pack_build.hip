@@ -18,7 +18,7 @@ namespace dl {
 
 constexpr int kPackChunk = 8192;   // columns per chunk (= per thread)
 constexpr int kPackSellMaxLen = 24;        // sell.h: kSellMaxH
-constexpr int kPackSellMaxLenLanes = 255;  // sell.h: kSellMaxLenLanes (entries sliced with K lanes per column: flag bit 3)
+constexpr int kPackSellMaxLenLanes = 512;  // sell.h: kSellMaxLenLanes (entries sliced with K lanes per column: flag bit 3)
 
 struct PackErr {
     int bad_colptr;      // a column pointer decreases

@@ -34,15 +34,22 @@ __host__ __device__ inline int sell_chunks(int H) { return (H + 3) >> 2; }
 // contiguous run, and the per-lane recurrences are unchanged; each per-COLUMN quantity (maximum, sums and sizes of the supports) is
 // combined over the K lanes by log2 K butterfly steps on the DPP unit (quad_perm, row_half_mirror, row_mirror -- no LDS traffic),
 // after which all K lanes hold the same bits and take the same decisions.  K is the smallest power of two that brings the height
-// to <= 16 steps (the tallest variant that keeps its registers): 25-32 -> 2, 33-64 -> 4, 65-128 -> 8, 129-255 -> 16, so a slice is
-// 9 .. 16 steps high.  Before, such columns of a sliced entry were single-column tiles (one wavefront per column, latency bound)
+// to <= 16 steps (the tallest variant that keeps its registers): 25-32 -> 2, 33-64 -> 4, 65-128 -> 8, 129-255 -> 16, 256-512 -> 32 (the
+// last step of that butterfly crosses two DPP rows: one ds_swizzle), so a slice is 8 .. 16 steps high.  Before, such columns of a sliced entry were single-column tiles (one wavefront per column, latency bound)
 // and those of an unsliced entry went through the segmented window tile (instruction bound).
-constexpr int kSellMaxLenLanes = 255;  // longest column a slice can hold (the per-column length record is one byte)
-__host__ __device__ inline int sell_lanes_log(int len) { return len <= kSellMaxH ? 0 : (len <= 32 ? 1 : (len <= 64 ? 2 : (len <= 128 ? 3 : 4))); }
+constexpr int kSellMaxLenLanes = 512;  // longest column a slice can hold (K = 32: two columns per slice, their lengths ride the descriptor;
+                                       // up to 255 the per-column length record is one byte)
+__host__ __device__ inline int sell_lanes_log(int len) { return len <= kSellMaxH ? 0 : (len <= 32 ? 1 : (len <= 64 ? 2 : (len <= 128 ? 3 : (len <= 255 ? 4 : 5)))); }
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov0_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 // all-reduce over the 2^KLOG adjacent lanes of a column; commutative steps, so every lane of the group ends with identical bits
+// value of lane ^ 16 (ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10 -- inside each half of the wavefront; no address register)
+__device__ __forceinline__ uint32_t swizzle_xor16(uint32_t x) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F); }
+__device__ __forceinline__ float swizzle_xor16(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)); }
+__device__ __forceinline__ double swizzle_xor16(double x) {
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
+}
 struct OpMaxNonNegT {
     template <class T>
     __device__ __forceinline__ T operator()(T a, T b) const { return max_nonneg(a, b); }
@@ -54,6 +61,7 @@ __device__ __forceinline__ T group_sum(T x) {
     if constexpr (KLOG >= 2) x = (T)(x + dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
     if constexpr (KLOG >= 3) x = (T)(x + dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
     if constexpr (KLOG >= 4) x = (T)(x + dpp_mov0<DPP_ROW_MIRROR, 0xf>(x));
+    if constexpr (KLOG == 5) x = (T)(x + swizzle_xor16(x));  // lane ^ 16: the partner row of a 32-lane column
     return x;
 }
 template <int KLOG>
@@ -63,6 +71,7 @@ __device__ __forceinline__ uint32_t group_sum_u32(uint32_t x) {
     if constexpr (KLOG >= 2) x += dpp_mov0_u32<DPP_QUAD_XOR2>(x);
     if constexpr (KLOG >= 3) x += dpp_mov0_u32<DPP_ROW_HALF_MIRROR>(x);
     if constexpr (KLOG >= 4) x += dpp_mov0_u32<DPP_ROW_MIRROR>(x);
+    if constexpr (KLOG == 5) x += swizzle_xor16(x);
     return x;
 }
 template <int KLOG, class T>
@@ -72,6 +81,7 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
     if constexpr (KLOG >= 2) x = max_nonneg(x, dpp_mov0<DPP_QUAD_XOR2, 0xf>(x));
     if constexpr (KLOG >= 3) x = max_nonneg(x, dpp_mov0<DPP_ROW_HALF_MIRROR, 0xf>(x));
     if constexpr (KLOG >= 4) x = max_nonneg(x, dpp_mov0<DPP_ROW_MIRROR, 0xf>(x));
+    if constexpr (KLOG == 5) x = max_nonneg(x, swizzle_xor16(x));
     return x;
 }
 
@@ -410,7 +420,8 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
         const bool has_col = (lane >> klog) < ncols;
         const uint64_t dense = (uint64_t)dense0 + (uint32_t)(has_col ? lane >> klog : 0);
         int len = has_col ? H << klog : 0;  // (one length in the slice, a multiple of K: no length bytes read)
-        if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;
+        if (klog == 5) len = has_col ? (int)((w2 >> (11 + 9 * (lane >> 5))) & 511u) + 1 : 0;  // K = 32: two columns, their lengths - 1 in bits 11 .. 28 of the descriptor
+        else if (Hmin != H) len = has_col ? (int)g.sell_len[dense] : 0;
         const int sub = lane & ((1 << klog) - 1);
         const int len_lane = has_col ? (len - sub + (1 << klog) - 1) >> klog : 0;
         const ProjT<T> pj = w.proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
@@ -443,7 +454,8 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
             case 1: DL_SELL_LANES(1);
             case 2: DL_SELL_LANES(2);
             case 3: DL_SELL_LANES(3);
-            default: DL_SELL_LANES(4);
+            case 4: DL_SELL_LANES(4);
+            default: DL_SELL_LANES(5);
         }
 #undef DL_SELL_LANES_H
 #undef DL_SELL_LANES

@@ -15,7 +15,7 @@ namespace dl {
 
 constexpr int kSellPidSlots = 256;  // projection ids that can own slices (the kernel's LDS projection table)
 constexpr int kSellBins = kSellMaxLenLanes + 2;  // histogram bins per entry: lengths 0 .. kSellMaxLenLanes, last = longer
-constexpr int kSellHistLds = 32;                  // entries whose histogram is privatised in LDS (the others count in memory)
+constexpr int kSellHistLds = 16;                  // entries whose histogram is privatised in LDS (the others count in memory)
 
 // (entry, length) histogram, privatised in LDS for the first kSellHistLds entries: a single-entry map would otherwise put every
 // column on a few dozen addresses.  nnz_by_pid[2 q + 1]: non-zeros of entry q in columns longer than kSellMaxLenLanes.
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(256) void sell_hist_kernel(int64_t n, const IdxT* _
 
 template <class IdxT>
 __global__ __launch_bounds__(256) void sell_keys_kernel(int64_t n, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj,
-                                                        const uint8_t* __restrict__ pid_sell, uint16_t* __restrict__ keys, uint32_t* __restrict__ ids, int desc) {
+                                                        const uint8_t* __restrict__ pid_sell, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int desc) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t len = (int64_t)colptr[j + 1] - (int64_t)colptr[j];
         const int32_t pid = col_proj ? col_proj[j] : 0;
         // pid_sell[q]: 0 = entry without slices, 1 = columns of <= kSellMaxH non-zeros, 2 = of <= kSellMaxLenLanes (K lanes per column)
         const int64_t max_len = (pid >= 0 && pid < kSellPidSlots - 1) ? (pid_sell[pid] == 2 ? kSellMaxLenLanes : (pid_sell[pid] ? kSellMaxH : 0)) : 0;
         const bool ok = len >= 1 && len <= max_len;
-        keys[j] = ok ? (uint16_t)(((uint32_t)pid << 8) | (uint32_t)(desc ? 255 - len : len)) : (uint16_t)0xFFFF;  // (desc: longest first inside an entry; pid <= 254)
+        keys[j] = ok ? (((uint32_t)pid << 10) | (uint32_t)(desc ? 1023 - len : len)) : 0x3FFFFu;  // 18 bits (desc: longest first inside an entry; pid <= 254)
         ids[j] = (uint32_t)j;
     }
 }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(uint32_t n_slices, const
     int len = 0;
     uint64_t k0 = 0;
     if (col < ncols) {
-        len = (int)slen[(size_t)dense0 + col];
+        len = klog == 5 ? (int)((desc[(size_t)sl * kSellDescWords + 2] >> (11 + 9 * col)) & 511u) + 1 : (int)slen[(size_t)dense0 + col];  // (K = 32: lengths in the descriptor)
         k0 = colstart[(size_t)dense0 + col];
     }
     for (int t = 0; t < H; ++t) {
@@ -123,7 +123,7 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
     if (n_proj <= 0 || !projs) return;
     uint64_t dense = 0, base = 0;
     // length classes by lanes per column (sell_lanes_log): K = 1 << k holds lengths lo[k] .. hi[k]
-    const int lo[5] = {1, kSellMaxH + 1, 33, 65, 129}, hi[5] = {kSellMaxH, 32, 64, 128, kSellMaxLenLanes};
+    const int lo[6] = {1, kSellMaxH + 1, 33, 65, 129, 256}, hi[6] = {kSellMaxH, 32, 64, 128, 255, kSellMaxLenLanes};
     const bool down = sell_descending();
     for (int pid = 0; pid < kSellPidSlots - 1 && pid < (single_entry ? 1 : n_proj); ++pid) {
         const int kind = projs[pid].kind;
@@ -142,7 +142,7 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
         else lg += sh_lanes;
         const double ms = min_share < 0.0 ? (lanes_entry ? 0.0 : 0.9) : min_share;
         if (sh <= 0.0 || sh < ms * (sh + lg)) continue;
-        const int n_classes = lanes_entry ? 5 : 1;
+        const int n_classes = lanes_entry ? 6 : 1;
         pid_sell[pid] = lanes_entry ? 2 : 1;
         *n_nnz += (uint64_t)sh;
         // columns of this entry in sorted order: class by class, hist[l] columns of every length l, shortest first (see sell_descending)
@@ -187,7 +187,13 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
                 const int hmin = len_min >> k;                // the fewest elements any lane of a column holds
                 desc.push_back((uint32_t)base);
                 desc.push_back((uint32_t)(base >> 32) | ((uint32_t)H << 8) | ((uint32_t)hmin << 16) | ((ncols - 1u) << 24));
-                desc.push_back((uint32_t)pid | ((uint32_t)k << 8));
+                // (K = 32: two columns per slice, whose lengths - 1 ride in bits 11 .. 28 -- the per-column length record is one byte)
+                uint32_t lens32 = 0;
+                if (k == 5) {
+                    const int len_first = l_lo, len_second = ncols > 1 ? l_hi : l_lo;  // in table order (ascending, or descending with DUALIP_HIP_SELL_ORDER=desc)
+                    lens32 = ((uint32_t)(len_first - 1) << 11) | ((uint32_t)(len_second - 1) << 20);
+                }
+                desc.push_back((uint32_t)pid | ((uint32_t)k << 8) | lens32);
                 desc.push_back((uint32_t)dense);
                 base += (uint64_t)H * 64u;
                 dense += ncols;
@@ -254,7 +260,7 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
     const uint64_t n_cols = (uint64_t)h->n_sell_cols, n_elems = (uint64_t)h->n_sell_elems;
     const int blocks = (int)std::min<int64_t>(8192, (h->n + 255) / 256);
     // ---- sort the columns by (entry, length): stable, so equal keys keep the caller's column order (deterministic) ----
-    uint16_t *keys = nullptr, *keys2 = nullptr;
+    uint32_t *keys = nullptr, *keys2 = nullptr;
     uint32_t *ids = nullptr, *ids2 = nullptr;
     uint8_t* flags = nullptr;
     void* tmp = nullptr;
@@ -264,8 +270,8 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
             if (p) (void)hipFree(p);
     };
     const size_t n = (size_t)h->n;
-    hipError_t e = hipMalloc((void**)&keys, 2 * n);
-    if (e == hipSuccess) e = hipMalloc((void**)&keys2, 2 * n);
+    hipError_t e = hipMalloc((void**)&keys, 4 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&keys2, 4 * n);
     if (e == hipSuccess) e = hipMalloc((void**)&ids, 4 * n);
     if (e == hipSuccess) e = hipMalloc((void**)&ids2, 4 * n);
     if (e == hipSuccess) e = hipMalloc((void**)&flags, kSellPidSlots);
@@ -274,9 +280,9 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
         hipLaunchKernelGGL(sell_keys_kernel<IdxT>, dim3(blocks), dim3(256), 0, st, h->n, colptr, col_proj, flags, keys, ids, sell_descending() ? 1 : 0);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, ids, ids2, (int)n, 0, 16, st);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, ids, ids2, (int)n, 0, 18, st);
     if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, ids, ids2, (int)n, 0, 16, st);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, ids, ids2, (int)n, 0, 18, st);
     if (e != hipSuccess) {
         cleanup();
         return hip_fail(e, "slice sort");

@@ -113,7 +113,7 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
  * 16 dwords per window descriptor (12; 2 when every window is point-wise: compact table; 4 for the 64-wide layout),
  * 17 columns of slices that hold more than one column length (only their length bytes are read per launch),
  * 18 + w (w < 1024): rounds of workgroup w in the window tiles' cyclic deal (-1: no table; synchronous device read),
- * 2000 columns held in slices with K = 2 .. 16 lanes per column (counted in 13 too): those of 25 .. 255 non-zeros, and a handle's
+ * 2000 columns held in slices with K = 2 .. 32 lanes per column (counted in 13 too): those of 25 .. 512 non-zeros, and a handle's
  *      FEW short columns, which join the two-lane class. */
 int64_t dl_matching_info(const dl_matching* h, int what);
 

@@ -153,7 +153,7 @@ def test_long_columns_empty_columns_and_nested_ranges():
     for dn in ("f32", "f64"):
         f = _compare(p, pm, entries, col_proj, 0.03, dn, lam)
         # (column 1999 is in no entry: point-wise columns of any length are part of the window stream, not single-column tiles)
-        assert f.info()["long_columns"] >= 3
+        assert f.info()["long_columns"] + f.info().get("slice_lane_columns", 0) >= 3  # (up to 512 non-zeros: K-lane slices of the second binary)
 
 
 @pytest.mark.parametrize("host_pack", [False, True])
@@ -346,7 +346,7 @@ def test_hot_rows_with_single_column_tiles_and_primal(monkeypatch):
             f = _compare(p, create_projection_map(pt, dict(pp), p["n"]), entries, None, 0.05, dn, lam)
             info = f.info()
             if info["layout"] == 4:
-                assert info["hot_rows"] == 192 and info["long_columns"] >= 3
+                assert info["hot_rows"] == 192 and info["long_columns"] + info.get("slice_lane_columns", 0) >= 3
 
 
 @pytest.mark.parametrize("forced", [False, True])

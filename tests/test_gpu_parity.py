@@ -334,7 +334,7 @@ def test_movielens_like_trace():
     p = problem(z)
     g, it, s0, s1 = z["params"]
     f = _objective(p, "f64", create_projection_map("simplex", {"z": 1.0}, p["n"]), float(g))
-    assert f.info()["long_columns"] > 0
+    assert f.info()["long_columns"] + f.info().get("slice_lane_columns", 0) > 0  # (the long columns' paths: single-column tiles / K-lane slices)
     res = AcceleratedGradientDescent(max_iter=int(it), gamma=float(g), initial_step_size=s0, max_step_size=s1, iteration_callback=False).maximize(
         f, torch.zeros(p["m"], dtype=torch.float64, device=DEV)
     )

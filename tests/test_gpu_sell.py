@@ -48,12 +48,12 @@ def _ragged(seed, n=6000, m=300, lens=None):
     return dict(m=m, n=len(lens), colptr=colptr, rowidx=rowidx, a=a, c=c, b=rng.uniform(0.5, 3.0, m))
 
 
-def _boundary_lengths(seed, n=3000, m=400):
-    """Column lengths that hit every class of the K-lanes-per-column slices and its edges (24|25, 32|33, 64|65, 128|129, 255|256),
-    the window limit (253) and columns past everything, plus a random filling of 0 .. 300."""
+def _boundary_lengths(seed, n=3000, m=600):
+    """Column lengths that hit every class of the K-lanes-per-column slices and its edges (24|25, 32|33, 64|65, 128|129, 255|256, 512|513),
+    the window limit (253) and columns past everything, plus a random filling of 0 .. 400."""
     rng = np.random.default_rng(seed)
-    lens = rng.integers(0, 301, n)
-    edges = [1, 2, 23, 24, 25, 26, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 66, 96, 127, 128, 129, 130, 192, 252, 253, 254, 255, 256, 257, 300, 399]
+    lens = rng.integers(0, 401, n)
+    edges = [1, 2, 23, 24, 25, 26, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 66, 96, 127, 128, 129, 130, 192, 252, 253, 254, 255, 256, 257, 287, 288, 289, 300, 399, 448, 511, 512, 513, 577, 600]
     lens[: 3 * len(edges)] = np.repeat(edges, 3)
     rng.shuffle(lens)
     lens[::97] = 0
@@ -64,13 +64,13 @@ def _boundary_lengths(seed, n=3000, m=400):
 @pytest.mark.parametrize("dn", ["f32", "f64"])
 @pytest.mark.parametrize("kind", ["simplex", "simplex_eq", "mixed"])
 def test_lane_slices_every_length_class(kind, dn, merge):
-    """Columns of 25 .. 255 non-zeros are dealt to K = 2 .. 16 lanes each (csrc/sell.h): x, gradient and objective against the
+    """Columns of 25 .. 512 non-zeros are dealt to K = 2 .. 32 lanes each (csrc/sell.h): x, gradient and objective against the
     oracle and against the same handle without slices, at every class edge; the primal comes back in the caller's order.
     merge = 1 (the default for a handle this small): the few short columns join the two-lane class; merge = 0: they keep their one-lane
     slices, so both slice loops of the second binary run in one launch."""
     from dualip_amd.projections import create_projection_map
 
-    p = _ragged(23, m=400, lens=_boundary_lengths(29))
+    p = _ragged(23, m=600, lens=_boundary_lengths(29))
     n, m = p["n"], p["m"]
     lens = np.diff(p["colptr"])
     if kind == "mixed":
@@ -86,9 +86,9 @@ def test_lane_slices_every_length_class(kind, dn, merge):
     f0 = _objective(p, dn, pm, gamma, sell=False, ctor=ctor)
     f1 = _objective(p, dn, pm, gamma, ctor=ctor, DUALIP_HIP_SELL_LANES=0)  # one lane per column only: the longer columns walk alone
     info, info1 = f.info(), f1.info()
-    assert info["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 255)).sum())
-    assert info["slice_lane_columns"] == int(((in_entry >= (1 if merge else 25)) & (in_entry <= 255)).sum())
-    assert info["long_columns"] >= int((in_entry > 255).sum())
+    assert info["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 512)).sum())
+    assert info["slice_lane_columns"] == int(((in_entry >= (1 if merge else 25)) & (in_entry <= 512)).sum())
+    assert info["long_columns"] >= int((in_entry > 512).sum())
     assert info1["slice_lane_columns"] == 0 and info1["slice_columns"] == int(((in_entry >= 1) & (in_entry <= 24)).sum())
     rng = np.random.default_rng(7)
     for scale in (0.0, 0.02, 0.5):
@@ -105,7 +105,7 @@ def test_lane_slices_every_length_class(kind, dn, merge):
         assert torch.equal(f.calculate(lam, gamma, save_primal=True).primal_var, r.primal_var)  # bit-reproducible
         if kind == "simplex":  # every projected column sums to z or less, and to z where the clamped column exceeded it
             sums = np.add.reduceat(x, p["colptr"][:-1][lens > 0])
-            assert (sums <= 2.0 * (1 + (1e-5 if dn == "f32" else 1e-10))).all()
+            assert (sums <= 2.0 * (1 + (5e-5 if dn == "f32" else 1e-10))).all()  # (fp32: up to 600 terms per column)
     if kind == "simplex_eq":  # exact mode
         fe = _objective(p, dn, pm, gamma)
         lam = torch.from_numpy(rng.uniform(0, 0.3, m)).to(TD[dn]).to(DEV)
