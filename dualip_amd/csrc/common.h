@@ -134,7 +134,7 @@ struct dl_matching {
     uint32_t* sell_lane_begin = nullptr;  // owned: [n_wg + 1] ranges of the K-lane slice table, one per workgroup
     int64_t long_nnz = 0;             // non-zeros in single-column tiles walked by one wavefront each
     int64_t n_sell_lane_slices = 0;   // slices with K > 1 lanes per column: the FIRST n of sell_desc (walked by their own loop)
-    int64_t n_sell_lane_cols = 0;     // columns dealt to K > 1 lanes each (25 .. 255 non-zeros; sell.h)
+    int64_t n_sell_lane_cols = 0;     // columns dealt to K > 1 lanes each (25 .. 512 non-zeros; sell.h)
     int64_t n_sell_mixed_cols = 0;    // columns of slices that hold more than one length (the only ones whose length bytes are read)
     uint32_t* sell_desc = nullptr;    // owned, 4 dwords per slice
     uint8_t* sell_len = nullptr;      // owned, [n_sell_cols]

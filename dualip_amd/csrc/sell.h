@@ -28,7 +28,7 @@ constexpr int kSellDescWords = 4; // { base[31:0] ; base[39:32] | H << 8 | Hmin 
 
 __host__ __device__ inline int sell_chunks(int H) { return (H + 3) >> 2; }
 
-// ---- K lanes per column (round 3): columns of 25 .. 255 non-zeros ----
+// ---- K lanes per column (round 3): columns of 25 .. 512 non-zeros ----
 // A column longer than the tallest slice is dealt to K = 2, 4, 8 or 16 ADJACENT lanes: element e of the column sits at lane
 // K * (column in slice) + (e mod K), step e / K -- the slice is still base + 64 t + lane, every load of a wavefront still one
 // contiguous run, and the per-lane recurrences are unchanged; each per-COLUMN quantity (maximum, sums and sizes of the supports) is
@@ -374,7 +374,7 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
     }
 }
 
-// The slices with K = 2 .. 16 lanes per column (descriptors g.sell_lane_desc[0 .. g.n_sell_lanes): the columns of 25 .. 255 non-zeros),
+// The slices with K = 2 .. 32 lanes per column (descriptors g.sell_lane_desc[0 .. g.n_sell_lanes): the columns of 25 .. 512 non-zeros),
 // walked in their OWN loop ahead of the other phases.  Two reasons: they are the most expensive slices (9 .. 16 steps, more Newton
 // passes), so they must not end a launch; and with their eight variants inside sell_loop the code of the one-lane variants changed
 // enough to cost the benchmark's shapes 6 % at 10M entities (same box, DUALIP_HIP_SELL_LANES=0 on the same binary no faster: the code,

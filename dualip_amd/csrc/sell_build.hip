@@ -130,7 +130,7 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
         if (kind != DL_PROJ_SIMPLEX && kind != DL_PROJ_SIMPLEX_EQ) continue;
         if (projs[pid].flags & DL_PROJ_FLAG_NO_SLICES) continue;
         const unsigned long long* hp = hist + (size_t)pid * kSellBins;
-        // An entry gets K-lane slices when its columns of 25 .. 255 non-zeros hold at least `lane_share` of its non-zeros: a handle with
+        // An entry gets K-lane slices when its columns of 25 .. 512 non-zeros hold at least `lane_share` of its non-zeros: a handle with
         // such slices runs the second binary of the fused kernel (fused4_kernel.h), and a handful of long columns -- the benchmark's
         // Poisson(10) columns: one non-zero in 10^4 -- is not worth leaving the first.  Such an entry is sliced whatever the share of its
         // short columns (its only leftovers are columns no window could hold either); otherwise the share rule of the one-lane slices
@@ -226,7 +226,7 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     (void)hipFree(stats);
     if (e != hipSuccess) return hip_fail(e, "slice statistics");
     uint64_t n_cols = 0, n_elems = 0, n_nnz = 0, n_lane_cols = 0;
-    // K lanes per column for the columns of 25 .. 255 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0, for the entries in which they
+    // K lanes per column for the columns of 25 .. 512 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0, for the entries in which they
     // hold at least DUALIP_HIP_SELL_LANES_MIN_SHARE (default 1 %) of the non-zeros (sell_plan).
     const char* le = getenv("DUALIP_HIP_SELL_LANES");
     const bool lanes_on = !(le && le[0] == '0');
