@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(uint32_t n_slices, const
 // An entry qualifies when it is a simplex kind and at least `min_share` of its non-zeros sit in columns of <= kSellMaxH
 // non-zeros (the rest of such an entry goes to single-column tiles: windows over the leftovers would stream mostly skipped data).
 // Slices run in ASCENDING length order.  Longest first (so that the last, partly filled round of the kernel's cyclic deal holds
-// the cheapest slices) was measured on one box, three repetitions each (tools/ab_sell.sh): 100M mixed 1.677-1.685 ms against
+// the cheapest slices) was measured on one box, three repetitions each (tools/ab.sh bench): 100M mixed 1.677-1.685 ms against
 // 1.654-1.660 ms ascending, 12.5M 0.224-0.230 against 0.221-0.224 -- slower.  DUALIP_HIP_SELL_ORDER=desc keeps it reachable.
 static bool sell_descending() {
     const char* e = getenv("DUALIP_HIP_SELL_ORDER");
