@@ -71,6 +71,12 @@ def parse():
                     "dist_utils.PROJECTION_COST of a box column); reference: the reference's count-balanced contiguous cuts n // W (+1); balanced: every rank takes "
                     "its share of every projection block (interleaved, not contiguous; run_solver: ComputeArgs(partition=\"balanced\")) -- the default: every rank "
                     "carries the same operator mix, which the fused pass streams fastest")
+    ap.add_argument("--no-partition-compare", action="store_true", help="N > 1: skip the extra window that times the OTHER split (the reference's n // W (+1) cut when "
+                    "--partition balanced, and vice versa) -- aux.partition.compared")
+    ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in THIS invocation: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a "
+                    "3-step run of the same workload as child processes, 2 x FETCH_SIZE + WRITE_SIZE KiB per fused launch (gfx950 corrections of "
+                    "MI355X_MICROARCH.md; calibration profiles/r02_fetch_size_calibration.json)")
+    ap.add_argument("--record-traffic", action="store_true", help="with --measure-traffic: store the figure, the commit and the kernel layout it belongs to in profiles/traffic.json")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="with --emulate-world: which rank's shard to hold (default: the most expensive one of the partition)")
     ap.add_argument("--force-sharded", action="store_true", help="take the N>1 code path (distributed objective + exchange) even with one rank")
     ap.add_argument("--emulate-world", type=int, default=0, help="developer aid: with --force-sharded and one rank, hold rank 0's shard of a W-rank run and "
@@ -269,6 +275,89 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
     return out
 
 
+TRAFFIC_LAYOUT_KEYS = ("tiles", "long_columns", "workgroup_columns", "slices", "slice_elements", "slice_lane_columns", "window_descriptor_words", "row_index_bytes", "hot_rows", "layout", "workgroups")
+
+
+def traffic_key(args, world):
+    key = f"{args.proj}_{args.entities}_{world}"
+    if args.sparsity != 1e-3 or args.destinations != 10_000:
+        key += f"_m{args.destinations}_s{args.sparsity:g}"
+    return key + ("_f64" if args.dtype == "f64" else "")
+
+
+def current_commit():
+    c = os.environ.get("DUALIP_COMMIT")
+    if c:
+        return c
+    try:
+        import subprocess
+
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+def stored_traffic(args, world, lay, phys_bytes):
+    """(bytes, source) from profiles/traffic.json, or (None, why not).  A record carries the kernel layout (dl_matching_info) it was
+    measured on and the commit; it is REFUSED when today's handle is laid out differently -- a layout change that keeps the bytes
+    within 10 % must not inherit yesterday's counters.  (Records of rounds 1-3 are bare numbers: accepted within 10 % of the
+    layout's bytes and labelled as unverifiable.)"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(tpath)).get(traffic_key(args, world))
+    except Exception:
+        rec = None
+    if rec is None:
+        return None, "no counter pass recorded for this configuration"
+    if isinstance(rec, dict):
+        diff = {k: (rec.get("layout", {}).get(k), lay.get(k)) for k in TRAFFIC_LAYOUT_KEYS if rec.get("layout", {}).get(k) != lay.get(k)}
+        if diff:
+            return None, f"the record of commit {rec.get('commit')} was taken on another kernel layout ({diff}): refused"
+        return float(rec["bytes"]), (f"profiles/traffic.json: rocprofv3 --pmc passes of this command at commit {rec.get('commit')} ({rec.get('file', 'bench.py --measure-traffic --record-traffic')}), "
+                                     "2 x FETCH_SIZE + WRITE_SIZE (gfx950 corrections), same kernel layout as this run")
+    if abs(float(rec) - phys_bytes) > 0.1 * phys_bytes:
+        return None, "the (round 1-3, layout-less) record is more than 10 % from this launch's bytes by construction: refused"
+    return float(rec), "profiles/traffic.json: rocprofv3 --pmc passes of this command in an earlier round (record without layout / commit: only checked to be within 10 % of the layout's bytes)"
+
+
+def measure_traffic_now():
+    """HBM bytes per fused launch measured NOW: this command line re-run (3 steps, no side legs) under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, as the guide prescribes), averaged over the fused kernel's dispatches.  Returns (bytes, details)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    drop = {"--measure-traffic", "--record-traffic"}
+    base = [a for a in sys.argv[1:] if a not in drop]
+    for flag in ("--steps", "--warmup"):  # (value flags the child gets its own of)
+        while flag in base:
+            i = base.index(flag)
+            del base[i:i + 2]
+    child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-late", "--no-verify", "--no-cpu-baseline"]
+    vals, details = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="dualip_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", DUALIP_BENCH_NO_EVENTS="1")
+            r = subprocess.run([rocprof, "--output-format", "csv", "--pmc", counter, "-d", tmp, "-o", "p", "--"] + child, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+            rows = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "matching_fused" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        rows.append(float(row["Counter_Value"]))
+            if not rows:
+                return None, {"error": f"no {counter} rows for the fused kernel (rocprofv3 exit {r.returncode}): {r.stderr[-300:]}"}
+            vals[counter] = sum(rows) / len(rows)
+            details[counter + "_KiB_per_launch"] = vals[counter]
+            details[counter + "_dispatches"] = len(rows)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, details
+
+
 def timed_window(run, local, comm, n_iters, fence, elapsed_max, stride=1):
     """Time `n_iters` iterations of a device run between two fences; returns (seconds [max over ranks], fused launches,
     fused-kernel ms, exchange brackets, exchange ms)."""
@@ -389,21 +478,26 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
         return v * float(emu) if emu else v
 
+    def make_shard(partition):
+        """This rank's columns under `partition` as nb kernel-handle inputs, with the capacity vector of the WHOLE problem."""
+        block_inputs, nnz_local, loads, rho, ranges_first = [], 0, None, None, None
+        for k in range(nb):  # (nb > 1: the shard as nb kernel handles, each with its share of every projection block)
+            ranges_k, pm_k = shard_plan(args.proj, n, vworld, vrank0 + k, CHUNK_COLS, partition)
+            ranges_first = ranges_k if k == 0 else ranges_first
+            prob_k = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_ranges=ranges_k)
+            prob_k["input_args"].projection_map = pm_k
+            block_inputs.append(prob_k["input_args"])
+            nnz_local += prob_k["nnz"]
+            loads = prob_k["loads_local"] if loads is None else loads + prob_k["loads_local"]
+            rho = prob_k["rho"]
+        # b = rho * (greedy load of the WHOLE problem + 1e-8): the m-sized loads are the only thing the shards of the generator share
+        b_vec = (torch.from_numpy(rho).to(device) * (reduce_loads(loads) + 1e-8)).to(tdt)
+        for bi in block_inputs:
+            bi.b_vec = b_vec
+        return block_inputs, nnz_local, b_vec, ranges_first
+
     t_gen = time.perf_counter()
-    block_inputs, nnz_local, loads, rho = [], 0, None, None
-    for k in range(nb):  # (nb > 1: the shard as nb kernel handles, each with its share of every projection block)
-        ranges_k, pm_k = shard_plan(args.proj, n, vworld, vrank0 + k, CHUNK_COLS, args.partition)
-        ranges_first = ranges_k if k == 0 else ranges_first
-        prob_k = generate_matching_problem(n, m, args.sparsity, seed=args.seed, device=device, dtype=tdt, col_ranges=ranges_k)
-        prob_k["input_args"].projection_map = pm_k
-        block_inputs.append(prob_k["input_args"])
-        nnz_local += prob_k["nnz"]
-        loads = prob_k["loads_local"] if loads is None else loads + prob_k["loads_local"]
-        rho = prob_k["rho"]
-    # b = rho * (greedy load of the WHOLE problem + 1e-8): the m-sized loads are the only thing the shards of the generator share
-    b_vec = (torch.from_numpy(rho).to(device) * (reduce_loads(loads) + 1e-8)).to(tdt)
-    for bi in block_inputs:
-        bi.b_vec = b_vec
+    block_inputs, nnz_local, b_vec, ranges_first = make_shard(args.partition)
     pm_local = block_inputs[0].projection_map
     inp = block_inputs[0]
     torch.cuda.synchronize()
@@ -458,22 +552,28 @@ def main():
     phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + (lay["tiles"] - lay["long_columns"]) * desc_bytes \
         + lay["long_columns"] * (48 if lay["layout"] == 4 else 16) + lay.get("slices", 0) * 16 + lay.get("slice_mixed_columns", 0) + lay["workgroups"] * (m * 8 + 16)
 
-    # roofline.traffic: HBM bytes per launch from the PMC counters when profiles/traffic.json holds this configuration (collected
-    # by rocprofv3 --pmc passes of this command on an earlier run), else what the launch moves by construction (phys_bytes)
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and not sharded:  # (the recorded passes are single-GPU runs of the whole problem)
-        try:
-            traffic = json.load(open(tpath)).get(f"{args.proj}_{args.entities}_{world}")
-        except Exception:
-            traffic = None
-    if traffic and abs(traffic - phys_bytes) > 0.1 * phys_bytes:  # not this launch (another layout / shard): fall back to the layout's bytes
-        traffic = None
-    if traffic:
-        traffic_source = "profiles/traffic.json: rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, gfx950 corrections) on an earlier run"
-    else:
+    # roofline.traffic: HBM bytes per launch from the PMC counters -- measured in this invocation (--measure-traffic), else the record
+    # of profiles/traffic.json IF it was taken on this very kernel layout, else what the launch moves by construction (phys_bytes)
+    traffic, traffic_source, traffic_details = None, None, None
+    if args.measure_traffic and not sharded and rank == 0:
+        traffic, traffic_details = measure_traffic_now()
+        if traffic:
+            traffic_source = f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (3 steps) at commit {current_commit()}, 2 x FETCH_SIZE + WRITE_SIZE KiB per launch"
+            if args.record_traffic:
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")
+                try:
+                    table = json.load(open(tpath))
+                except Exception:
+                    table = {}
+                table[traffic_key(args, world)] = {"bytes": traffic, "commit": current_commit(), "layout": {k: lay.get(k) for k in TRAFFIC_LAYOUT_KEYS},
+                                                   "by_construction": phys_bytes, "counters": traffic_details, "file": "bench.py --measure-traffic --record-traffic"}
+                json.dump(table, open(tpath, "w"), indent=1)
+    if not traffic and not sharded:  # (the recorded passes are single-GPU runs of the whole problem)
+        traffic, traffic_source = stored_traffic(args, world, lay, phys_bytes)
+    if not traffic:
+        why = traffic_source or "sharded run"
         traffic = float(phys_bytes)
-        traffic_source = "layout: bytes the launch moves by construction (no counter pass recorded for this configuration)"
+        traffic_source = f"layout: bytes the launch moves by construction ({why})"
     roof_bytes = float(traffic)
 
     def roof(kernel_ms, launches):
@@ -485,13 +585,30 @@ def main():
 
     # ---- headline: W untimed iterations from zero duals, then exactly K timed ----------------------------------
     total_iters = args.warmup + args.steps
-    solver = AcceleratedGradientDescent(max_iter=total_iters, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
-    run = solver.start_device_run(f, torch.zeros(m, dtype=tdt, device=device), rank=rank)
-    run.advance(args.warmup)
     stride = 4 if nnz_first > 400_000_000 else 8  # (bracket every 4th / 8th fused launch: see timed_window)
-    elapsed, launches, kernel_ms, xn, xms = timed_window(run, local, comm, args.steps, fence, elapsed_max, stride)
-    result = run.finish()
-    run.close()
+
+    def headline(f_, local_, comm_):
+        solver = AcceleratedGradientDescent(max_iter=total_iters, gamma=args.gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
+        run = solver.start_device_run(f_, torch.zeros(m, dtype=tdt, device=device), rank=rank)
+        try:
+            run.advance(args.warmup)
+            el, ln, kms, xn_, xms_ = timed_window(run, local_, comm_, args.steps, fence, elapsed_max, stride)
+            return el, ln, kms, xn_, xms_, run.finish()  # (finish() of a sharded run meets the ranks: a failed exchange raises on every rank)
+        finally:
+            run.close()
+
+    from dualip_amd.utils.comm import ExchangeError
+
+    try:
+        elapsed, launches, kernel_ms, xn, xms, result = headline(f, local, comm)
+    except ExchangeError as exc:
+        # first contact with real xGMI may show that the unfenced P2P ordering does not hold there: every exchange is checksummed, the
+        # ranks stop together, an `auto` communicator moves to the fenced ordering and the measurement is REPEATED -- the line says so
+        if comm is None or not comm.degrade():
+            raise
+        if collective is not None:
+            collective["repeated_after"] = str(exc)
+        elapsed, launches, kernel_ms, xn, xms, result = headline(f, local, comm)
     avg_kernel_s, achieved, achieved_alg = roof(kernel_ms, launches)
 
     # ---- the reference's whole solve (benchmark/config.py:16-18: max_iter 1000) and its late window ----------------
@@ -537,6 +654,38 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             verified["ok_all_ranks"] = bool(okt.item() > 0.5)
 
+    # ---- N > 1: the OTHER split of the entities, timed beside the one the line is quoted on ---------------------------------
+    # (the reference cuts contiguously at n // W (+1), dist_utils.py:53-57; the default here gives every rank its share of every
+    #  projection block.  A scaling curve quoted on one of them carries the other's per-rank time next to it.)
+    compared = None
+    if sharded and (world > 1 or emu) and not args.no_partition_compare:
+        other = "reference" if args.partition != "reference" else "balanced"
+        bi2, nnz2, b2, ranges2 = make_shard(other)
+        for bi in bi2:
+            bi.b_vec = None
+        f2 = MatchingSolverDualObjectiveFunctionDistributed(bi2 if nb > 1 else bi2[0], b2, args.gamma, host_device=device, comm_backend=args.comm)
+        comm2 = f2.communicator()
+        if emu and comm2 is not None:
+            comm2.set_emulation(float(emu))
+        el2, ln2, kms2, xn2, xms2, _res2 = headline(f2, f2.local_objective, comm2)
+        compared = {"kind": other, "ms_per_step": el2 / args.steps * 1e3, "iterations_per_s": args.steps / el2, "kernel_avg_ms": kms2 / max(ln2, 1),
+                    "this_rank_columns": [list(r) for r in ranges2], "this_rank_nnz": int(nnz2), "us_per_exchange": (xms2 / xn2 * 1e3) if xn2 else None,
+                    "backend": comm2.backend if comm2 is not None else "torch.distributed", "window": [args.warmup + 1, args.warmup + args.steps]}
+        if comm2 is not None:
+            comm2.close()
+        del f2, bi2, b2
+
+    # A launch whose bytes fit the 256 MB Infinity Cache is not bound by HBM at all (BASELINE config 2: 1M entities = 120 MB): its
+    # yardstick is what a plain streaming-read launch reaches over a buffer of THAT size on this box (launch included, best of 20)
+    cache_resident = None
+    if phys_bytes < (256 << 20) and rank == 0:
+        ws = max(1 << 20, int(phys_bytes) // 4096 * 4096)
+        ceil_ws = read_ceiling_gbps(device, nbytes=ws, reps=20)
+        cache_resident = {"working_set_bytes": ws, "note": "the launch's bytes fit the 256 MB Infinity Cache: the fraction of the HBM peak is not the yardstick; "
+                          "read_ceiling_GBps = dl_measure_read_bandwidth (one launch of the streaming-read probe) over a buffer of the same size, read repeatedly",
+                          "read_ceiling_GBps": ceil_ws, "kernel_GBps": achieved, "kernel_frac_of_ceiling": achieved / ceil_ws if ceil_ws > 0 else None,
+                          "ceiling_launch_us": ws / ceil_ws / 1e3 if ceil_ws > 0 else None, "kernel_launch_us": avg_kernel_s * 1e6}
+
     if rank == 0:
         out = {
             "metric": "dual_ascent_iterations_per_sec",
@@ -576,6 +725,7 @@ def main():
                 "event_stride": stride,
                 "physical_bytes_per_launch": phys_bytes,
                 "window": [args.warmup + 1, args.warmup + args.steps],
+                "frac_of_read_ceiling": None,
             },
             "aux": {
                 "generate_s": t_gen,
@@ -591,6 +741,8 @@ def main():
                     "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
                 },
                 "partition": {"kind": args.partition if sharded else None, "ranks": vworld,
+                              "ms_per_step": {args.partition: elapsed / args.steps * 1e3, **({compared["kind"]: compared["ms_per_step"]} if compared else {})} if sharded else None,
+                              "compared": compared,
                               "cost_model": "columns x dist_utils.PROJECTION_COST (simplex 1.14, point-wise 1.0)",
                               "estimated_imbalance_max_over_mean": {k: v["imbalance"] for k, v in ptable.items()},
                               "cuts": ptable[args.partition]["cuts"] if sharded else None,
@@ -602,8 +754,12 @@ def main():
                 "collective": collective,
                 "copy_ceiling_GBps": copy_ceiling_gbps(device),
                 "read_ceiling_GBps": read_ceiling_gbps(device),
+                "traffic_counters": traffic_details,
+                "cache_resident": cache_resident,
             },
         }
+        rc_gbps = out["aux"]["read_ceiling_GBps"]
+        out["roofline"]["frac_of_read_ceiling"] = achieved / rc_gbps if rc_gbps else None  # (same box, same run: what a plain streaming read reaches)
         if comm is not None:
             out["aux"]["collective"] = {**(collective or {}), **comm.info(), "emulated_world": emu or None, "emulated_rank": emu_rank if emu else None,
                                         "exchanges": comm.exchanges, "us_per_exchange": (xms / xn * 1e3) if xn else None,

@@ -43,11 +43,44 @@ def generate(n_users=138_493, n_movies=26_744, seed=7, device="cuda:0"):
     return A, C, counts
 
 
+LENGTH_CLASSES = [(1, 24), (25, 255), (256, 512), (513, 1024), (1025, 1 << 30)]  # one kernel plan each
+
+
+def stress_duals(m, device, seed=11):
+    """A dual vector that makes the projection work: prices of the order of a rating step on the popular movies (row index =
+    popularity rank in generate()), so thresholds fall between tied ratings and the Newton passes multiply."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lam = torch.rand(m, device=device, generator=g) * 3.0 / (1.0 + torch.arange(m, device=device) / 2000.0)
+    return lam.float()
+
+
+def verify(f, inp, gamma, lam, device):
+    """tests/helpers.verify_at_size (the checker bench.py runs at the benchmark size) on this problem, at the solve's duals and at
+    a stress dual vector: the oracle on slabs of columns -- incl. one slab around a column of every length class -- A x, c.x and
+    sum x^2 recomputed in float64 from the primal, the two-handle sharded route against the single objective."""
+    from tests.helpers import verify_at_size
+
+    ok = True
+    for tag, lv in (("solve's duals", lam), ("stress duals", stress_duals(lam.numel(), device))):
+        out = verify_at_size("f32", gamma, inp, inp.projection_map, f, f, lv.contiguous(), device=device, length_classes=LENGTH_CLASSES)
+        worst = max(out["checks"], key=lambda c: c["err"] / max(c["tol"], 1e-300))
+        print(f"verify ({tag}): {'ok' if out['ok'] else 'FAILED'}, {len(out['checks'])} checks, worst: {worst['name']} err {worst['err']:.3g} (tol {worst['tol']:g})")
+        for c in out["checks"]:
+            if not c["ok"]:
+                print("   FAILED", c)
+        ok = ok and out["ok"]
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-iter", type=int, default=1000)
     ap.add_argument("--capacity", type=float, default=30.0)
     ap.add_argument("--gamma", type=float, default=0.1)
+    ap.add_argument("--stress", action="store_true", help="start from stress_duals() instead of zero: the kernel's cost with prices that cut between tied ratings")
+    ap.add_argument("--no-verify", action="store_true", help="skip the checks against the CPU oracle after the solve (they are outside every timed region)")
     args = ap.parse_args()
     from dualip_amd.objectives.matching import MatchingInputArgs
     from dualip_amd.projections import create_projection_map
@@ -71,7 +104,7 @@ def main():
     print(f"objective built in {time.perf_counter() - t0:.3f}s: {f.info()}")
     solver = AcceleratedGradientDescent(max_iter=args.max_iter, gamma=args.gamma, initial_step_size=1e-8, max_step_size=1e-6, iteration_callback=False)
     t0 = time.perf_counter()
-    res = solver.maximize(f, torch.zeros(m, device=dev))
+    res = solver.maximize(f, stress_duals(m, dev) if args.stress else torch.zeros(m, device=dev))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if os.environ.get("DUALIP_HIP_TIMELINE"):
@@ -81,6 +114,8 @@ def main():
         us = (tl - tl[:, 0].min()) / 100.0
         d = us[:, 2] - us[:, 1]
         print(f"per-workgroup tile-loop duration of the last launch (us): min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f}; kernel span {us[:, 3].max():.0f}")
+    if not args.no_verify:
+        verify(f, inp, args.gamma, res.dual_val, dev)
     print(f"maximize: {args.max_iter} iterations in {dt:.3f}s ({args.max_iter / dt:.1f} iterations/s, {dt / args.max_iter * 1e3:.3f} ms each); dual objective "
           f"{res.dual_objective:.3f} (first {res.dual_objective_log[0]:.3f})")
 

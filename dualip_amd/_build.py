@@ -1,6 +1,7 @@
 """Builds libdualip_hip.so (the C-ABI HIP library, include/dualip_hip.h) in-tree with hipcc for gfx950."""
 import fcntl
 import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -105,6 +106,138 @@ def _spill_defects(asm_path: str):
     return out
 
 
+_SREG = __import__("re").compile(r"^s(\d+)$|^s\[(\d+):(\d+)\]$")
+# instructions whose FIRST operand is a scalar destination (everything s_* that writes, plus the lane reads)
+_NO_SDST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch", "s_barrier", "s_endpgm", "s_sleep", "s_setprio", "s_cmp", "s_bitcmp", "s_setreg", "s_sendmsg",
+            "s_store", "s_buffer_store", "s_dcache", "s_icache", "s_setpc", "s_trap", "s_sethalt", "s_inst_prefetch", "s_clause", "s_code_end", "s_set_gpr",
+            "s_ttrace", "s_waitcnt_depctr", "s_delay_alu", "s_wait_", "s_atc_probe", "s_version")
+
+
+def _sreg(tok):
+    """(lo, hi) of a scalar register operand ``sN`` / ``s[a:b]``, else None."""
+    m = _SREG.match(tok.strip().rstrip(","))
+    if not m:
+        return None
+    if m.group(1) is not None:
+        return int(m.group(1)), int(m.group(1))
+    return int(m.group(2)), int(m.group(3))
+
+
+def _sgpr_pair_defects(asm_path: str):
+    """The SECOND code-generation defect seen here (tools/gdb_fault.sh): a 64-bit value that was loaded as part of a
+    multi-dword scalar load (``s_load_dwordx4 s[52:55]``: the row stride in s[54:55]) had ONE HALF overwritten by an unrelated scalar
+    load (``s_load_dword s55``: gridDim.x) while the pair was still live; both registers were then spilled to adjacent VGPR lanes and
+    later reloaded AS A PAIR and used as a 64-bit operand -- 157 * 2^32 + 320 instead of the stride, a memory fault at best.
+    The screen walks every kernel's instructions in program order and reports a reload of two adjacent spill lanes into an adjacent
+    scalar pair that is then used as ``s[P:P+1]`` when, at spill time, the two source registers had been defined together by one
+    multi-register instruction and exactly one of them had since been redefined ALONE by a scalar memory load.  Text order, no
+    control-flow analysis: a heuristic that matches the observed miscompile and stays silent on the committed kernels."""
+    out, kernel = [], "?"
+    lastdef, lastop, group = {}, {}, {}   # per SGPR: index of the defining instruction, its mnemonic, (def index, lo, hi) of a multi-register definition
+    slot = {}                             # (vgpr, lane) -> (sreg, def index, op, group) at spill time
+    reloads = []                          # (idx, P, vgpr, lane, origin)
+    with open(asm_path, errors="replace") as fh:
+        lines = fh.read().split("\n")
+    instrs = []
+    for ln in lines:
+        t = ln.strip()
+        m = _KERNEL.match(t)
+        if m:
+            instrs.append(("kernel", m.group(1)))
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        if t:
+            instrs.append(("i", t))
+    pending = []  # suspicious reloaded pairs awaiting a 64-bit use: (P, description, expires at)
+    for idx, (kind, t) in enumerate(instrs):
+        if kind == "kernel":
+            kernel = t
+            lastdef, lastop, group, slot, pending = {}, {}, {}, {}, []
+            continue
+        parts = t.replace(",", " ").split()
+        op, ops = parts[0], parts[1:]
+        # a pending pair used as a 64-bit operand?
+        if pending:
+            keep = []
+            for P, desc, until in pending:
+                if f"s[{P}:{P + 1}]" in t and not (op.startswith("v_readlane") and False):
+                    out.append(f"{kernel} {desc}; the pair is then used as s[{P}:{P + 1}] by `{t}`")
+                    continue
+                if idx < until:
+                    keep.append((P, desc, until))
+            pending = keep
+        if op == "v_writelane_b32" and len(ops) >= 3:
+            sr, vreg = _sreg(ops[1]), ops[0]
+            if sr and ops[2].isdigit():
+                r = sr[0]
+                slot[(vreg, int(ops[2]))] = (r, lastdef.get(r), lastop.get(r), group.get(r))
+            continue
+        if op == "v_readlane_b32" and len(ops) >= 3:
+            sr = _sreg(ops[0])
+            if sr and ops[2].isdigit():
+                P, vreg, lane = sr[0], ops[1], int(ops[2])
+                org = slot.get((vreg, lane))
+                lo_org = slot.get((vreg, lane - 1))
+                # this reload completes an adjacent pair (P-1 <- lane-1 just before, P <- lane)?
+                prev = reloads[-1] if reloads else None
+                if org and lo_org and prev and prev[1] == P - 1 and prev[2] == vreg and prev[3] == lane - 1 and idx - prev[0] <= 4 and lo_org[0] + 1 == org[0]:
+                    (rl, dl, ol, gl), (rh, dh, oh, gh) = lo_org, org
+                    for whole, (rx, dx, ox) in ((gl, (rh, dh, oh)), (gh, (rl, dl, ol))):
+                        # `whole` = the multi-register definition one half still carries; the OTHER half (rx) was redefined alone, by a scalar load
+                        if whole and whole[1] <= rl and rh <= whole[2] and dx is not None and dx != whole[0] and dx > whole[0] and str(ox).startswith(("s_load_dword ", "s_load_dword", "s_buffer_load_dword")) \
+                                and not str(ox).startswith(("s_load_dwordx", "s_buffer_load_dwordx")):
+                            pending.append((P - 1, f"reloads s[{P - 1}:{P}] from lanes {lane - 1}/{lane} of {vreg}: s{rl}/s{rh} were defined together (registers s[{whole[1]}:{whole[2]}]) "
+                                                   f"but s{rx} had been overwritten alone by `{ox}` before the spill", idx + 400))
+                reloads.append((idx, P, vreg, lane, org))
+                lastdef[P], lastop[P] = idx, "reload"
+                group.pop(P, None)
+            continue
+        if op.startswith("s_") and not op.startswith(_NO_SDST) and ops:
+            sr = _sreg(ops[0])
+            if sr:
+                for r in range(sr[0], sr[1] + 1):
+                    lastdef[r], lastop[r] = idx, op
+                    if sr[1] > sr[0]:
+                        group[r] = (idx, sr[0], sr[1])
+                    else:
+                        group.pop(r, None)
+        elif op.startswith("v_readfirstlane") and ops:
+            sr = _sreg(ops[0])
+            if sr:
+                lastdef[sr[0]], lastop[sr[0]] = idx, op
+                group.pop(sr[0], None)
+    return out
+
+
+def _kernel_resources(asm_path: str):
+    """{mangled kernel name: {vgpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count, scratch_bytes, lds_bytes}} from the
+    ``.amdgpu_metadata`` block of one device assembly file (what the code object's notes record)."""
+    with open(asm_path, errors="replace") as fh:
+        text = fh.read()
+    a, b = text.find(".amdgpu_metadata"), text.find(".end_amdgpu_metadata")
+    if a < 0 or b < 0:
+        return {}
+    import yaml
+
+    body = text[text.index("\n", a) + 1:b]
+    end = body.rfind("\n...")  # (the YAML document's end marker; what follows is the assembler directive's own indentation)
+    meta = yaml.safe_load(body[:end] if end >= 0 else body) or {}
+    out = {}
+    for k in meta.get("amdhsa.kernels", []):
+        out[k.get(".name", "?")] = {"vgpr_count": k.get(".vgpr_count"), "agpr_count": k.get(".agpr_count"), "sgpr_count": k.get(".sgpr_count"),
+                                    "vgpr_spill_count": k.get(".vgpr_spill_count", 0), "sgpr_spill_count": k.get(".sgpr_spill_count", 0),
+                                    "scratch_bytes": k.get(".private_segment_fixed_size", 0), "lds_bytes": k.get(".group_segment_fixed_size", 0)}
+    return out
+
+
+# the benchmark's instantiation -- matching_fused_kernel4<float, unsigned short, LAM_LDS, GRAD_LDS, !HOT, !FAIR, !LANES> -- must not touch
+# scratch: a VGPR spill in its hot loop costs the headline several per cent, and its registers are what the second defect went through
+BENCHMARK_KERNEL = "_ZN2dl22matching_fused_kernel4IftLb1ELb1ELb0ELb0ELb0EEEvNS_9FusedArgsIT_EE"
+MANIFEST_PATH = os.path.join(LIB_DIR, "build_manifest.json")
+
+
 def _compile_objects(verbose: bool):
     """One object per source, compiled in parallel and kept by content hash: editing one file rebuilds one object."""
     from concurrent.futures import ThreadPoolExecutor
@@ -117,7 +250,7 @@ def _compile_objects(verbose: bool):
     for name in SOURCES:
         obj = os.path.join(obj_dir, f"{os.path.splitext(name)[0]}.{_object_hash(name)}.o")
         objs.append(obj)
-        if not os.path.exists(obj):
+        if not os.path.exists(obj) or not os.path.exists(obj + ".json"):
             jobs.append((name, obj))
 
     def one(job):
@@ -135,14 +268,32 @@ def _compile_objects(verbose: bool):
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 return name, r.stdout + r.stderr
-            found = []
+            found, pairs, resources, scanned = [], [], {}, 0
             for f in sorted(os.listdir(work)):
                 if f.endswith(".s") and "amdgcn" in f:
+                    scanned += 1
                     found += _spill_defects(os.path.join(work, f))
-            if found and os.environ.get("DUALIP_BUILD_ALLOW_SPILL_DEFECT", "0") in ("", "0"):
+                    pairs += _sgpr_pair_defects(os.path.join(work, f))
+                    resources.update(_kernel_resources(os.path.join(work, f)))
+            allow = os.environ.get("DUALIP_BUILD_ALLOW_SPILL_DEFECT", "0") not in ("", "0")
+            if not scanned and not allow:  # the screens must not pass because there was nothing to look at
+                return name, ("--save-temps=obj left no '*amdgcn*.s' device assembly beside the object (another toolchain's naming?): the code-generation "
+                              "screens of dualip_amd/_build.py cannot run; set DUALIP_BUILD_ALLOW_SPILL_DEFECT=1 to build unscreened")
+            if found and not allow:
                 return name, ("hipcc placed a VGPR spill ahead of the exec restore of a control-flow join (lanes that skipped the branch never store "
                               "their value and reload garbage -- DESIGN.md section 8, tools/spill_exec_check.py):\n  " + "\n  ".join(found) +
                               "\nchange the register pressure of that kernel (or set DUALIP_BUILD_ALLOW_SPILL_DEFECT=1 to build anyway)")
+            if pairs and not allow:
+                return name, ("hipcc reloads a 64-bit scalar pair from spill lanes after one half was overwritten by an unrelated scalar load (the stride-in-"
+                              "s[54:55] miscompile, DESIGN.md section 3.1b):\n  " + "\n  ".join(pairs) +
+                              "\nre-read that value from the kernel arguments where it is used (or set DUALIP_BUILD_ALLOW_SPILL_DEFECT=1 to build anyway)")
+            bench = resources.get(BENCHMARK_KERNEL)
+            if bench and (bench["vgpr_spill_count"] or bench["scratch_bytes"]) and not allow:
+                return name, (f"the benchmark instantiation of the fused kernel uses scratch ({bench}): its hot loop must stay in registers "
+                              "(DUALIP_BUILD_ALLOW_SPILL_DEFECT=1 builds anyway)")
+            with open(tmp + ".json", "w") as fh:
+                json.dump({"source": name, "screened_assembly_files": scanned, "spill_before_exec_restore": found, "sgpr_pair_half_redefined": pairs, "kernels": resources}, fh)
+            os.replace(tmp + ".json", obj + ".json")
             os.replace(tmp, obj)
             return name, None
         finally:
@@ -156,11 +307,22 @@ def _compile_objects(verbose: bool):
     keep = set(objs)
     for f in os.listdir(obj_dir):  # objects of older source states
         full = os.path.join(obj_dir, f)
-        if f.endswith(".o") and full not in keep:
+        if (f.endswith(".o") and full not in keep) or (f.endswith(".o.json") and full[:-5] not in keep):
             try:
                 os.remove(full)
             except OSError:
                 pass
+    # what the screens saw, per kernel: registers, spills, scratch (from the code object's metadata) -- checked by tests/test_host_api.py
+    manifest = {"flags": FLAGS, "benchmark_kernel": BENCHMARK_KERNEL, "objects": []}
+    for obj in objs:
+        try:
+            with open(obj + ".json") as fh:
+                manifest["objects"].append(json.load(fh))
+        except OSError:  # an object of an older build of this file (no record beside it): rebuild it next time
+            manifest["objects"].append({"source": os.path.basename(obj), "screened_assembly_files": 0, "kernels": {}})
+    with open(MANIFEST_PATH + ".tmp", "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    os.replace(MANIFEST_PATH + ".tmp", MANIFEST_PATH)
     return hipcc, objs
 
 

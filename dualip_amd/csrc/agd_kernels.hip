@@ -100,6 +100,7 @@ struct StatsArgs {
     int n_packed;
     // ... or this rank's mailbox of the P2P exchange (comm.h): the kernel waits for every rank's slot and adds them in rank order
     MailArgs mail;
+    unsigned long long* chk_partial;  // [gridDim.x + 2]: hash sums of what each block read from the mailbox, of the two scalars, and the announced total
     double scale;                     // developer aid (dl_comm_set_emulation): factor on the exchanged sums
     double* packed_out;               // [m+2]: A x and the two scalars as this step used them (kept for logging / callers; may alias packed_in[0])
     const T* __restrict__ b;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     constexpr bool FROM_SLABS = SRC == 1;
     __shared__ long long shi[kStatRows * kStatSlices];
     const int tid = threadIdx.x;
-    if constexpr (SRC == 2) mail_wait(p.mail);
+    unsigned long long chk_expected = 0ull, chk_read = 0ull;
+    if constexpr (SRC == 2) chk_expected = mail_wait(p.mail);
     const int rl = tid & (kStatRows - 1);
     const int ws = tid / kStatRows;
     const int64_t col = (int64_t)blockIdx.x * kStatRows + rl;  // slab column
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
     } else {
         if (ws == 0 && live) {
             if constexpr (SRC == 2) {
-                ax = mail_sum(p.mail, row) * p.scale;
+                ax = mail_sum(p.mail, row, chk_read) * p.scale;
             } else {
                 ax = p.packed_in[0][row];
                 for (int k = 1; k < p.n_packed; ++k) ax += p.packed_in[k][row];
@@ -170,15 +172,20 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
             p.packed_out[row] = ax;
         }
         if (blockIdx.x == 0 && tid == kStatRows) {  // the two scalars (c.x, sum x^2), by a thread without a row
+            unsigned long long chk_scal = 0ull;
             for (int64_t i = p.m; i < p.m + 2; ++i) {
                 double v;
                 if constexpr (SRC == 2) {
-                    v = mail_sum(p.mail, i);
+                    v = mail_sum(p.mail, i, chk_scal);
                 } else {
                     v = p.packed_in[0][i];
                     for (int k = 1; k < p.n_packed; ++k) v += p.packed_in[k][i];
                 }
                 p.packed_out[i] = v * p.scale;
+            }
+            if constexpr (SRC == 2) {
+                p.chk_partial[gridDim.x] = chk_scal;
+                p.chk_partial[gridDim.x + 1] = chk_expected;
             }
         }
     }
@@ -206,6 +213,10 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
         g2 = wave_allreduce_dpp(g2, OpAdd());
         dg2 = wave_allreduce_dpp(dg2, OpAdd());
         dy2 = wave_allreduce_dpp(dy2, OpAdd());
+        if constexpr (SRC == 2) {  // what this block read from the mailbox, hashed: the step that consumes the statistics adds the blocks up
+            chk_read = (unsigned long long)wave_allreduce((long long)chk_read, OpAdd());  // and compares with the announced total (agd_step.h)
+            if (tid == 0) p.chk_partial[blockIdx.x] = chk_read;
+        }
         if (tid == 0) {
             double* o = p.partial_stats + (int64_t)blockIdx.x * kStatCols;
             o[0] = dvtg;
@@ -489,6 +500,8 @@ static int agd_stats_typed(dl_agd* s, const StepSource& src, const void* b, hipS
         for (int k = 0; k < 4; ++k) sa.packed_in[k] = k < src.n_packed ? src.packed[k] : nullptr;
         sa.n_packed = src.n_packed;
         if (src.mail) sa.mail = *src.mail;
+        sa.chk_partial = s->chk_partial;
+        s->chk_dead = src.mail ? src.mail->dead : nullptr;  // (the step that consumes these statistics verifies the exchange)
         sa.scale = src.scale;
         sa.packed_out = s->packed;
         sa.b = (const T*)b;

@@ -45,6 +45,10 @@ struct ApplyArgs {
     int64_t iter;
     T* __restrict__ x_perm;              // or null
     const int32_t* __restrict__ perm;    // caller's row -> renumbered row
+    // P2P exchange (comm.h): hash sums of what the stats launch read from the mailbox -- [n_blocks] per block, then the two scalars',
+    // then the total the senders announced -- and the communicator's sticky error word; null when the sums came from elsewhere
+    const unsigned long long* chk;
+    int* chk_dead;
 };
 
 // The scalars of the step, identical in every wavefront that calls it: sums the stats partials in a fixed order (no LDS, no
@@ -116,6 +120,13 @@ __device__ __forceinline__ double agd_step_scalars(const ApplyArgs<T>& p, int la
             const double cand = lmax != 0.0 ? 1.0 / lmax : si.max_step;
             step = cand < si.max_step ? cand : si.max_step;
         }
+    }
+    if (writer && tid < 64 && p.chk) {  // (wave-uniform: one wavefront of one workgroup) did the exchange deliver what its senders announced?
+        unsigned long long got = 0ull;
+        for (int k = lane; k < p.n_blocks + 1; k += 64) got += p.chk[k];
+        got = (unsigned long long)wave_allreduce((long long)got, OpAdd());
+        const unsigned long long expected = p.chk[p.n_blocks + 1];
+        if (lane == 0 && ((got - expected) & ((1ull << 40) - 1ull)) != 0ull && *p.chk_dead == 0) *p.chk_dead = 2;  // comm.h: kDeadChecksum
     }
     if (writer && tid < kLipsMax) p.st_out->lips[tid] = ring_new;
     if (writer && tid == 0) {
@@ -197,6 +208,8 @@ inline ApplyArgs<T> make_apply_args(const dl_agd* s, const PendingStep& ps) {
     aa.iter = ps.iter;
     aa.x_perm = nullptr;
     aa.perm = nullptr;
+    aa.chk = (s->chk_dead && n_blocks > 0) ? s->chk_partial : nullptr;
+    aa.chk_dead = s->chk_dead;
     return aa;
 }
 // after a step has been applied (by the apply kernel or by a fused launch's prologue): the buffer that received y_i becomes y,

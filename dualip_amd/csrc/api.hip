@@ -1039,7 +1039,7 @@ int dl_dual_epilogue(int64_t m, int val_dtype, const double* packed, const void*
 // ---------------------------------------------------------------------------------------------------------
 static void agd_free(dl_agd* s) {
     if (!s) return;
-    void* ptrs[] = {s->x, s->x_alt, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats, s->packed_blk[0], s->packed_blk[1], s->packed_blk[2]};
+    void* ptrs[] = {s->x, s->x_alt, s->y, s->y_old, s->g, s->g_old, s->beta, s->log, s->state, s->packed, s->partial_stats, s->chk_partial, s->packed_blk[0], s->packed_blk[1], s->packed_blk[2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -1071,6 +1071,7 @@ int dl_agd_create(dl_agd** out, int64_t m, int val_dtype, int64_t max_iter, cons
     if (e == hipSuccess) e = hipMalloc(&s->state, agd_state_bytes());
     if (e == hipSuccess) e = hipMalloc((void**)&s->packed, sizeof(double) * (size_t)(m + 2));
     if (e == hipSuccess) e = hipMalloc((void**)&s->partial_stats, agd_partial_stats_bytes(m));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->chk_partial, sizeof(unsigned long long) * (size_t)((m + 63) / 64 + 2));
     if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->x, lambda0, vb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && m > 0) e = hipMemcpyAsync(s->y, lambda0, vb, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(s->y_old, 0, vb, st);

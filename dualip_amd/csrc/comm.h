@@ -22,14 +22,45 @@ constexpr int kMaxWorld = 16;          // ranks of one node (8 on an MI355X node
 constexpr int kFlagStride = 8;         // one 64-byte line per flag word (uint64 units)
 constexpr size_t kMailHeaderBytes = 2 * kMaxWorld * kFlagStride * sizeof(unsigned long long);  // flags [2][kMaxWorld]
 
+// ---- payload checksum (round 4) ----
+// A flag word carries, besides the sequence number of the exchange it announces, a 40-bit checksum of the slot's payload:
+//     flag = checksum << 24 | (seq mod 2^24),      checksum = sum_i hash40(bits of element i)  mod 2^40.
+// One 64-bit store, so the checksum arrives WITH the flag and costs the writer no extra round trip: every pushing block adds the
+// hashes of what it stored to the upper 40 bits of the same 64-bit arrival counter whose lower 24 bits count the blocks (one
+// atomic per block, as before); the last arriver reads the total off the returned value.  The reader hashes what it actually
+// loaded and compares (stats kernel: per-block partial sums, compared by the step that consumes them -- no atomic, no extra
+// launch; stand-alone all-reduce: a ticket).  A mismatch sets the communicator's sticky `dead` word to kDeadChecksum: data that
+// arrived after its flag (the ordering the unfenced variant relies on, violated), a torn or corrupted slot, a stale slot of the
+// same parity (the checksum of exchange seq - 2 does not carry seq's flag: the flag's sequence field differs, and a slot that is
+// stale in part hashes differently unless the stale values equal the new ones -- in which case nothing is wrong).
+constexpr int kSeqBits = 24;
+constexpr unsigned long long kSeqMask = (1ull << kSeqBits) - 1ull;
+constexpr unsigned long long kChkMask = (1ull << 40) - 1ull;
+constexpr int kDeadTimeout = 1, kDeadChecksum = 2;
+__host__ __device__ inline unsigned long long chk_hash(double v) {
+    unsigned long long b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (unsigned long long)__double_as_longlong(v);
+#else
+    __builtin_memcpy(&b, &v, sizeof(b));
+#endif
+    return (b * 0x9E3779B97F4A7C15ull) >> 24;  // top 40 bits of a multiplicative hash: every input bit reaches them
+}
+__host__ __device__ inline unsigned long long flag_word(unsigned long long seq, unsigned long long chk) { return ((chk & kChkMask) << kSeqBits) | (seq & kSeqMask); }
+// has the flag reached exchange `seq`?  (modular: ranks are never 2^23 exchanges apart; a zeroed mailbox reads as "exchange 0")
+__host__ __device__ inline bool flag_arrived(unsigned long long flag, unsigned long long seq) { return ((flag - seq) & kSeqMask) < (1ull << (kSeqBits - 1)); }
+__host__ __device__ inline unsigned long long flag_chk(unsigned long long flag) { return (flag >> kSeqBits) & kChkMask; }
+
 // Where one rank's sums go: slot (parity, my rank) of every rank's mailbox.
 struct PushArgs {
     double* dst[kMaxWorld];               // slot base in rank r's mailbox
     unsigned long long* flag[kMaxWorld];  // its flag word
     int world;
     unsigned long long seq;
-    unsigned int* counter;                // arrival counter of the pushing launch (device memory, zero between launches)
+    unsigned long long* counter;          // arrival counter of the pushing launch (device memory, zero between launches): blocks in bits 0..23, checksum above
     int fenced;                           // 1: the by-the-book variant (system-scope release / acquire fences around the flags)
+    int fault;                            // test hook (dl_comm_inject_fault), this exchange only: 0 none, 1 element 0 of the slot in rank `fault_rank`'s
+    int fault_rank;                       //   mailbox is stored with a flipped bit, 2 the data stores to that rank are dropped (its slot stays stale)
 };
 
 // What a rank reads: its own mailbox of the parity.
@@ -42,6 +73,7 @@ struct MailArgs {
     int* dead;                            // sticky: a wait timed out (the run's results are invalid)
     unsigned long long timeout_ticks;     // 100 MHz wall clock
     int fenced;                           // see PushArgs
+    unsigned long long* ticket;           // stand-alone gather only: arrival counter + checksum of what the gathering launch loaded
 };
 
 // Memory-ordering rules of the exchange.  Two variants, chosen per communicator (dl_comm_set_fenced; the creation-time soak test
@@ -65,54 +97,80 @@ struct MailArgs {
 // system-scope release fence after its data stores, the arrival counter is an acq_rel atomic, the last arriver releases again
 // before the flag stores; the reader's poll is followed by a system-scope acquire fence in every thread.  Slow (the measured
 // 61 us) and always correct by the book; the fallback when the soak test of the default variant fails on a machine.
-__device__ __forceinline__ void push_value(const PushArgs& p, int64_t i, double v) {
-    for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.dst[r] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// `h` accumulates the hashes of what this thread pushed (handed to push_finish).
+__device__ __forceinline__ void push_value(const PushArgs& p, int64_t i, double v, unsigned long long& h) {
+    h += chk_hash(v);
+    for (int r = 0; r < p.world; ++r) {
+        double vs = v;
+        if (p.fault && r == p.fault_rank) {  // (test hook: cold)
+            if (p.fault == 2) continue;
+            if (i == 0) vs = __longlong_as_double(__double_as_longlong(v) ^ 0x0000000100000000ll);
+        }
+        __hip_atomic_store(p.dst[r] + i, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-// Called by EVERY thread of EVERY block of the pushing launch after its push_value calls.
-__device__ __forceinline__ void push_finish(const PushArgs& p) {
+// Called by EVERY thread of EVERY block of the pushing launch after its push_value calls, with the thread's hash sum.
+__device__ __forceinline__ void push_finish(const PushArgs& p, unsigned long long h) {
+    __shared__ unsigned long long push_h;
+    if (threadIdx.x == 0) push_h = 0ull;
+    __syncthreads();
+    h = (unsigned long long)wave_allreduce((long long)h, OpAdd());
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(&push_h, h);  // (LDS; integer sums: any order)
     if (p.fenced) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope: HIP's default for __atomic_thread_fence)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have landed
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned int old;
-        if (p.fenced) old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        else old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == gridDim.x) {  // last arriver: every block's data is in place
-            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (stream ordered)
+        const unsigned long long add = ((push_h & kChkMask) << kSeqBits) | 1ull;  // (a carry out of the top drops: arithmetic mod 2^40 up there)
+        unsigned long long old;
+        if (p.fenced) old = __hip_atomic_fetch_add(p.counter, add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        else old = __hip_atomic_fetch_add(p.counter, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long now = old + add;
+        if ((now & kSeqMask) == (unsigned long long)gridDim.x) {  // last arriver: every block's data is in place
+            __hip_atomic_store(p.counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch (stream ordered)
+            const unsigned long long word = flag_word(p.seq, now >> kSeqBits);
             if (p.fenced) {
-                for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
-                for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int r = 0; r < p.world; ++r) __hip_atomic_store(p.flag[r], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
 }
 
-// Whole block: returns once every rank's slot of this exchange has arrived (or the wait timed out: *dead = 1).
-__device__ __forceinline__ void mail_wait(const MailArgs& a) {
+// Whole block: returns once every rank's slot of this exchange has arrived (or the wait timed out: *dead = kDeadTimeout).
+// Returns (to every thread) the sum of the slots' announced checksums: what the hashes of everything read from them must add up to.
+__device__ __forceinline__ unsigned long long mail_wait(const MailArgs& a) {
+    __shared__ unsigned long long mail_expected;
+    if (threadIdx.x == 0) mail_expected = 0ull;
+    __syncthreads();
     if ((int)threadIdx.x < a.world) {
         if (__hip_atomic_load(a.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             const unsigned long long* f = a.flags + (size_t)threadIdx.x * kFlagStride;
-            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            unsigned long long word = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!flag_arrived(word, a.seq)) {
                 const unsigned long long t0 = wall_clock64();
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+                while (!flag_arrived(word = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), a.seq)) {
                     __builtin_amdgcn_s_sleep(2);
                     if (wall_clock64() - t0 > a.timeout_ticks) {
-                        __hip_atomic_store(a.dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.dead, kDeadTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
             }
+            // (the word read is exchange seq's own: a writer one exchange ahead raises the OTHER parity's flag, and none can be two ahead)
+            atomicAdd(&mail_expected, flag_chk(word));
         }
     }
     __syncthreads();
     if (a.fenced) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return mail_expected & kChkMask;
 }
 
-// Sum of element i over the ranks' slots, in rank order (identical on every rank).  All loads of a batch of eight ranks are
-// in flight before the first is added: the mailbox is uncached, every load is a memory round trip.
-__device__ __forceinline__ double mail_sum(const MailArgs& a, int64_t i) {
+// Sum of element i over the ranks' slots, in rank order (identical on every rank); `h` accumulates the hashes of the loaded
+// values.  All loads of a batch of eight ranks are in flight before the first is added: the mailbox is uncached, every load is a
+// memory round trip.
+__device__ __forceinline__ double mail_sum(const MailArgs& a, int64_t i, unsigned long long& h) {
     double acc = 0.0;
     for (int r0 = 0; r0 < a.world; r0 += 8) {
         double v[8];
@@ -122,9 +180,18 @@ __device__ __forceinline__ double mail_sum(const MailArgs& a, int64_t i) {
             v[u] = __hip_atomic_load(a.slots + (int64_t)r * a.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (r0 + u < a.world) ? v[u] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+            acc += (r0 + u < a.world) ? v[u] : 0.0;
+            h += (r0 + u < a.world) ? chk_hash(v[u]) : 0ull;
+        }
     }
     return acc;
+}
+
+// Verdict on one exchange: `got` = sum of the hashes of everything the reader loaded, `expected` = mail_wait's return.
+__device__ __forceinline__ void mail_judge(int* dead, unsigned long long got, unsigned long long expected) {
+    if (((got - expected) & kChkMask) != 0ull && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(dead, kDeadChecksum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace dl
@@ -149,8 +216,10 @@ struct dl_comm {
     bool connected = false;
     bool fenced = false;                          // the by-the-book variant of the protocol (see the ordering rules above)
     unsigned long long seq = 0;                   // exchanges issued
-    unsigned int* counter = nullptr;              // owned
-    int* dead = nullptr;                          // owned
+    unsigned long long* counter = nullptr;        // owned: [0] the pushing launches' arrival counter + checksum, [1] the stand-alone gather's ticket
+    int* dead = nullptr;                          // owned: 0, kDeadTimeout or kDeadChecksum (sticky)
+    int fault_kind = 0, fault_rank = 0;           // test hook (dl_comm_inject_fault): applied to exchange fault_seq, once
+    unsigned long long fault_seq = 0;
     unsigned long long timeout_ticks = 2000000000ull;  // 20 s at 100 MHz
     double* scratch = nullptr;                    // owned, double[stride]: result staging of the stand-alone all-reduce
     // measurement (dl_comm_profile): event pairs around the exchanges of dl_agd_run_matching_sharded

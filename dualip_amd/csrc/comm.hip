@@ -82,6 +82,13 @@ PushArgs comm_push_args(dl_comm* c, unsigned long long seq) {
     p.seq = seq;
     p.counter = c->counter;
     p.fenced = c->fenced ? 1 : 0;
+    p.fault = 0;
+    p.fault_rank = 0;
+    if (c->fault_kind && c->fault_seq == seq) {  // test hook: this exchange only
+        p.fault = c->fault_kind;
+        p.fault_rank = c->fault_rank;
+        c->fault_kind = 0;
+    }
     return p;
 }
 MailArgs comm_mail_args(dl_comm* c, unsigned long long seq) {
@@ -95,19 +102,38 @@ MailArgs comm_mail_args(dl_comm* c, unsigned long long seq) {
     a.dead = c->dead;
     a.timeout_ticks = c->timeout_ticks;
     a.fenced = c->fenced ? 1 : 0;
+    a.ticket = c->counter ? c->counter + 1 : nullptr;
     return a;
 }
 
 // stand-alone all-reduce, P2P: push the buffer, then gather the sum back into it
 __global__ __launch_bounds__(256) void p2p_push_kernel(const double* __restrict__ src, int64_t count, PushArgs p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) push_value(p, i, src[i]);
-    push_finish(p);
+    unsigned long long h = 0ull;
+    if (i < count) push_value(p, i, src[i], h);
+    push_finish(p, h);
 }
+// (the gathering launch checks what it loaded against the slots' announced checksums with a ticket: its last block to arrive
+//  compares -- not the hot path; the solver loop's reader does the same without an atomic, agd_kernels.hip)
 __global__ __launch_bounds__(256) void p2p_gather_kernel(double* __restrict__ dst, int64_t count, MailArgs a, double scale) {
-    mail_wait(a);
+    const unsigned long long expected = mail_wait(a);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) dst[i] = mail_sum(a, i) * scale;
+    unsigned long long h = 0ull;
+    if (i < count) dst[i] = mail_sum(a, i, h) * scale;
+    __shared__ unsigned long long gather_h;
+    if (threadIdx.x == 0) gather_h = 0ull;
+    __syncthreads();
+    h = (unsigned long long)wave_allreduce((long long)h, OpAdd());
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(&gather_h, h);
+    __syncthreads();
+    if (threadIdx.x == 0 && a.ticket) {
+        const unsigned long long add = ((gather_h & kChkMask) << kSeqBits) | 1ull;
+        const unsigned long long now = __hip_atomic_fetch_add(a.ticket, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((now & kSeqMask) == (unsigned long long)gridDim.x) {
+            __hip_atomic_store(a.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mail_judge(a.dead, now >> kSeqBits, expected);
+        }
+    }
 }
 
 int comm_push_buffer(const double* src, int64_t count, const PushArgs& push, hipStream_t st) {
@@ -286,8 +312,8 @@ int dl_comm_p2p_begin(dl_comm** out, int32_t world, int32_t rank, int64_t max_co
         e = hipExtMallocWithFlags(&c->mail, c->mail_bytes, hipDeviceMallocFinegrained);
     }
     if (e == hipSuccess) e = hipMemset(c->mail, 0, c->mail_bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(c->counter, 0, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->counter, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&c->scratch, sizeof(double) * (size_t)c->stride);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     hipIpcMemHandle_t hd;
@@ -333,6 +359,17 @@ int64_t dl_comm_info(const dl_comm* c, int what) {
         case 3: return (int64_t)c->seq;
         case 4: return c->max_count;
         case 5: return c->fenced ? 1 : 0;
+        case 6: return c->device;  // the HIP device ordinal the communicator was created on
+        case 7: {                  // ranks the RCCL communicator itself reports (-1: not an RCCL communicator)
+            int n = -1;
+            if (c->backend == DL_COMM_RCCL && c->nccl && g_rccl.CommCount && g_rccl.CommCount(c->nccl, &n) != 0) n = -1;
+            return n;
+        }
+        case 8: {                  // this rank as the RCCL communicator reports it
+            int r = -1;
+            if (c->backend == DL_COMM_RCCL && c->nccl && g_rccl.CommUserRank && g_rccl.CommUserRank(c->nccl, &r) != 0) r = -1;
+            return r;
+        }
         default: return -1;
     }
 }
@@ -340,6 +377,15 @@ int64_t dl_comm_info(const dl_comm* c, int what) {
 int dl_comm_set_emulation(dl_comm* c, double scale) {
     if (!c || !(scale > 0.0)) return fail(DL_E_ARG, "bad argument");
     c->emu_scale = scale;
+    return 0;
+}
+
+int dl_comm_inject_fault(dl_comm* c, int32_t kind, int32_t target_rank, uint64_t at_exchange) {
+    if (!c || c->backend != DL_COMM_P2P) return fail(DL_E_ARG, "fault injection needs a P2P communicator");
+    if (kind < 0 || kind > 2 || target_rank < 0 || target_rank >= c->world) return fail(DL_E_ARG, "bad fault description");
+    c->fault_kind = kind;
+    c->fault_rank = target_rank;
+    c->fault_seq = at_exchange;
     return 0;
 }
 
@@ -354,7 +400,7 @@ int dl_comm_reset(dl_comm* c, dl_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     DL_HIP(hipStreamSynchronize(st));
     DL_HIP(hipMemsetAsync(c->dead, 0, sizeof(int), st));
-    if (c->counter) DL_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned int), st));
+    if (c->counter) DL_HIP(hipMemsetAsync(c->counter, 0, 2 * sizeof(unsigned long long), st));
     DL_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -404,11 +450,23 @@ int dl_comm_set_timeout_ms(dl_comm* c, int64_t ms) {
     return 0;
 }
 
+int dl_comm_status(dl_comm* c, int32_t* dead_out_host, dl_stream_t stream) {
+    if (!c || !dead_out_host) return fail(DL_E_ARG, "null argument");
+    int dead = 0;
+    DL_HIP(hipMemcpyAsync(&dead, c->dead, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *dead_out_host = dead;
+    return 0;
+}
+
 int dl_comm_check(dl_comm* c, dl_stream_t stream) {
     if (!c) return fail(DL_E_ARG, "null communicator");
     int dead = 0;
     DL_HIP(hipMemcpyAsync(&dead, c->dead, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     DL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (dead == kDeadChecksum)
+        return fail(DL_E_STATE, "a P2P exchange delivered a slot whose payload does not match the checksum its sender announced (data behind its flag, "
+                                "a torn or corrupted slot): the results of this run are invalid%s", c->fenced ? "" : " -- DUALIP_COMM=p2p-fenced or rccl orders the exchange by the book");
     if (dead) return fail(DL_E_STATE, "a P2P exchange timed out waiting for another rank's partial sums: the results of this run are invalid");
     return 0;
 }

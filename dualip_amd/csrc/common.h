@@ -171,4 +171,6 @@ struct dl_agd {
     double* packed = nullptr;  // owned scratch double[m+2]: the sums the latest step used
     double* packed_blk[3] = {nullptr, nullptr, nullptr};  // owned, lazily: reduced sums of the further blocks of a split shard
     double* partial_stats = nullptr;  // owned: per-workgroup partial reductions of the step kernel
+    unsigned long long* chk_partial = nullptr;  // owned, [stats blocks + 2]: hash sums of what the stats launch read from a P2P mailbox (comm.h)
+    int* chk_dead = nullptr;          // the communicator's sticky error word when the latest statistics came from a mailbox, else null
 };

@@ -284,10 +284,11 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
                                                                       const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
                                                                       int accumulate) {
+    unsigned long long pushed_h = 0ull;  // hashes of what this thread pushed (comm.h: the payload checksum the flag will carry)
     auto emit = [&](int64_t i, double v) {
         if constexpr (MODE == 0) packed[i] = v;
         else if constexpr (MODE == 1) packed[i] += v;
-        else push_value(push, i, accumulate ? packed[i] + v : v);
+        else push_value(push, i, accumulate ? packed[i] + v : v, pushed_h);
     };
     __shared__ long long shi[kRedThreads];
     __shared__ double sh[kRedThreads / 32];
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
             const int64_t orow = inv ? (int64_t)inv[row] : row;
             emit(orow, (dense && orow >= m - 2) ? dense[orow - (m - 2)] : ldexp((double)t, -(*shift_in)));  // (fairness pair: the two dense rows)
         }
-        if constexpr (MODE == 2) push_finish(push);
+        if constexpr (MODE == 2) push_finish(push, pushed_h);
         return;
     }
     {   // exact integer sums of the workgroups' fixed-point partials, scaled once
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
             emit(m, ldexp((double)oo, -shift_in[1]));
             emit(m + 1, ldexp((double)qq, -shift_in[1]));
         }
-        if constexpr (MODE == 2) push_finish(push);
+        if constexpr (MODE == 2) push_finish(push, pushed_h);
     }
 }
 

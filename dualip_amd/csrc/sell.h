@@ -118,8 +118,15 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     constexpr int CH = 4;  // steps per batch of the RELOAD variants (loads of a batch are in flight together)
     T a[KEEP], c[KEEP], f[FAIR ? KEEP : 1], u[HM];
     uint32_t r[KEEP];
+    // (developer-only timing ablations, K-lane / in-place slices of the second binary only -- results are wrong on purpose:
+    //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather)
+    constexpr bool DEVAB = KLOG > 0;
+    const int ab = DEVAB ? kernarg_args(g).ablate : 0;
     auto lam_of = [&](uint32_t row) -> T {
-        if constexpr (HOT) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
+        if constexpr (HOT) {
+            if (DEVAB && (ab & (1 << 17))) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)0;
+            return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
+        }
         else return LAM_LDS ? w.lam_s[row] : (T)(s * g.lambda[row]);
     };
     const T NEG = (T)(-INFINITY);
@@ -231,6 +238,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     theta = tmax(theta, keep ? (T)0 : theta0);  // (sum - z)/cnt >= theta_0 in exact arithmetic: keep it so under rounding (nested supports)
     theta = vertex ? theta0 : theta;  // (the threshold the single member was counted at)
     CntT cprev = cnt;
+    if (DEVAB && (ab & (1 << 16))) act = false;
     for (int it = 0; it < (kSellMaxH << KLOG) + 2 && __any(act); ++it) {
         T s2 = (T)0;
         CntT c2 = (CntT)0;
@@ -254,10 +262,10 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         const T xg = relu((T)(u[t] - theta));
         const T x = (vertex && u[t] > theta) ? pj.z : xg;  // vertex: exact z at the maximum, as the reference (xg is 0 at its other members)
         const T ax = (T)(at * x);
-        if (ax != (T)0) {
+        if (ax != (T)0 && !(DEVAB && (ab & (1 << 15)))) {
             if constexpr (HOT) {
                 if ((int64_t)rt < g.m_hot) scatter_fixed(w.gacc, rt, ax, w.scale);
-                else scatter_fixed(g.cold_grad, rt, ax, w.scale);
+                else if (!(DEVAB && (ab & (1 << 14)))) scatter_fixed(g.cold_grad, rt, ax, w.scale);
             } else {
                 scatter_fixed(w.gacc, rt, ax, w.scale);
             }

@@ -173,6 +173,26 @@ class AcceleratedGradientDescent:
         return DeviceRun(self, f, initial_value, rank)
 
     def _maximize_native(self, f, initial_value, rank):
+        """The device-resident loop.  A sharded run whose exchange was chosen by ``DUALIP_COMM=auto`` gets ONE more attempt when a
+        payload checksum did not match under the unfenced P2P ordering: every rank moves to the fenced ordering together
+        (``Communicator.degrade``) and the solve is repeated from ``initial_value`` -- it is deterministic, so nothing of the failed
+        attempt survives.  Any other failure (a timed-out wait, an explicitly chosen back-end) is raised on every rank."""
+        from dualip_amd.utils.comm import CHECKSUM, ExchangeError
+
+        state = (self.gamma, self.max_step_size)
+        try:
+            return self._maximize_native_once(f, initial_value, rank)
+        except ExchangeError as exc:
+            comm = f.communicator()
+            if not (all(c in (0, CHECKSUM) for c in exc.codes) and comm is not None and comm.degrade()):
+                raise
+            import warnings
+
+            warnings.warn(f"dualip_amd: {exc}; repeating the solve with the fenced exchange")
+            self.gamma, self.max_step_size = state
+            return self._maximize_native_once(f, initial_value, rank)
+
+    def _maximize_native_once(self, f, initial_value, rank):
         run = self.start_device_run(f, initial_value, rank)
         try:
             per_iteration = callable(self._user_callback)
@@ -198,8 +218,7 @@ class AcceleratedGradientDescent:
                         elif rank == 0:
                             print(_summary_from_log(it, rows[k]))
                 if meet:
-                    f.communicator().check()
-                    f.communicator().rendezvous()
+                    f.communicator().meet()  # (a dead exchange stops the solve on EVERY rank at once)
             return run.finish()
         finally:
             run.close()
@@ -210,6 +229,27 @@ def _summary_from_log(iteration: int, row) -> str:
         f"iter={iteration} | dual_objective={row[0]} | dual_grad_norm={row[6]} | reg_penalty={row[2]} | "
         f"dual_val_times_grad={row[3]} | max_pos_slack={row[4]} | sum_pos_slack={row[5]}"
     )
+
+
+def dual_digest(dual_val: torch.Tensor) -> int:
+    """Order-sensitive 63-bit digest of a dual vector's BYTES (two vectors that differ in one bit differ here)."""
+    bits = dual_val.detach().contiguous().view(torch.int32 if dual_val.element_size() == 4 else torch.int64).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, dtype=torch.int64, device=bits.device) * 0x9E3779B1
+    return int((bits * w).sum().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def _assert_same_duals(dual_val: torch.Tensor, group=None) -> None:
+    """Every rank of a column-sharded solve must end with the same duals (the reference broadcasts rank 0's, agd.py:204-206;
+    here every rank applies the identical update to identical sums).  A collective call at the end of every sharded ``maximize``:
+    all ranks raise together when the byte digests differ -- an exchange that handed different sums to different ranks is then
+    loud, whatever the back-end."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    mine = dual_digest(dual_val)
+    all_d = [None] * dist.get_world_size(group)
+    dist.all_gather_object(all_d, mine, group=group)
+    if len(set(all_d)) != 1:
+        raise RuntimeError(f"column-sharded solve: the ranks ended with DIFFERENT duals (byte digests {all_d}); the exchange handed them different sums")
 
 
 def _all_ranks(flag: bool, group=None) -> bool:
@@ -354,13 +394,16 @@ class DeviceRun:
     def finish(self) -> SolverResult:
         solver = self.solver
         if self.native_sharded:
-            self.f.communicator().check()  # a P2P wait that timed out invalidates the run: raise instead of returning numbers
+            # a failed exchange invalidates the run: every rank raises together instead of returning numbers (Communicator.meet)
+            self.f.communicator().meet()
         rows = self.read_log(0, self.done)
         mx = ctypes.c_double(0.0)
         with torch.cuda.device(self.device):
             _hip.check(self.lib.dl_agd_read_max_step(self.state, ctypes.byref(mx), _hip.stream_ptr(self.device)))
             dual_val = self._fetch(1)
             final = self.result_from_row(rows[-1], with_grad=True) if self.done > 0 else None
+        if self.sharded and self.native_sharded:
+            _assert_same_duals(dual_val, getattr(self.f, "process_group", None))
         solver.gamma = self.gamma.value
         if self.decay_steps > 0:
             solver.max_step_size = mx.value

@@ -28,6 +28,18 @@ from dualip_amd import _hip
 
 RCCL, P2P = 1, 2
 _NAMES = {RCCL: "rccl", P2P: "p2p"}
+HEALTHY, TIMED_OUT, CHECKSUM = 0, 1, 2  # dl_comm_status
+_STATUS = {TIMED_OUT: "a wait for another rank's partial sums timed out", CHECKSUM: "a slot's payload did not match the checksum its sender announced"}
+
+
+class ExchangeError(RuntimeError):
+    """The P2P exchange failed on some rank (raised on EVERY rank by ``Communicator.meet``): ``codes`` = dl_comm_status per rank."""
+
+    def __init__(self, codes, backend):
+        self.codes, self.backend = list(codes), backend
+        bad = ", ".join(f"rank {r}: {_STATUS.get(c, c)}" for r, c in enumerate(self.codes) if c)
+        hint = "" if backend != "p2p" else " (DUALIP_COMM=p2p-fenced or rccl orders the exchange by the book)"
+        super().__init__(f"the {backend} exchange failed -- {bad}: the results of this run are invalid on every rank{hint}")
 
 
 def _world(group):
@@ -67,6 +79,9 @@ class Communicator:
         one_node = len({i[0] for i in idents}) == 1
         self.fallback_reason = None
         self.selftest = None  # what the creation-time soak test saw, per level tried
+        self.auto = want == "auto" and not force_fenced  # free to move to a stricter level at run time (degrade)
+        self.degraded = None  # set when a run-time checksum mismatch moved an `auto` communicator from p2p to p2p-fenced
+        self.devices = [f"{i[0]}:{i[1] or i[4]}" for i in idents]  # every rank's node:PCI bus id (device ordinal when torch does not say)
         if want == "rccl" and shared_device and self.world > 1:
             raise RuntimeError("DUALIP_COMM=rccl: RCCL cannot place two ranks on one device")
         if want in ("auto", "p2p", "p2p-fenced") and one_node and self.world <= 16:
@@ -177,7 +192,13 @@ class Communicator:
         return int(self.lib.dl_comm_info(self.handle, 3))
 
     def info(self) -> dict:
+        """What a run can print to show which exchange it really used: back-end, world and rank as the C handle holds them, the rank
+        count and rank the RCCL communicator ITSELF reports (None for P2P), every rank's device, the creation-time soak test."""
+        rccl_n, rccl_r = int(self.lib.dl_comm_info(self.handle, 7)), int(self.lib.dl_comm_info(self.handle, 8))
         return {"backend": self.backend, "world": int(self.lib.dl_comm_info(self.handle, 1)), "rank": int(self.lib.dl_comm_info(self.handle, 2)),
+                "rccl_reported_world": rccl_n if rccl_n >= 0 else None, "rccl_reported_rank": rccl_r if rccl_r >= 0 else None,
+                "devices": self.devices, "distinct_devices": len(set(self.devices)), "device_ordinal": int(self.lib.dl_comm_info(self.handle, 6)),
+                "payload_checksums": self.backend.startswith("p2p"), "degraded": self.degraded,
                 "fallback_reason": self.fallback_reason, "creation_selftest": self.selftest}
 
     def all_reduce_(self, buf: torch.Tensor) -> torch.Tensor:
@@ -195,9 +216,45 @@ class Communicator:
         _gather(0, self.group, self.world)
 
     def check(self) -> None:
-        """Synchronise and raise if a P2P wait ever timed out."""
+        """Synchronise and raise if a P2P exchange ever failed ON THIS RANK (a timed-out wait, a payload checksum mismatch).
+        Rank-local: inside a solve use ``meet`` so that every rank stops together."""
         with torch.cuda.device(self.device):
             _hip.check(self.lib.dl_comm_check(self.handle, _hip.stream_ptr(self.device)))
+
+    def status(self) -> int:
+        """Synchronise; 0 healthy, 1 a wait timed out, 2 payload checksum mismatch (sticky, this rank)."""
+        code = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.dl_comm_status(self.handle, ctypes.byref(code), _hip.stream_ptr(self.device)))
+        return int(code.value)
+
+    def meet(self) -> None:
+        """Host-side meeting of the ranks that also exchanges their health (a collective call): if the exchange failed on ANY
+        rank, EVERY rank raises ``ExchangeError`` here -- a rank that saw a failure does not throw alone while its peers block in
+        the next collective until the process group times out."""
+        codes = _gather(self.status(), self.group, self.world)
+        if any(codes):
+            raise ExchangeError(codes, self.backend)
+
+    def degrade(self) -> bool:
+        """After ``meet`` raised for a checksum mismatch: move an ``auto`` communicator from the unfenced P2P ordering to the
+        fenced one (collective; the same decision on every rank) and clear the error state, so that the caller can repeat its run.
+        False when there is no stricter level to move to (explicitly chosen back-end, already fenced, RCCL)."""
+        can = self.auto and self.backend == "p2p"
+        if not all(_gather(can, self.group, self.world)):
+            return False
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.dl_comm_reset(self.handle, _hip.stream_ptr(self.device)))
+        _hip.check(self.lib.dl_comm_set_fenced(self.handle, 1))
+        _gather(0, self.group, self.world)  # every rank is reset and fenced before anyone pushes again
+        self.degraded = "p2p -> p2p-fenced at run time (a payload checksum did not match under the unfenced ordering)"
+        return True
+
+    def inject_fault(self, kind: int, target_rank: int, at_exchange: Optional[int] = None) -> None:
+        """Test hook: damage this rank's contribution to exchange ``at_exchange`` (default: the next) as stored into
+        ``target_rank``'s mailbox -- 1 = a flipped bit in one element, 2 = data stores dropped (stale slot), 0 = disarm."""
+        seq = self.exchanges + 1 if at_exchange is None else int(at_exchange)
+        _hip.check(self.lib.dl_comm_inject_fault(self.handle, int(kind), int(target_rank), seq))
 
     def set_emulation(self, scale: float) -> None:
         _hip.check(self.lib.dl_comm_set_emulation(self.handle, float(scale)))

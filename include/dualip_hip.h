@@ -233,14 +233,27 @@ int dl_comm_adopt_rccl(dl_comm** out, void* nccl_comm, int64_t max_count);
 int dl_comm_p2p_begin(dl_comm** out, int32_t world, int32_t rank, int64_t max_count, void* ipc_handle_out_host);
 int dl_comm_p2p_connect(dl_comm* c, const void* all_handles_host);
 int dl_comm_destroy(dl_comm* c);
-/* what = 0 back-end (DL_COMM_*), 1 world size, 2 rank, 3 exchanges issued so far, 4 capacity in doubles. */
+/* what = 0 back-end (DL_COMM_*), 1 world size, 2 rank, 3 exchanges issued so far, 4 capacity in doubles, 5 fenced variant of the
+ * P2P ordering (0 / 1), 6 the HIP device ordinal the communicator lives on, 7 / 8 rank count / this rank AS THE RCCL COMMUNICATOR
+ * ITSELF REPORTS THEM (ncclCommCount / ncclCommUserRank; -1 for P2P) -- so a run can show that the collective really spans the
+ * ranks the launcher believes it started. */
 int64_t dl_comm_info(const dl_comm* c, int what);
 /* In-place sum over the ranks of buf[0..count) (double, device), enqueued on `stream`; count <= max_count.  Every rank must
  * issue the same sequence of exchanges on a communicator. */
 int dl_allreduce_sum(dl_comm* c, double* buf, int64_t count, dl_stream_t stream);
-/* Synchronises `stream` and reports whether a P2P exchange ever timed out waiting for a rank (DL_E_STATE; waits are bounded --
- * 20 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device). */
+/* Synchronises `stream` and reports whether a P2P exchange ever FAILED (DL_E_STATE): a wait for a rank timed out (waits are
+ * bounded -- 20 s, DUALIP_COMM_TIMEOUT_MS -- so a lost rank cannot hang the device), or a slot's payload did not match the
+ * checksum its sender announced with the flag (every exchange is verified: data behind its flag, a torn or corrupted slot).
+ * The state is sticky; the results of a run that saw it are invalid on THIS rank -- ranks should meet (dl_comm_status over the
+ * caller's side channel) so that all of them stop together. */
 int dl_comm_check(dl_comm* c, dl_stream_t stream);
+/* The same without turning the state into an error: *dead_out_host = 0 healthy, 1 a wait timed out, 2 payload checksum mismatch. */
+int dl_comm_status(dl_comm* c, int32_t* dead_out_host, dl_stream_t stream);
+/* Test hook (P2P): damage this rank's NEXT contribution whose sequence number is `at_exchange` (dl_comm_info(c, 3) + 1 = the next),
+ * once, as it is stored into rank `target_rank`'s mailbox -- kind 1: one element with a flipped bit, kind 2: the data stores
+ * dropped (the slot keeps what it held two exchanges ago) while the flag is raised as usual; kind 0 disarms.  The reader on
+ * `target_rank` must notice (dl_comm_status = 2). */
+int dl_comm_inject_fault(dl_comm* c, int32_t kind, int32_t target_rank, uint64_t at_exchange);
 /* Bound of the in-kernel waits of the P2P exchange from now on, in milliseconds (> 0).  The Python communicator runs its
  * creation-time self-test under a short bound (2 s) and restores the default afterwards. */
 int dl_comm_set_timeout_ms(dl_comm* c, int64_t ms);

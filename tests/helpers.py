@@ -155,7 +155,8 @@ def padded_eq_entries(p, zz, batching):
     return [("simplex_eq", {"z": zz})] * len(ids), lblocks, col_proj
 
 
-def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, world=1, sharded=False, device="cuda:0", comm_backend=None):
+def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, world=1, sharded=False, device="cuda:0", comm_backend=None, length_classes=None,
+                   skip_route_check=False):
     """Correctness at the benchmark size (bench.py runs it outside every timed region -> aux.verified; tests/test_gpu_fullsize.py
     runs it on the 10M-entity configurations).  Returns {"ok": bool, "checks": [...]}.
 
@@ -164,7 +165,11 @@ def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, worl
     2. A x, c.x, sum x^2 recomputed from the returned primal with torch ops (float64, chunked);
     3. N = 1: the sharded route (this shard split into two kernel handles + the exchange) against the single objective;
        N > 1: this library's exchange against torch.distributed's all-reduce of the same local sums, and the duals of all
-       ranks bit-identical."""
+       ranks bit-identical.
+
+    ``length_classes``: [(lo, hi), ...] -- for every class that has a column of lo <= length <= hi, one more oracle slab of 400
+    columns around such a column (shapes whose kernel plan depends on the column length: each plan's columns get checked).
+    The names of those checks carry ``length class [lo, hi]``."""
     import torch
     import torch.distributed as dist
 
@@ -204,6 +209,15 @@ def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, worl
             slabs.append((f"straddling the cut between entries {q} and {q + 1}", cut - W // 2, cut + W // 2))
     if n_local > W:
         slabs.append(("last columns of the arrays", n_local - W, n_local))
+    if length_classes:
+        lens_d = colptr[1:] - colptr[:-1]
+        for lo_len, hi_len in length_classes:
+            cand = torch.nonzero((lens_d >= lo_len) & (lens_d <= hi_len)).flatten()
+            if cand.numel() == 0:
+                continue
+            j = int(cand[int(torch.randint(0, cand.numel(), (1,), generator=gsl))])
+            s0 = max(0, min(j - 200, n_local - 400))
+            slabs.append((f"length class [{lo_len}, {hi_len}] (column {j}, {int(lens_d[j])} non-zeros)", s0, min(n_local, s0 + 400)))
     for name, lo, hi in slabs:
         cp = colptr[lo : hi + 1].cpu().numpy().astype(np.int64)
         k0, k1 = int(cp[0]), int(cp[-1])
@@ -233,7 +247,9 @@ def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, worl
     note("c.x recomputed from the primal", float((cx - packed[m]).abs() / cx.abs().clamp_min(1e-30)), tol_s)
     note("sum x^2 recomputed from the primal", float((xx - packed[m + 1]).abs() / xx.abs().clamp_min(1e-30)), tol_s)
     # 3. sharded against single / this library's exchange against torch.distributed's
-    if not sharded:
+    if skip_route_check:
+        pass
+    elif not sharded:
         from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunctionDistributed
 
         # two blocks, each with its share of EVERY projection entry (the partition bench.py gives the ranks of an N > 1 run)

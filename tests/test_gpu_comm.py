@@ -266,3 +266,171 @@ def test_step_applied_in_the_next_launch_prologue_is_bit_identical(dn):
         assert torch.equal(ra.dual_val, rb.dual_val) and torch.equal(ra.objective_result.dual_gradient, rb.objective_result.dual_gradient)
         if not sharded:
             assert torch.equal(ra.objective_result.primal_var, rb.objective_result.primal_var)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The exchange must fail LOUDLY: every slot carries a payload checksum with its flag (csrc/comm.h), the reader hashes what it
+# actually loaded, and a mismatch stops EVERY rank together (Communicator.meet) -- or, under DUALIP_COMM=auto, moves all ranks to
+# the fenced ordering and repeats the solve.  Fault injection: dl_comm_inject_fault damages one rank's contribution to one
+# exchange as it is stored into one other rank's mailbox (a flipped bit / dropped data stores = a stale slot behind a raised flag).
+# ---------------------------------------------------------------------------------------------------------
+def _fault_allreduce_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DUALIP_COMM_SOAK_ROUNDS"] = "50"
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.utils.comm import CHECKSUM, Communicator, ExchangeError
+
+        n = 10_002
+        comm = Communicator(n, "cuda:0", backend="auto")
+        assert comm.backend == "p2p" and comm.info()["payload_checksums"] and comm.info()["distinct_devices"] == 1
+        g = torch.Generator(device="cuda:0").manual_seed(99)
+        events = []
+
+        def rounds(k):
+            bad = 0
+            for _ in range(k):
+                parts = torch.randint(-1000, 1000, (world, n), generator=g, device="cuda:0").double()
+                v = parts[rank].clone()
+                comm.all_reduce_(v)
+                bad += int((v != parts.sum(0)).sum())
+            return bad
+
+        assert rounds(10) == 0
+        comm.meet()  # healthy: passes on every rank
+        # 1. rank 1 stores one element with a flipped bit into rank 0's mailbox: rank 0 must notice, BOTH ranks must raise
+        if rank == 1:
+            comm.inject_fault(1, 0)
+        bad = rounds(1)
+        events.append(("flip", bad, comm.status()))
+        try:
+            comm.meet()
+            events.append(("meet", "passed"))
+        except ExchangeError as exc:
+            events.append(("meet", exc.codes))
+        # 2. an `auto` communicator moves to the fenced ordering and works again
+        events.append(("degrade", comm.degrade(), comm.backend, comm.info()["degraded"] is not None))
+        events.append(("after", rounds(10), comm.status()))
+        comm.meet()
+        # 3. rank 0 raises its flag in rank 1's mailbox WITHOUT the data (a stale slot): rank 1 must notice; no level left to move to
+        if rank == 0:
+            comm.inject_fault(2, 1)
+        rounds(1)
+        try:
+            comm.meet()
+            events.append(("meet2", "passed"))
+        except ExchangeError as exc:
+            events.append(("meet2", exc.codes))
+        events.append(("degrade2", comm.degrade()))
+        q.put((rank, events, CHECKSUM))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (ev, c)) for r, ev, c in [q.get() for _ in procs])
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    CHK = got[0][1]
+    ev0, ev1 = dict((e[0], e[1:]) for e in got[0][0]), dict((e[0], e[1:]) for e in got[1][0])
+    assert ev0["flip"][0] > 0 and ev0["flip"][1] == CHK, ev0   # rank 0 read the damaged element AND its reader noticed
+    assert ev1["flip"] == (0, 0), ev1                           # rank 1's own mailbox was fine
+    assert ev0["meet"] == ([CHK, 0],) and ev1["meet"] == ([CHK, 0],)  # ... yet both ranks stop, with the same picture
+    for ev in (ev0, ev1):
+        assert ev["degrade"] == (True, "p2p-fenced", True) and ev["after"] == (0, 0), ev
+        assert ev["meet2"] == ([0, CHK],) and ev["degrade2"] == (False,), ev
+
+
+def _fault_loop_worker(rank, world, port, fuse, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DUALIP_COMM_SOAK_ROUNDS"] = "50"
+    os.environ["DUALIP_HIP_FUSE_APPLY"] = fuse
+    import warnings
+
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunctionDistributed
+        from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+        from dualip_amd.projections import create_projection_map
+        from dualip_amd.utils.comm import ExchangeError
+        from dualip_amd.utils.dist_utils import balanced_block_ranges
+        from tests.helpers import load, problem, sub_problem, torch_args
+
+        z = load("g3_syn2000.npz")
+        p = problem(z)
+        gamma, iters, s0, s1 = z["params"]
+        (lo, hi), = balanced_block_ranges([(0, p["n"])], world, rank)
+        local = sub_problem(p, lo, hi)
+        args = torch_args(local, "f64", create_projection_map("simplex", {"z": 1.0}, local["n"]), "cuda:0", with_b=False)
+        kw = dict(max_iter=int(iters), gamma=float(gamma), initial_step_size=float(s0), max_step_size=float(s1), iteration_callback=False)
+        lam0 = torch.zeros(p["m"], dtype=torch.float64, device="cuda:0")
+        # (a) DUALIP_COMM=auto: a slot damaged in iteration 7 -> the solve is repeated under the fenced ordering and is RIGHT
+        f = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0")
+        comm = f.communicator()
+        assert comm.backend == "p2p"
+        if rank == 1:
+            comm.inject_fault(1, 0, comm.exchanges + 7)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            res = AcceleratedGradientDescent(**kw).maximize(f, lam0)
+        warned = any("repeating the solve with the fenced exchange" in str(x.message) for x in w)
+        out = dict(log=np.array(res.dual_objective_log), dual=res.dual_val.cpu().numpy(), backend=comm.backend, degraded=comm.info()["degraded"], warned=warned)
+        # (b) an explicitly chosen back-end has no level to move to: every rank raises
+        f2 = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0", comm_backend="p2p")
+        if rank == 0:
+            f2.communicator().inject_fault(2, 1, f2.communicator().exchanges + 30)
+        try:
+            AcceleratedGradientDescent(**kw).maximize(f2, lam0)
+            out["explicit"] = "returned"
+        except ExchangeError as exc:
+            out["explicit"] = exc.codes
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_damaged_exchange_inside_the_c_loop_degrades_or_raises_on_every_rank(fuse):
+    """The reader of the solver loop is the statistics kernel + the step that consumes it (its own launch, or the next fused
+    launch's prologue: both routes, ``fuse``).  Replaces matching.py:272-277 / agd.py:204-206 semantics -- every rank must hold
+    the same duals -- with a check instead of a broadcast."""
+    from tests.helpers import load, relerr
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_loop_worker, args=(r, 2, port, fuse, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get() for _ in procs)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    z = load("g3_syn2000.npz")
+    want_log, want_dual = z["simplex1|w2|f64|dual_obj_log"], z["simplex1|w2|f64|dual_val"]
+    for r in range(2):
+        o = got[r]
+        assert o["warned"] and o["backend"] == "p2p-fenced" and "checksum" in o["degraded"], o
+        assert relerr(o["log"][:40], want_log[:40]) < 1e-9 and relerr(o["dual"], want_dual) < 1e-5
+        assert o["explicit"] == [0, 2], o["explicit"]
+    assert np.array_equal(got[0]["dual"], got[1]["dual"]) and np.array_equal(got[0]["log"], got[1]["log"])

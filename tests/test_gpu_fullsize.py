@@ -95,6 +95,48 @@ def test_logs_are_bit_identical_run_to_run_with_the_adaptive_deal():
         assert torch.equal(lam, outs[0][2]) and torch.equal(grad, outs[0][3])
 
 
+def test_movielens_shape_at_full_size_under_the_checker():
+    """BASELINE config 1 at its REAL shape (examples/movielens_matching/movies_lens_matching.py:222-275: 138 493 users x 26 744
+    movies, one simplex per user, capacity 30, gamma 0.1) -- the shape whose kernel plan is everything the benchmark's is not:
+    more rows than the LDS holds (hot-rows plan, cold tail on global atomics), the fused kernel's second binary, K-lane slices,
+    in-place one-column slices, whole-workgroup columns, all at once in fp32.  50 iterations of the device loop, then the checker
+    of bench.py (oracle slabs incl. a column of every length class, sums recomputed in float64, the two-handle route) at the
+    solve's duals and at a stress dual vector that multiplies the Newton passes."""
+    from benchmark.movielens_like import LENGTH_CLASSES, generate, stress_duals
+    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import verify_at_size
+
+    A, C, counts = generate(device=DEV)
+    n, m = A.shape[1], A.shape[0]
+    assert (n, m) == (138_493, 26_744)
+    for lo, hi in LENGTH_CLASSES[1:]:
+        assert int(((counts >= lo) & (counts <= hi)).sum()) > 0, (lo, hi)  # (generate() draws no user below 20 ratings; after de-duplication a few fall under 25)
+    gamma = 0.1
+    inp = MatchingInputArgs(A=A, c=C, projection_map=create_projection_map("simplex", {"z": 1.0}, n, indices=range(n)), b_vec=torch.full((m,), 30.0, device=DEV), equality_mask=None)
+    f = MatchingSolverDualObjectiveFunction(matching_input_args=inp, gamma=gamma)
+    info = f.info()
+    assert info["layout"] == 4 and info["hot_rows"] > 0 and info["hot_rows"] < m, info        # more rows than the LDS holds
+    assert info["slice_lane_columns"] > 0 and info["long_columns"] > 0 and info["workgroup_columns"] > 0, info  # second binary: K-lane slices, single-column tiles, whole-workgroup columns
+    solver = AcceleratedGradientDescent(max_iter=50, gamma=gamma, initial_step_size=1e-5, max_step_size=1e-3, iteration_callback=False)
+    run = solver.start_device_run(f, torch.zeros(m, dtype=torch.float32, device=DEV))
+    run.advance(50)
+    res = run.finish()
+    run.close()
+    log = np.array(res.dual_objective_log)
+    assert len(log) == 50 and np.isfinite(log).all() and log[-1] > log[0]
+    assert float(res.dual_val.abs().max()) > 0
+    for tag, lam in (("solve", res.dual_val), ("stress", stress_duals(m, DEV))):
+        out = verify_at_size("f32", gamma, inp, inp.projection_map, f, f, lam.contiguous(), device=DEV, length_classes=LENGTH_CLASSES)
+        bad = [c for c in out["checks"] if not c["ok"]]
+        assert out["ok"] and not bad, (tag, bad)
+        names = " ".join(c["name"] for c in out["checks"])
+        for lo, hi in LENGTH_CLASSES[1:]:
+            assert f"length class [{lo}, {hi}]" in names, (lo, hi)
+        assert "recomputed from the primal" in names and "sharded route" in names
+
+
 @pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0"),
                                     ("DUALIP_HIP_FLAT", "0"), ("DUALIP_HIP_FLAT", "1"), ("DUALIP_HIP_COMPACT", "0"), ("DUALIP_HIP_HOST_PACK", "1"), ("DUALIP_HIP_ROW32", "1"),
                                     ("DUALIP_HIP_XCD_BALANCE", "0"), ("DUALIP_HIP_LDS_MODE", "grad"), ("DUALIP_HIP_LDS_MODE", "none"), ("DUALIP_HIP_HOT_ROWS", "64")])

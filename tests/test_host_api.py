@@ -388,6 +388,59 @@ def test_build_screens_device_assembly_for_the_misplaced_spill():
         os.unlink(fh.name)
 
 
+def test_build_screens_device_assembly_for_the_half_redefined_scalar_pair():
+    """Guard for the SECOND code-generation defect: a 64-bit scalar value whose high half was overwritten by
+    an unrelated scalar load while the pair was live, spilled to VGPR lanes and reloaded as a pair.  The screen must flag the
+    hand-written listing, and pass (a) the same code with gridDim.x loaded into a register OUTSIDE the pair, (b) a zero-extension
+    (the high half redefined by s_mov, a legitimate way to form a 64-bit value), (c) two unrelated 32-bit values that merely sit
+    in adjacent lanes and are never used as a pair."""
+    import tempfile
+
+    from dualip_amd import _build
+
+    bad = os.path.join(ROOT, "tests", "golden", "sgpr_pair_half_redefined.s")
+    found = _build._sgpr_pair_defects(bad)
+    assert len(found) == 1 and "s[10:11]" in found[0] and "s55" in found[0] and "lanes 34/35" in found[0] and "matching_fused_kernel4IdtLb1ELb1ELb0ELb0ELb1" in found[0], found
+    assert _build._spill_defects(bad) == []  # (the other screen has nothing to say about it)
+    text = open(bad).read()
+    variants = {
+        "other register": text.replace("s_load_dword s55, s[0:1], 0x230", "s_load_dword s56, s[0:1], 0x230").replace("s_mul_i32 s4, s55, 16", "s_mul_i32 s4, s56, 16"),
+        "zero extension": text.replace("s_load_dword s55, s[0:1], 0x230", "s_mov_b32 s55, 0"),
+        "never used as a pair": text.replace("s_lshl_b64 s[8:9], s[10:11], 3", "s_lshl_b32 s8, s10, 3"),
+    }
+    for name, var in variants.items():
+        assert var != text, name
+        with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
+            fh.write(var)
+        try:
+            assert _build._sgpr_pair_defects(fh.name) == [], name
+        finally:
+            os.unlink(fh.name)
+
+
+def test_build_manifest_records_what_the_screens_saw():
+    """dualip_amd/lib/build_manifest.json (written by every build): per translation unit the number of device-assembly files the
+    screens read (never zero: a build must not pass because there was nothing to look at), their findings (none), and per kernel
+    the registers / spills / scratch of the code object's metadata.  The benchmark's instantiation of the fused kernel must not
+    touch scratch."""
+    import json
+
+    from dualip_amd import _build
+
+    _build.build()
+    man = json.load(open(_build.MANIFEST_PATH))
+    assert sorted(o["source"] for o in man["objects"]) == sorted(_build.SOURCES)
+    kernels = {}
+    for o in man["objects"]:
+        assert o["screened_assembly_files"] >= 1, o["source"]
+        assert o["spill_before_exec_restore"] == [] and o["sgpr_pair_half_redefined"] == [], o["source"]
+        kernels.update(o["kernels"])
+    bench = kernels[man["benchmark_kernel"]]
+    assert man["benchmark_kernel"] == _build.BENCHMARK_KERNEL and "matching_fused_kernel4IftLb1ELb1ELb0ELb0ELb0" in man["benchmark_kernel"]
+    assert bench["vgpr_spill_count"] == 0 and bench["scratch_bytes"] == 0 and bench["vgpr_count"] <= 128, bench
+    assert len(kernels) > 60 and all(v["vgpr_count"] is not None for v in kernels.values())
+
+
 def test_build_lists_cover_every_source_and_header():
     """The build hashes SOURCES + HEADERS to decide staleness and compiles exactly SOURCES: a file added under csrc/ but not
     listed would be silently left out of the library (or of the staleness check)."""

@@ -19,12 +19,17 @@ A, C, counts = generate()
 m, n = int(A.shape[0]), int(A.shape[1])
 inp = MatchingInputArgs(A=A, c=C, projection_map=create_projection_map("simplex", {"z": 1.0}, n, indices=range(n)), b_vec=torch.full((m,), 30.0, device="cuda:0"))
 f = MatchingSolverDualObjectiveFunction(inp, 0.1)
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+stress = "--stress" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+iters = int(argv[0]) if argv else 50
 solver = AcceleratedGradientDescent(max_iter=iters, gamma=0.1, initial_step_size=1e-8, max_step_size=1e-6, iteration_callback=False)
-run = solver.start_device_run(f, torch.zeros(m, dtype=torch.float32, device="cuda:0"), rank=0)
+from benchmark.movielens_like import stress_duals
+
+run = solver.start_device_run(f, stress_duals(m, "cuda:0") if stress else torch.zeros(m, dtype=torch.float32, device="cuda:0"), rank=0)
 run.advance(iters)
 torch.cuda.synchronize()
-us = (f.timeline().astype(np.int64) - f.timeline().astype(np.int64)[:, 0].min()) / 100.0
+tl = f.timeline().astype(np.int64) & 0x0FFFFFFFFFFFFFFF  # (the top four bits of stamp 0 carry the XCD id)
+us = (tl - tl[:, 0].min()) / 100.0
 print("info", f.info())
 for k, name in enumerate(["start", "stamp1", "loop_done", "end"]):
     print(f"{name:10s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
