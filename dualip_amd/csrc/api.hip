@@ -1,6 +1,7 @@
 // api.hip -- extern "C" surface of libdualip_hip.so (include/dualip_hip.h) and the one-off set-up work:
 // row-index re-encoding, wave-tile packing and workgroup partitioning.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -584,7 +585,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         // (handles of the fused kernel's second binary -- K-lane slices, or >= 1 % of the non-zeros in single-column tiles; same rule
         //  as matching_kernels.hip: wants_lanes_binary -- deal these tiles to the wavefronts of a workgroup dynamically: plain descending order)
         bool lanes_binary = h->long_nnz > 0 && h->long_nnz * 100 >= nnz;
-        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !lanes_binary; t += 4) lanes_binary = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
+        if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) lanes_binary = e[0] == '1';  // testing: either binary on any handle without K-lane slices
+        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !lanes_binary; t += 4) lanes_binary = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;  // (only the second binary walks K-lane slices)
+        h->lanes_binary = lanes_binary;  // read once, here: the binary a launch takes and the tile order below must agree (matching_kernels.hip: launch_fused4)
         auto snake = [lanes_binary](std::vector<uint32_t>& wv, std::vector<uint32_t>& pv, size_t width) {
             const size_t nt = pv.size();
             if (nt < 2 || width == 0) return;
@@ -759,6 +762,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     }
     memcpy(&h->amax, &mx_host[0], sizeof(double));
     memcpy(&h->cmax, &mx_host[1], sizeof(double));
+    if (!std::isfinite(h->amax) || !std::isfinite(h->cmax)) {  // (absmax_kernel: any inf / NaN element surfaces here)
+        matching_free(h);
+        return fail(DL_E_ARG, "the values of %s hold an inf or NaN: the exact fixed-point sums of the fused pass are undefined for it (the reference would return NaN)",
+                    !std::isfinite(h->amax) ? "A" : "c");
+    }
     for (unsigned int v : row_count_h) h->row_count_max = v > (unsigned int)h->row_count_max ? (int64_t)v : h->row_count_max;
     if (h->m_hot > 0) {
         // renumber rows by descending non-zero count (stable): new id < m_hot <=> the row lives in LDS
@@ -958,14 +966,17 @@ static int refresh_absmax(dl_matching* h, const void* values, double* out, hipSt
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, h->absmax_dev, sizeof(bits), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the bound travels to the kernel as an argument: the host needs it)
     if (e != hipSuccess) return hip_fail(e, "value refresh");
-    memcpy(out, &bits, sizeof(double));
+    double v;
+    memcpy(&v, &bits, sizeof(double));
+    if (!std::isfinite(v)) return fail(DL_E_ARG, "the rewritten values hold an inf or NaN: the exact fixed-point sums of the fused pass are undefined for it");
+    *out = v;
     return 0;
 }
 
 int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
     hipStream_t st = (hipStream_t)stream;
-    if (h->has_unbounded && h->nnz > 0) {  // max |c| bounds |v| (hence |x|) for projections that do not bound x themselves
+    if (h->nnz > 0) {  // max |c| scales the fixed-point sums c.x / sum x^2 (fused_common.h: scalar_shift) and bounds |v| for projections that do not bound x
         int rc = refresh_absmax(h, h->c, &h->cmax, st);
         if (rc) return rc;
     }

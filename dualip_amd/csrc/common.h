@@ -133,6 +133,8 @@ struct dl_matching {
     std::vector<uint64_t> wg_preload;  // per workgroup: cost (in slice slots) of the whole-workgroup columns it walks first
     uint32_t* sell_lane_begin = nullptr;  // owned: [n_wg + 1] ranges of the K-lane slice table, one per workgroup
     int64_t long_nnz = 0;             // non-zeros in single-column tiles walked by one wavefront each
+    bool lanes_binary = false;        // launches go to the fused kernel's SECOND binary; decided ONCE at creation (the order of the
+                                      // single-column tiles -- descending for its dynamic deal, snake for the first binary's static one -- goes with it)
     int64_t n_sell_lane_slices = 0;   // slices with K > 1 lanes per column: the FIRST n of sell_desc (walked by their own loop)
     int64_t n_sell_lane_cols = 0;     // columns dealt to K > 1 lanes each (25 .. 512 non-zeros; sell.h)
     int64_t n_sell_mixed_cols = 0;    // columns of slices that hold more than one length (the only ones whose length bytes are read)

@@ -1,7 +1,7 @@
 // fused4_kernel.h -- the fused pass with 256-wide tiles: FOUR consecutive non-zeros per lane.
 //
 // Included by four translation units: matching_kernels4[_f64].hip (DL_FUSED4_LANES 0) and matching_kernels4_lanes[_f64].hip (DL_FUSED4_LANES 1).
-// The second carries, in addition, the loop over the slices with K = 2 .. 16 lanes per column (sell.h: sell_lanes_loop) and is
+// The second carries, in addition, the loop over the slices with K = 2 .. 32 lanes per column (sell.h: sell_lanes_loop; columns of 25 .. 512 non-zeros) and is
 // launched for the handles that have such slices.  Two binaries of one source, because the eight extra slice variants inside the
 // kernel cost the handles WITHOUT such slices 2 % per launch (10M entities, all-box map included: same box, HEAD 0.1670 ms,
 // with the loop compiled in 0.1713, with the call compiled out 0.1664 -- code placement, not executed work), and the benchmark's
@@ -297,11 +297,26 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         // issue of the next tile's loads
         uint32_t row[kSlots];
         T lam[kSlots];
+        if constexpr (HOT) {  // (cold rows: four unconditional requests -- a hot lane reads lambda[0] -- then a select; see sell.h)
+            const uint32_t mh = (uint32_t)g.m_hot;
+            T lg[kSlots];
 #pragma unroll
-        for (int j = 0; j < kSlots; ++j) {
-            row[j] = (uint32_t)cur.r.v[j];
-            if constexpr (HOT) lam[j] = (int64_t)row[j] < g.m_hot ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
-            else lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+            for (int j = 0; j < kSlots; ++j) {
+                row[j] = (uint32_t)cur.r.v[j];
+                lg[j] = g.lambda[row[j] >= mh ? row[j] : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                const bool cold = row[j] >= mh;
+                const T hot_val = w.lam_s[cold ? 0u : row[j]];
+                lam[j] = cold ? (T)(s * lg[j]) : hot_val;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+                row[j] = (uint32_t)cur.r.v[j];
+                lam[j] = LAM_LDS ? w.lam_s[row[j]] : (T)(s * g.lambda[row[j]]);
+            }
         }
         const uint32_t dv_cur_next = dv_next;
         const uint32_t ti_nn = deal_slot(dealw, kernarg_args(g).balance, kw + 2u, n_tiles);

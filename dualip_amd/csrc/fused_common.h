@@ -58,7 +58,7 @@ struct FusedArgs {
     const void* __restrict__ sell_r;
     const T* __restrict__ sell_f;
     uint32_t n_sell;               // one-lane-per-column slices (sell_desc)
-    const uint32_t* sell_lane_desc;  // slices with K = 2 .. 16 lanes per column (sell.h: sell_lanes_loop), their own table ...
+    const uint32_t* sell_lane_desc;  // slices with K = 2 .. 32 lanes per column (sell.h: sell_lanes_loop), their own table ...
     uint32_t n_sell_lanes;           // ... and count (cold: read from the kernel arguments)
     const uint32_t* sell_lane_begin; // [workgroups + 1]: workgroup w walks table entries sell_lane_begin[w] .. sell_lane_begin[w + 1]
     // the previous iteration's optimiser step, applied in this launch's prologue (agd_step.h): do_apply != 0 => `lambda` is not read,
@@ -146,10 +146,14 @@ __device__ __forceinline__ long long to_fixed(double ax, double scale) { return 
 // of a lane: four slots of a window, 24 steps of a slice) below the 2^51 the 1.5 * 2^52 conversion trick holds.
 __device__ __forceinline__ int scalar_shift(double nnz, double cmax, double xmax) {
     const double q = (cmax * xmax > xmax * xmax) ? cmax * xmax : xmax * xmax;
+    // (max |c| and the projection bounds are finite -- the handle refuses arrays with inf / NaN -- but their product with nnz may not be:
+    //  an overflowing bound takes the coarsest grid instead of leaving the exponent at 0, which would put garbage into the integer sums)
     int e_tot = 0, e_one = 0;
     const double tot = nnz * q, one = 32.0 * q;
-    if (tot > 0.0 && tot < 1e300) (void)frexp(tot, &e_tot);
-    if (one > 0.0 && one < 1e300) (void)frexp(one, &e_one);
+    if (tot > 0.0 && tot < 1.7e308) (void)frexp(tot, &e_tot);
+    else if (tot > 0.0) e_tot = 1100;
+    if (one > 0.0 && one < 1.7e308) (void)frexp(one, &e_one);
+    else if (one > 0.0) e_one = 1100;
     int sh = 62 - e_tot;
     sh = sh < 50 - e_one ? sh : 50 - e_one;
     return sh > 1000 ? 1000 : (sh < -1000 ? -1000 : sh);
@@ -238,9 +242,23 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             cv[u] = g.c[k];
             rv[u] = (uint32_t)reinterpret_cast<const RowT*>(g.rowidx)[k];
         }
+        // (hot-rows plan: the cold rows' dual entries are requested for the whole batch at once, unconditionally -- a hot lane reads
+        //  lambda[0] -- and chosen by a select; a load under a per-element branch waits for its own L2 round trip at every join)
+        T lg[kLB];
+        if (LAM_LDS && m_hot > 0) {
+#pragma unroll
+            for (int u = 0; u < kLB; ++u) lg[u] = g.lambda[(int64_t)rv[u] >= m_hot ? rv[u] : 0u];
+        }
 #pragma unroll
         for (int u = 0; u < kLB; ++u) {
-            const T lam = (LAM_LDS && (m_hot == 0 || (int64_t)rv[u] < m_hot)) ? lam_s[rv[u]] : (T)(s * g.lambda[rv[u]]);
+            T lam;
+            if (LAM_LDS && m_hot > 0) {
+                const bool cold = (int64_t)rv[u] >= m_hot;
+                const T hot_val = lam_s[cold ? 0u : rv[u]];
+                lam = cold ? (T)(s * lg[u]) : hot_val;
+            } else {
+                lam = LAM_LDS ? lam_s[rv[u]] : (T)(s * g.lambda[rv[u]]);
+            }
             v[u] = (T)((T)(av[u] * lam) + (T)(s * cv[u]));
         }
         if (fair_acc) {  // fairness pair: + f_k * (-(lambda_K - lambda_{K+1}) / gamma)
@@ -507,7 +525,8 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         }
         const double bound = g.amax * xmax * g.row_count_max;
         int e = 0;
-        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
+        if (bound > 0.0 && bound < 1.7e308) (void)frexp(bound, &e);
+        else if (bound > 0.0) e = 1100;  // (an overflowing bound: the coarsest grid, not exponent 0)
         shift = FixedBits<T>::value - e;
         shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
         shift2 = scalar_shift((double)g.nnz, g.cmax, xmax);

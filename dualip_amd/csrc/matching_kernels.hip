@@ -351,16 +351,18 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
     }
 }
 
-// max |v| over an array (one-off, at handle creation): non-negative floats order like their bit patterns
+// max |v| over an array (one-off, at handle creation): non-negative floats order like their bit patterns -- and +inf, then NaN, order
+// ABOVE every finite value, so a non-finite element anywhere comes back as a non-finite maximum (the handle refuses such arrays: the
+// fixed-point sums of the fused pass are undefined for them, where the reference would return NaN)
 template <class T>
 __global__ void absmax_kernel(int64_t n, const T* __restrict__ v, unsigned long long* __restrict__ out_bits) {
-    double mx = 0.0;
+    long long mx = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
-        const double a = fabs((double)v[k]);
-        mx = a > mx ? a : mx;  // NaN is ignored here; it poisons the results elsewhere
+        const long long a = __double_as_longlong(fabs((double)v[k])) & 0x7FFFFFFFFFFFFFFFll;
+        mx = a > mx ? a : mx;
     }
     mx = wave_allreduce(mx, OpMax());
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(mx));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)mx);
 }
 
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st) {
@@ -414,11 +416,8 @@ int launch_fused4_f32_lanes(const dl_matching* h, const FusedArgs<float>& args, 
 int launch_fused4_f64_lanes(const dl_matching* h, const FusedArgs<double>& args, hipStream_t st);
 // the second binary: handles with K-lane slices, or with >= 1 % of their non-zeros in single-column tiles (which it walks as
 // one-column slices, sell.h) -- the benchmark's shapes have neither
-static bool wants_lanes_binary(const dl_matching* h) {
-    if (h->n_sell_lane_slices > 0) return true;  // (only the second binary walks them)
-    if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) return e[0] == '1';  // testing: either binary on any handle without K-lane slices
-    return h->long_nnz > 0 && h->long_nnz * 100 >= h->nnz;
-}
+// (decided once per handle, at creation -- api.hip -- together with the order of the single-column tiles that goes with each binary)
+static bool wants_lanes_binary(const dl_matching* h) { return h->lanes_binary || h->n_sell_lane_slices > 0; }
 static int launch_fused4(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st) {
     return wants_lanes_binary(h) ? launch_fused4_f32_lanes(h, args, st) : launch_fused4_f32(h, args, st);
 }

@@ -119,14 +119,28 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     T a[KEEP], c[KEEP], f[FAIR ? KEEP : 1], u[HM];
     uint32_t r[KEEP];
     // (developer-only timing ablations, K-lane / in-place slices of the second binary only -- results are wrong on purpose:
-    //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather)
+    //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather,
+    //  18 = the cold-row gather of round 3: one global load per step, each under its own branch)
     constexpr bool DEVAB = KLOG > 0;
     const int ab = DEVAB ? kernarg_args(g).ablate : 0;
+    // Hot-rows plan: a row >= m_hot has its dual entry in global memory (L2).  Round 3 read it under a per-element branch
+    // (`row < m_hot ? lam_s[row] : s * lambda[row]`): every step of a slice then waits for its own L2 round trip at the branch's join
+    // (the compiler's s_waitcnt insertion falls back to vmcnt(0) there), sixteen dependent round trips per slice -- 11 us per slice on
+    // the MovieLens shape, four slices per wavefront.  Now ALL steps' global loads are issued together, unconditionally (a hot lane
+    // reads lambda[0]: one line, broadcast), straight after the row indices arrive, and the choice is a select: two round trips per slice.
+    const uint32_t m_hot32 = HOT ? (uint32_t)g.m_hot : 0u;
+    auto lam_cold_load = [&](uint32_t row) -> T {  // the value a cold row needs, requested unconditionally
+        if (DEVAB && (ab & (1 << 17))) return (T)0;
+        return g.lambda[row >= m_hot32 ? row : 0u];
+    };
+    auto lam_pick = [&](uint32_t row, T cold_val) -> T {
+        const bool cold = row >= m_hot32;
+        const T hot_val = w.lam_s[cold ? 0u : row];
+        return cold ? (T)(s * cold_val) : hot_val;
+    };
+    const bool old_gather = DEVAB && (ab & (1 << 18));
     auto lam_of = [&](uint32_t row) -> T {
-        if constexpr (HOT) {
-            if (DEVAB && (ab & (1 << 17))) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)0;
-            return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
-        }
+        if constexpr (HOT) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
         else return LAM_LDS ? w.lam_s[row] : (T)(s * g.lambda[row]);
     };
     const T NEG = (T)(-INFINITY);
@@ -146,9 +160,18 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                 if constexpr (FAIR) f[t] = (T)0;
             }
         }
+        if constexpr (HOT) {
+            if (!old_gather) {
+#pragma unroll
+                for (int t = 0; t < HM; ++t) u[t] = lam_cold_load(r[t]);  // (all in flight together; u[t] is free until the next loop writes it)
+            }
+        }
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
-            T v = (T)((T)(a[t] * lam_of(r[t])) + (T)(s * c[t]));
+            T lam;
+            if constexpr (HOT) lam = old_gather ? lam_of(r[t]) : lam_pick(r[t], u[t]);
+            else lam = lam_of(r[t]);
+            T v = (T)((T)(a[t] * lam) + (T)(s * c[t]));
             if constexpr (FAIR) v = (T)(v + (T)(sd * f[t]));
             u[t] = relu_finite(v);
             if constexpr (ORIG) u[t] = (t < Hmin || t < len_lane) ? u[t] : (T)0;
@@ -173,9 +196,18 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                     f8[q] = (T)0;
                 }
             }
+            if constexpr (HOT) {
+                if (!old_gather) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) u[t0 + q] = lam_cold_load(r8[q]);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
-                T v = (T)((T)(a8[q] * lam_of(r8[q])) + (T)(s * c8[q]));
+                T lam;
+                if constexpr (HOT) lam = old_gather ? lam_of(r8[q]) : lam_pick(r8[q], u[t0 + q]);
+                else lam = lam_of(r8[q]);
+                T v = (T)((T)(a8[q] * lam) + (T)(s * c8[q]));
                 if constexpr (FAIR) v = (T)(v + (T)(sd * f8[q]));
                 u[t0 + q] = relu_finite(v);
                 if constexpr (ORIG) u[t0 + q] = (t0 + q < Hmin || t0 + q < len_lane) ? u[t0 + q] : (T)0;

@@ -74,6 +74,13 @@ def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, p
     if partition not in ("reference", "cost", "balanced"):
         raise ValueError(f"partition must be 'reference', 'cost' or 'balanced', got {partition}")
     blocks = _column_blocks(input_args.projection_map, n) if partition == "balanced" else None
+    if partition == "balanced" and blocks is None:
+        # (entries given as index LISTS -- create_projection_map turns short ranges into lists -- or overlapping / strided ranges: there are
+        #  no contiguous blocks to share out.  Said out loud: a run that asked for one split must not silently be timed on another.)
+        import warnings
+
+        warnings.warn("dualip_amd.run_solver: partition='balanced' needs a projection map whose entries are disjoint step-1 ranges; this map is not -- "
+                      "using the reference's contiguous cut n // W (+1) instead")
     if blocks is not None and len(blocks) > 1:
         pieces = balanced_block_ranges(blocks, world, rank)
     else:
@@ -90,6 +97,8 @@ def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, p
         cols.append(range(lo, hi))
         off += k1 - k0
     width = sum(len(r) for r in cols)
+    if not rows:  # a rank without columns (blocks narrower than the world): an EMPTY shard -- it still takes part in every exchange
+        rows, a_vals, c_vals = [A.row_indices()[:0].to(device)], [A.values()[:0].to(device)], [c.values()[:0].to(device)]
     sub_ptr, sub_rows = torch.cat(ptrs), torch.cat(rows)
     if len(cols) == 1:
         local_map = global_to_local_projection_map(input_args.projection_map, cols[0])
@@ -124,7 +133,12 @@ def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_
         if world != compute_args.compute_device_num:
             raise ValueError(f"compute_device_num={compute_args.compute_device_num} but the process group has {world} ranks")
         device = torch.device("cuda", torch.cuda.current_device())
-        local = _local_shard(input_args, rank, world, device, os.environ.get("DUALIP_PARTITION", getattr(compute_args, "partition", "reference")))
+        partition = os.environ.get("DUALIP_PARTITION", getattr(compute_args, "partition", "reference"))
+        kinds = [None] * world  # (ComputeArgs and the environment are per process: every rank must cut the SAME way, or columns are lost / doubled)
+        dist.all_gather_object(kinds, partition)
+        if len(set(kinds)) != 1:
+            raise ValueError(f"the ranks disagree on the partition of the entities ({kinds}): set ComputeArgs.partition / DUALIP_PARTITION identically on every rank")
+        local = _local_shard(input_args, rank, world, device, partition)
         return MatchingSolverDualObjectiveFunctionDistributed(
             local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device, use_jacobi_precondition=jac
         )

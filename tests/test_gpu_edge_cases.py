@@ -505,3 +505,34 @@ def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
         assert abs(float(got.dual_objective) - wo) <= 1e-6 * abs(wo)
     # (the timings of a real device are never perfectly even: the table moves; if it ever did not, the test still passed the invariants)
     print("tables seen", len(tables))
+
+
+def test_non_finite_values_are_refused_and_rescaled_costs_keep_the_objective_exact():
+    """The gradient, c.x and sum x^2 are exact fixed-point sums whose grids come from max |a|, max |c| (fused_common.h).  A value array
+    with an inf or NaN has no such grid: the handle refuses it (the reference would return NaN) instead of logging integer garbage.
+    And costs rewritten in place -- here scaled by 10^7 under a BOUNDED map -- must move the grid of the scalar sums with them:
+    ``costs_changed()`` refreshes max |c| for every map (round 3 did so only for unbounded projections)."""
+    from dualip_amd._hip import HipLibraryError
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    p = _random_problem(300, 5000, 8, seed=5)
+    pm = create_projection_map("box", {"lower": 0.0, "upper": 1.0}, p["n"])
+    for which, bad in (("a", np.nan), ("c", np.inf)):
+        q = dict(p)
+        q[which] = p[which].copy()
+        q[which][1234] = bad
+        with pytest.raises((HipLibraryError, RuntimeError, ValueError), match="inf or NaN"):
+            MatchingSolverDualObjectiveFunction(torch_args(q, "f32", pm, DEV), gamma=0.05)
+    f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.05)
+    lam = np.full(p["m"], 0.02)
+    f.c.values().mul_(1e7)
+    f.costs_changed()
+    res = f.calculate(torch.from_numpy(lam).float().to(DEV), gamma=0.05, save_primal=True)
+    ax, obj0, ssq, x = oracle.matching_calculate(p["m"], p["n"], p["colptr"], p["rowidx"], p["a"], p["c"] * 1e7, lam, 0.05, [("box", {"lower": 0.0, "upper": 1.0})], dtype=np.float32)
+    grad, obj, reg, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, p["b"], 0.05, np.float32)
+    assert relerr(res.primal_var.cpu().numpy(), x) < RTOL["f32"]
+    assert relerr([float(res.dual_objective)], [obj]) < RTOL["f32"] * 10  # (garbage before: |c.x| * 2^shift left the 2^51 window of the conversion)
+    f.c.values()[7] = float("nan")
+    with pytest.raises((HipLibraryError, RuntimeError, ValueError), match="inf or NaN"):
+        f.costs_changed()

@@ -458,3 +458,41 @@ def test_build_lists_cover_every_source_and_header():
     for name, lanes, f64 in (("matching_kernels4.hip", 0, 0), ("matching_kernels4_f64.hip", 0, 1), ("matching_kernels4_lanes.hip", 1, 0), ("matching_kernels4_lanes_f64.hip", 1, 1)):
         text = open(os.path.join(_build.CSRC, name)).read()
         assert f"#define DL_FUSED4_LANES {lanes}" in text and f"#define DL_FUSED4_F64 {f64}" in text and '#include "fused4_kernel.h"' in text
+
+
+def test_local_shard_says_when_balanced_cannot_be_honoured_and_builds_empty_shards():
+    """run_solver._local_shard: partition='balanced' on a map without contiguous range blocks falls back to the reference's cut WITH a
+    warning (not silently); a rank whose share of every block is empty gets an empty shard instead of a torch.cat error."""
+    import warnings
+
+    import numpy as np
+    import torch
+
+    from dualip_amd.objectives.matching import MatchingInputArgs
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.run_solver import _local_shard
+
+    n, m = 6, 4
+    colptr = torch.arange(0, 2 * n + 1, 2)
+    rows = torch.tensor([0, 1] * n)
+    vals = torch.arange(1.0, 2 * n + 1)
+    A = torch.sparse_csc_tensor(colptr, rows, vals, size=(m, n))
+    C = torch.sparse_csc_tensor(colptr, rows, -vals, size=(m, n))
+    # two range blocks of 3 columns each, 4 ranks: rank 3's share of both blocks is empty
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, None, indices=range(0, 3)), **create_projection_map("simplex", {"z": 1.0}, None, indices=range(3, 6))}
+    inp = MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.ones(m))
+    widths = []
+    for r in range(4):
+        sh = _local_shard(inp, r, 4, "cpu", "balanced")
+        widths.append(int(sh.A.size(1)))
+        assert sh.A.values().numel() == 2 * widths[-1] and sh.A.ccol_indices().numel() == widths[-1] + 1
+    assert widths == [2, 2, 2, 0], widths
+    # index LISTS: no blocks to share out -> the reference's contiguous cut, said out loud
+    pm_list = create_projection_map("simplex", {"z": 1.0}, n, indices=[0, 1, 2, 3, 4, 5])
+    inp2 = MatchingInputArgs(A=A, c=C, projection_map=pm_list, b_vec=torch.ones(m))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sh = _local_shard(inp2, 1, 4, "cpu", "balanced")
+    assert any("partition='balanced'" in str(x.message) for x in w)
+    assert int(sh.A.size(1)) == 2  # n // W (+1 for the first n % W ranks): 2, 2, 1, 1
+    assert np.array_equal(sh.A.values().numpy(), vals.numpy()[4:8])
