@@ -77,6 +77,8 @@ def parse():
                     "3-step run of the same workload as child processes, 2 x FETCH_SIZE + WRITE_SIZE KiB per fused launch (gfx950 corrections of "
                     "MI355X_MICROARCH.md; calibration profiles/r02_fetch_size_calibration.json)")
     ap.add_argument("--record-traffic", action="store_true", help="with --measure-traffic: store the figure, the commit and the kernel layout it belongs to in profiles/traffic.json")
+    ap.add_argument("--release-inputs", action="store_true", help="N = 1: after every other leg, make the kernel handle self-contained (objective.release_inputs()), drop the "
+                    "generator's tensors, and time the window again -- aux.footprint: resident bytes before / after next to the bytes one launch streams")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="with --emulate-world: which rank's shard to hold (default: the most expensive one of the partition)")
     ap.add_argument("--force-sharded", action="store_true", help="take the N>1 code path (distributed objective + exchange) even with one rank")
     ap.add_argument("--emulate-world", type=int, default=0, help="developer aid: with --force-sharded and one rank, hold rank 0's shard of a W-rank run and "
@@ -675,6 +677,23 @@ def main():
             comm2.close()
         del f2, bi2, b2
 
+    # ---- footprint: the handle self-contained, the caller's CSC tensors gone -------------------------------------------------
+    footprint = None
+    if args.release_inputs and not sharded:
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated(device)
+        rel = f.release_inputs()
+        inp.A = inp.c = None
+        del block_inputs[:]
+        gc.collect()
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_allocated(device)
+        el3, ln3, kms3, _, _, _res3 = headline(f, local, comm)
+        footprint = {"torch_allocated_before": before, "torch_allocated_after": after, "handle_owned_bytes": rel["owned_bytes"], "kept_elements_of_the_csc_arrays": rel["kept_elements"],
+                     "streamed_bytes_per_launch": phys_bytes, "owned_over_streamed": rel["owned_bytes"] / phys_bytes,
+                     "note": "torch_allocated counts the generator's CSC tensors (values + int64 indices) and solver state, not the handle's hipMalloc'ed memory (handle_owned_bytes)",
+                     "ms_per_step_after_release": el3 / args.steps * 1e3, "kernel_avg_ms_after_release": kms3 / max(ln3, 1), "ms_per_step_before": elapsed / args.steps * 1e3}
+
     # A launch whose bytes fit the 256 MB Infinity Cache is not bound by HBM at all (BASELINE config 2: 1M entities = 120 MB): its
     # yardstick is what a plain streaming-read launch reaches over a buffer of THAT size on this box (launch included, best of 20)
     cache_resident = None
@@ -756,6 +775,7 @@ def main():
                 "read_ceiling_GBps": read_ceiling_gbps(device),
                 "traffic_counters": traffic_details,
                 "cache_resident": cache_resident,
+                "footprint": footprint,
             },
         }
         rc_gbps = out["aux"]["read_ceiling_GBps"]
@@ -766,7 +786,7 @@ def main():
                                         "bracket": "end of the fused pass -> end of the step's first kernel (slab reduction + exchange + gradient statistics)"}
         elif sharded:
             out["aux"]["collective"] = {**(collective or {}), "backend": "torch.distributed", "fallback_reason": getattr(f, "comm_fallback", None)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and inp.A is not None:
             inp.b_vec = b_vec
             out["cpu_baseline"] = cpu_baseline(args, inp, pm_local, total_nnz)
         else:

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "dl_comm_info": (_c_i64, [_c_vp, _c_int]),
     "dl_allreduce_sum": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp]),
     "dl_comm_check": (_c_int, [_c_vp, _c_vp]),
+    "dl_matching_own_inputs": (_c_int, [_c_vp, _c_vp]),
     "dl_comm_status": (_c_int, [_c_vp, ctypes.POINTER(ctypes.c_int32), _c_vp]),
     "dl_comm_inject_fault": (_c_int, [_c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64]),
     "dl_comm_set_emulation": (_c_int, [_c_vp, _c_dbl]),

@@ -112,6 +112,26 @@ static int reencode_rows(dl_matching* h, const void* rowidx, hipStream_t st, int
     return 0;
 }
 
+// one past the last non-zero of a column whose ENTRY has no column-per-lane slices (window tiles and their single-column tiles read
+// those in place)
+template <class IdxT>
+__global__ void unsliced_end_kernel(int64_t n, const IdxT* __restrict__ colptr, const int32_t* __restrict__ col_proj, const uint8_t* __restrict__ pid_sell, int32_t n_sell_flags,
+                                    int32_t n_proj, unsigned long long* __restrict__ out) {
+    unsigned long long best = 0ull;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k0 = (int64_t)colptr[j], k1 = (int64_t)colptr[j + 1];
+        const int64_t len = k1 - k0;
+        if (len <= 0) continue;
+        const int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
+        const uint8_t fl = (pid >= 0 && pid < n_sell_flags) ? pid_sell[pid] : (uint8_t)0;
+        // (columns of a SLICED entry that are too long for a slice are single-column tiles read in place, scattered over the entry's
+        //  range: dl_matching_own_inputs moves those into a pool -- only the columns of entries without slices define the prefix)
+        if (fl == 0) best = (unsigned long long)k1 > best ? (unsigned long long)k1 : best;
+    }
+    best = (unsigned long long)wave_allreduce((long long)best, OpMax());
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+
 static int owned_malloc(dl_matching* h, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
@@ -123,6 +143,8 @@ static int owned_malloc(dl_matching* h, void** p, size_t bytes) {
 static void matching_free(dl_matching* h) {
     if (!h) return;
     if (h->rowidx) (void)hipFree(h->rowidx);
+    if (h->own_a) (void)hipFree(h->own_a);
+    if (h->own_c) (void)hipFree(h->own_c);
     if (h->tiles) (void)hipFree(h->tiles);
     if (h->wg_tile_begin) (void)hipFree(h->wg_tile_begin);
     if (h->projs) (void)hipFree(h->projs);
@@ -578,6 +600,11 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             std::vector<uint32_t>& wv = !is_long ? short_words : (len > xlong_min ? xlong_words : long_words);
             std::vector<uint32_t>& pv = !is_long ? short_pid : (len > xlong_min ? xlong_pid : long_pid);
             wv.insert(wv.end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
+            if (is_long) {  // words 4 / 5: where the column's PRIMAL goes (the caller's order) -- the same place the column is read from, until
+                            // dl_matching_own_inputs moves a straggler of a sliced entry into the handle's pool and rewrites words 0 / 1
+                wv[wv.size() - 12 + 4] = words4[t * 12];
+                wv[wv.size() - 12 + 5] = words4[t * 12 + 1] & 0xFFu;
+            }
             pv.push_back(tile_pid4[t]);
         }
         // longest first, dealt in snake order (wavefront W takes slots W, W + S, ...: reversing every other round pairs the
@@ -743,9 +770,24 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     e = hipMemcpyAsync(row_count_h.data(), row_count_dev, sizeof(unsigned int) * row_count_h.size(), hipMemcpyDeviceToHost, st);
     // max |a|, max |c| (bound for the fixed-point gradient accumulation) and max |projection parameter|
     unsigned long long* mx_dev = nullptr;
-    unsigned long long mx_host[2] = {0, 0};
-    if (e == hipSuccess) e = hipMalloc((void**)&mx_dev, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(mx_dev, 0, 2 * sizeof(unsigned long long), st);
+    unsigned long long mx_host[3] = {0, 0, 0};
+    uint8_t* sell_flags_dev = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&mx_dev, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(mx_dev, 0, 3 * sizeof(unsigned long long), st);
+    if (e == hipSuccess && h->layout == 4 && n > 0) {  // where the in-place reads of the caller-ordered arrays end (dl_matching_own_inputs)
+        if (!pid_sell.empty()) {
+            e = hipMalloc((void**)&sell_flags_dev, pid_sell.size());
+            if (e == hipSuccess) e = hipMemcpyAsync(sell_flags_dev, pid_sell.data(), pid_sell.size(), hipMemcpyHostToDevice, st);
+        }
+        if (e == hipSuccess) {
+            const int blocks = (int)std::min<int64_t>(4096, (n + 255) / 256);
+            if (idx_dtype == DL_I64)
+                hipLaunchKernelGGL(unsliced_end_kernel<int64_t>, dim3(blocks), dim3(256), 0, st, n, (const int64_t*)colptr, col_proj, sell_flags_dev, (int32_t)pid_sell.size(), n_proj, mx_dev + 2);
+            else
+                hipLaunchKernelGGL(unsliced_end_kernel<int32_t>, dim3(blocks), dim3(256), 0, st, n, (const int32_t*)colptr, col_proj, sell_flags_dev, (int32_t)pid_sell.size(), n_proj, mx_dev + 2);
+            e = hipGetLastError();
+        }
+    }
     if (e == hipSuccess) e = hipMemsetAsync(h->shift_dev, 0, 2 * sizeof(int), st);
     if (e == hipSuccess && launch_absmax(val_dtype, nnz, a, mx_dev, st)) e = hipErrorUnknown;
     if (e == hipSuccess && launch_absmax(val_dtype, nnz, c, mx_dev + 1, st)) e = hipErrorUnknown;
@@ -756,10 +798,12 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     (void)hipFree(bad_dev);
     (void)hipFree(row_count_dev);
     if (mx_dev) (void)hipFree(mx_dev);
+    if (sell_flags_dev) (void)hipFree(sell_flags_dev);
     if (e != hipSuccess) {
         matching_free(h);
         return hip_fail(e, "create sync");
     }
+    h->unsliced_end = h->layout == 4 ? (int64_t)mx_host[2] : nnz;
     memcpy(&h->amax, &mx_host[0], sizeof(double));
     memcpy(&h->cmax, &mx_host[1], sizeof(double));
     if (!std::isfinite(h->amax) || !std::isfinite(h->cmax)) {  // (absmax_kernel: any inf / NaN element surfaces here)
@@ -889,6 +933,8 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 15: return h->n_sell_nnz;
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
+        case 2001: return h->owns_inputs ? 1 : 0;
+        case 2002: return h->owns_inputs ? h->own_count : h->unsliced_end;  // non-zeros read in place from the (caller's / owned) CSC-ordered arrays
         case 2000: return h->n_sell_lane_cols;
         default:
             if (what >= 18 && what < 18 + 1024) {  // rounds of workgroup (what - 18) in the window tiles' deal (synchronous read; -1: no table)
@@ -973,8 +1019,101 @@ static int refresh_absmax(dl_matching* h, const void* values, double* out, hipSt
     return 0;
 }
 
+// copies straggler columns (single-column tiles of sliced entries) into the owned arrays' pool: one block per column
+template <class T, class RowT>
+__global__ void pool_copy_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ dst, const uint64_t* __restrict__ len, const T* __restrict__ a, const T* __restrict__ c,
+                                 const RowT* __restrict__ r, T* __restrict__ oa, T* __restrict__ oc, RowT* __restrict__ orow) {
+    const uint64_t s0 = src[blockIdx.x], d0 = dst[blockIdx.x], n = len[blockIdx.x];
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        oa[d0 + i] = a[s0 + i];
+        oc[d0 + i] = c[s0 + i];
+        orow[d0 + i] = r[s0 + i];
+    }
+}
+
+int dl_matching_own_inputs(dl_matching* h, dl_stream_t stream) {
+    if (!h) return fail(DL_E_ARG, "null handle");
+    if (h->owns_inputs) return 0;
+    if (h->layout != 4) return fail(DL_E_STATE, "only handles of the 256-wide tile layout can own their inputs (unaligned or tiny inputs keep borrowing)");
+    if (h->fair) return fail(DL_E_STATE, "a handle with the fairness stream borrows three arrays; release is not offered for it");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t vs = h->val_dtype == DL_F32 ? 4 : 8;
+    // the prefix window tiles (and the single-column tiles of entries without slices) read in place: [0, unsliced_end) -- plus one
+    // window's width, because a window's loads cover 256 slots from its start (clamped to the arrays' end); never less than the 256
+    // slots at index 0 that the padding descriptors' unconditional prefetches touch
+    int64_t keep = h->unsliced_end + 256;
+    keep = (keep + 255) / 256 * 256;
+    if (keep > h->nnz) keep = h->nnz;
+    // stragglers: single-column tiles (of sliced entries) that reach beyond the prefix -> a pool behind it; their descriptors' read
+    // offset (words 0 / 1) moves, the primal's position (words 4 / 5) stays
+    const int64_t n_single = h->n_tiles - h->n_short;  // one-wavefront and whole-workgroup tiles
+    uint32_t* long_dev = reinterpret_cast<uint32_t*>(h->tiles) + (size_t)h->n_short * (size_t)h->desc_words + 12;
+    std::vector<uint32_t> lw((size_t)n_single * 12);
+    if (n_single > 0) {
+        DL_HIP(hipMemcpyAsync(lw.data(), long_dev, lw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        DL_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<uint64_t> src, dst, len;
+    int64_t total = keep;
+    for (int64_t t = 0; t < n_single; ++t) {
+        uint32_t* w = &lw[(size_t)t * 12];
+        const uint64_t k0 = (((uint64_t)w[1] << 32) | w[0]) & ((1ull << 40) - 1);
+        const uint64_t L = ((uint64_t)w[3] << 32) | w[2];
+        if (k0 + L <= (uint64_t)keep) continue;
+        src.push_back(k0);
+        dst.push_back((uint64_t)total);
+        len.push_back(L);
+        w[0] = (uint32_t)((uint64_t)total & 0xFFFFFFFFu);
+        w[1] = (w[1] & ~0xFFu) | (uint32_t)(((uint64_t)total >> 32) & 0xFFu);
+        total += ((int64_t)L + 3) / 4 * 4;
+    }
+    void *na = nullptr, *nc = nullptr, *nr = nullptr;
+    uint64_t* lists = nullptr;
+    hipError_t e = hipMalloc(&na, (size_t)total * vs);
+    if (e == hipSuccess) e = hipMalloc(&nc, (size_t)total * vs);
+    if (e == hipSuccess) e = hipMalloc(&nr, (size_t)total * (size_t)h->row_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(na, h->a, (size_t)keep * vs, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nc, h->c, (size_t)keep * vs, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(nr, h->rowidx, (size_t)keep * (size_t)h->row_bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && !src.empty()) {
+        const size_t ns = src.size();
+        e = hipMalloc((void**)&lists, 3 * ns * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(lists, src.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(lists + ns, dst.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(lists + 2 * ns, len.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            if (vs == 4 && h->row_bytes == 2) hipLaunchKernelGGL((pool_copy_kernel<float, uint16_t>), dim3((unsigned)ns), dim3(256), 0, st, lists, lists + ns, lists + 2 * ns, (const float*)h->a, (const float*)h->c, (const uint16_t*)h->rowidx, (float*)na, (float*)nc, (uint16_t*)nr);
+            else if (vs == 4) hipLaunchKernelGGL((pool_copy_kernel<float, uint32_t>), dim3((unsigned)ns), dim3(256), 0, st, lists, lists + ns, lists + 2 * ns, (const float*)h->a, (const float*)h->c, (const uint32_t*)h->rowidx, (float*)na, (float*)nc, (uint32_t*)nr);
+            else if (h->row_bytes == 2) hipLaunchKernelGGL((pool_copy_kernel<double, uint16_t>), dim3((unsigned)ns), dim3(256), 0, st, lists, lists + ns, lists + 2 * ns, (const double*)h->a, (const double*)h->c, (const uint16_t*)h->rowidx, (double*)na, (double*)nc, (uint16_t*)nr);
+            else hipLaunchKernelGGL((pool_copy_kernel<double, uint32_t>), dim3((unsigned)ns), dim3(256), 0, st, lists, lists + ns, lists + 2 * ns, (const double*)h->a, (const double*)h->c, (const uint32_t*)h->rowidx, (double*)na, (double*)nc, (uint32_t*)nr);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(long_dev, lw.data(), lw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (lw / src / dst / len are host objects)
+    if (lists) (void)hipFree(lists);
+    if (e != hipSuccess) {
+        if (na) (void)hipFree(na);
+        if (nc) (void)hipFree(nc);
+        if (nr) (void)hipFree(nr);
+        return hip_fail(e, "dl_matching_own_inputs");
+    }
+    (void)hipFree(h->rowidx);  // the re-encoded rows of the sliced columns live in the slices' transposed copy
+    h->owned_bytes -= (size_t)h->nnz * (size_t)h->row_bytes;
+    h->rowidx = nr;
+    h->own_a = na;
+    h->own_c = nc;
+    h->a = na;
+    h->c = nc;
+    h->own_count = total;
+    h->owned_bytes += (size_t)total * (2 * vs + (size_t)h->row_bytes);
+    h->owns_inputs = true;
+    return 0;
+}
+
 int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
+    if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): it no longer sees the caller's arrays -- build a new handle for new values");
     hipStream_t st = (hipStream_t)stream;
     if (h->nnz > 0) {  // max |c| scales the fixed-point sums c.x / sum x^2 (fused_common.h: scalar_shift) and bounds |v| for projections that do not bound x
         int rc = refresh_absmax(h, h->c, &h->cmax, st);
@@ -985,6 +1124,7 @@ int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
 
 int dl_matching_update_values(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
+    if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): it no longer sees the caller's arrays -- build a new handle for new values");
     hipStream_t st = (hipStream_t)stream;
     if (h->nnz > 0) {  // max |a| scales the fixed-point gradient; max |c| as in dl_matching_update_costs
         int rc = refresh_absmax(h, h->a, &h->amax, st);

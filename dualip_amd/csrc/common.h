@@ -75,6 +75,13 @@ struct dl_matching {
     const void* a = nullptr;  // caller-owned
     const void* c = nullptr;  // caller-owned
     void* rowidx = nullptr;   // owned, uint16 or uint32
+    // dl_matching_own_inputs: the handle stops borrowing -- it keeps its own copy of the value arrays' prefix that window tiles, single-
+    // column tiles and in-place slices read (everything the column-per-lane slices hold lives in the handle's transposed copies already)
+    void* own_a = nullptr;    // owned, val[own_count] or null
+    void* own_c = nullptr;
+    int64_t own_count = 0;    // elements of the owned prefix
+    int64_t unsliced_end = 0; // one past the last non-zero a tile reads in place from a / c / rowidx (0: every column is sliced)
+    bool owns_inputs = false;
     int row_bytes = 4;
     dl::TileDesc* tiles = nullptr;      // owned (layout 1: TileDesc[]; layout 4: 12 dwords per tile)
     int layout = 1;                     // 1 = one non-zero per lane (64-wide tiles), 4 = four per lane (256-wide tiles)

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
             double ol = 0.0, ql = 0.0;  // (this column's sums of this thread: one rounded integer each)
             process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
-                                                      FAIR ? &fair : nullptr);
+                                                      FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words);
             fx_add_wide(acc, ol, ql, w.scale2);
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     //  first: the G longest then sit on G different CUs instead of sixteen to a CU, and a handful of them no longer all land on
     //  workgroup 0)
     //  (... counted from the LAST wavefront of a workgroup down: wavefront 0's stamps feed the balance of the window tiles)
-    auto walk_long = [&](uint32_t dvl) __attribute__((always_inline)) {
+    auto walk_long = [&](uint32_t dvl, const uint32_t* desc) __attribute__((always_inline)) {
         const FusedArgs<T>& gk = kernarg_args(g);
         const uint32_t w0lo = rl(dvl, 0), w0hi = rl(dvl, 1), pidl = rl(dvl, 10);
         const ProjT<T> pl = lookup_proj(gk, w.proj_s, pidl);
@@ -212,20 +212,21 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             // flight at once, the values kept in registers, straight-line passes, reductions on the DPP unit
             if (is_simplex_kind(pl.kind) && len <= 1024 && !(gk.ablate & 1024)) {
                 const int L = (int)len, H = (L + 63) >> 6, Hmin = L >> 6;
+                const uint64_t kx = (((uint64_t)rl(dvl, 5) << 32) | rl(dvl, 4)) & ((1ull << 40) - 1);  // the column's place in the caller's order (primal)
                 const int len_lane = (L - lane + 63) >> 6;
                 constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
                 switch ((H + 3) >> 2) {
-                    case 1: sell_slice<T, RowT, 4, (4 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
-                    case 2: sell_slice<T, RowT, 8, (8 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
-                    case 3: sell_slice<T, RowT, 12, (12 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
-                    default: sell_slice<T, RowT, 16, (16 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, 0, true, lane, sd, eq_row, acc, fair); break;
+                    case 1: sell_slice<T, RowT, 4, (4 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
+                    case 2: sell_slice<T, RowT, 8, (8 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
+                    case 3: sell_slice<T, RowT, 12, (12 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
+                    default: sell_slice<T, RowT, 16, (16 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
                 }
                 return;
             }
         }
         double ol = 0.0, ql = 0.0;
         process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
-                                            FAIR ? &fair : nullptr);
+                                            FAIR ? &fair : nullptr, desc);
         fx_add_wide(acc, ol, ql, w.scale2);
     };
     // The second binary deals single-column tiles and K-lane slices to WORKGROUPS statically (workgroup w owns slots w, w + G, ...
@@ -255,24 +256,25 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         }
         __syncthreads();
         const uint32_t n_long = g.n_long, G = gridDim.x;
-        auto desc_of = [&](uint32_t j) -> uint32_t {
+        auto desc_at = [&](uint32_t j) -> const uint32_t* {
             const uint64_t q = (uint64_t)j * G + (uint32_t)wg;
-            return byte_offset(kernarg_args(g).long32 + (size_t)(q < n_long ? q : (n_long ? n_long - 1u : 0u)) * kDesc4Words, dlane * 4u)[0];
+            return kernarg_args(g).long32 + (size_t)(q < n_long ? q : (n_long ? n_long - 1u : 0u)) * kDesc4Words;
         };
+        auto desc_of = [&](uint32_t j) -> uint32_t { return byte_offset(desc_at(j), dlane * 4u)[0]; };
         if (n_long) {
             uint32_t j = claim(&wg_ctr[0]);
             uint32_t dvl = desc_of(j);
             while ((uint64_t)j * G + (uint32_t)wg < n_long) {
                 const uint32_t jn = claim(&wg_ctr[0]);
                 const uint32_t dvn = desc_of(jn);  // (travels while the current column is walked)
-                walk_long(dvl);
+                walk_long(dvl, desc_at(j));
                 j = jn;
                 dvl = dvn;
             }
         }
     } else {
         for (uint32_t lt = (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + (uint32_t)wg; lt < g.n_long; lt += S)
-            walk_long(byte_offset(kernarg_args(g).long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0]);
+            walk_long(byte_offset(kernarg_args(g).long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0], kernarg_args(g).long32 + (size_t)lt * kDesc4Words);
     }
     // the slices of the long columns (K lanes per column), every wavefront, ahead of everything cheap (sell.h)
     // (dealt like the single-column tiles above: one per workgroup before any workgroup gets a second)

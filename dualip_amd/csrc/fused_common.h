@@ -205,7 +205,7 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 template <class T, class RowT, bool LAM_LDS, bool WG = false>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
-                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr) {
+                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr) {
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
     auto all_sum = [&](double x) -> double {
@@ -397,7 +397,12 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             obj += (double)(T)(cv[u] * x);
             ssq += (double)(T)(x * x);
             if (fair_acc) *fair_acc += (double)(T)(g.fair[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] * x);
-            if (g.x_out) g.x_out[k0 + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] = x;
+            if (g.x_out) {
+                // where the primal goes: the column's place in the CALLER's order (descriptor words 4 / 5, re-read here: cold) -- the place
+                // it is read from, unless dl_matching_own_inputs moved the column into the handle's pool
+                const uint64_t kx = desc ? ((((uint64_t)desc[5] << 32) | desc[4]) & ((1ull << 40) - 1)) : k0;
+                g.x_out[kx + o0 + (uint64_t)lane + (uint64_t)kStride * (uint64_t)u] = x;
+            }
         }
     }
 }

@@ -310,7 +310,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     const FusedArgs<T>& gk = kernarg_args(g);
     T* xo = gk.x_out;
     uint64_t k0 = 0;
-    if (xo && has_col) k0 = (ORIG ? base : gk.sell_colstart[dense]) + (uint64_t)(lane & ((1 << KLOG) - 1));  // this lane's first element of the column
+    if (xo && has_col) k0 = (ORIG ? dense : gk.sell_colstart[dense]) + (uint64_t)(lane & ((1 << KLOG) - 1));  // (ORIG: `dense` IS the column's place in the caller's order)  // this lane's first element of the column
     if constexpr (!RELOAD) {
         // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
         //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)

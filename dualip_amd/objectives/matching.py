@@ -282,6 +282,21 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
             return dual_val, dual_grad
         return dual_val / self.row_norms, dual_grad * self.row_norms
 
+    def release_inputs(self) -> dict:
+        """Make the kernel handle self-contained and drop this objective's references to ``A`` and ``c`` (include/dualip_hip.h:
+        dl_matching_own_inputs).  The reference's objective keeps both tensors for its lifetime (matching.py:79-85) -- 24 bytes per
+        non-zero with torch's int64 indices -- although, here, columns held in column-per-lane slices are never read from them
+        again.  After this call the handle owns the prefix of the value / row arrays its tiles read in place and NOTHING of the
+        caller's: once the caller drops its own references too, the resident footprint is the handle's ``owned_bytes`` (about the
+        bytes one launch streams).  Results are bit-identical.  ``values_changed`` / ``costs_changed`` are refused afterwards, and
+        ``objective.A`` / ``.c`` become None.  Returns {"owned_bytes", "kept_elements"}."""
+        if self._custom is not None:
+            raise NotImplementedError("objectives with user-defined projection operators read A and c with torch ops every iteration")
+        with torch.cuda.device(self.device):
+            _hip.check(self._lib.dl_matching_own_inputs(self._handle, _hip.stream_ptr(self.device)))
+        self.A = self.c = self._a_vals = self._c_vals = None
+        return {"owned_bytes": int(self._lib.dl_matching_info(self._handle, 5)), "kept_elements": int(self._lib.dl_matching_info(self._handle, 2002))}
+
     def values_changed(self) -> None:
         """Tell the kernel handle that the values of ``A`` (and possibly ``c``) were rewritten in place, pattern unchanged.
 

@@ -92,6 +92,16 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
                        int32_t n_proj, const int32_t* col_proj, dl_stream_t stream);
 int dl_matching_destroy(dl_matching* h);
 
+/* Footprint: make the handle SELF-CONTAINED.  A handle borrows the caller's value arrays (window tiles, single-column tiles and in-place
+ * slices read them every launch) although the columns it keeps in column-per-lane slices are never read from them again, and it owns
+ * re-encoded row indices for all nnz.  After this call it owns a copy of the prefix [0, K) of a / c / rows that tiles read in place
+ * (K = one window past the last non-zero of a column that is not sliced: half the arrays for the benchmark's box-then-simplex map, a
+ * few hundred elements for an all-simplex one) and never touches the caller's arrays again -- the caller may free A and c (the
+ * reference keeps them alive for the objective's lifetime, matching.py:79-85: 16 + 8 bytes per non-zero with int64 indices).  Results
+ * are bit-identical.  dl_matching_update_costs / _values are refused afterwards.  dl_matching_info(h, 2001) = 1 once owned,
+ * (h, 2002) = K.  Only handles of the 256-wide layout without the fairness stream. */
+int dl_matching_own_inputs(dl_matching* h, dl_stream_t stream);
+
 /* The caller rewrote the values of c in place (same pattern): refresh what the handle derived from them -- the transposed copy
  * the column-per-lane slices read, and max |c| when a projection in use does not bound x itself.  A stays read-only (the
  * fixed-point scale of the gradient is taken from it).  Use: re-solving with new costs on the same graph; the folded form of

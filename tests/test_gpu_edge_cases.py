@@ -536,3 +536,54 @@ def test_non_finite_values_are_refused_and_rescaled_costs_keep_the_objective_exa
     f.c.values()[7] = float("nan")
     with pytest.raises((HipLibraryError, RuntimeError, ValueError), match="inf or NaN"):
         f.costs_changed()
+
+
+@pytest.mark.parametrize("order", ["box_then_simplex", "simplex_then_box", "all_simplex"])
+def test_release_inputs_makes_the_handle_self_contained(order):
+    """``objective.release_inputs()`` (dl_matching_own_inputs): the handle copies the prefix of a / c / rows its tiles read in place and
+    stops borrowing; the caller's tensors can then be freed.  Results are bit-identical (calculate, primal, and a device-resident
+    solve), the kept prefix is what the map implies (half the arrays for box-then-simplex, next to nothing for all-simplex, all of it
+    when the un-sliced block comes last), value refreshes are refused afterwards."""
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+
+    p = _random_problem(500, 60000, 9, seed=21, long_cols=[(7, 300), (59990, 400)])
+    n, half = p["n"], p["n"] // 2
+    box, simplex = ("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})
+    first, second = {"box_then_simplex": (box, simplex), "simplex_then_box": (simplex, box), "all_simplex": (simplex, simplex)}[order]
+    pm = {**create_projection_map(first[0], dict(first[1]), None, indices=range(0, half)), **create_projection_map(second[0], dict(second[1]), None, indices=range(half, n))}
+    lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.05, p["m"])).float().to(DEV)
+    kw = dict(max_iter=40, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
+
+    def run(release):
+        args = torch_args(p, "f32", pm, DEV)
+        f = MatchingSolverDualObjectiveFunction(args, gamma=0.02)
+        assert f.info()["layout"] == 4 and f.info()["slices"] > 0
+        out = None
+        if release:
+            before = torch.cuda.memory_allocated()
+            out = f.release_inputs()
+            assert f.A is None and f.c is None
+            del args  # the caller drops its tensors too: 8 bytes of values + 8 of int64 row indices per non-zero go away
+            torch.cuda.synchronize()
+            out["freed"] = before - torch.cuda.memory_allocated()
+        r = f.calculate(lam, gamma=0.02, save_primal=True)
+        res = AcceleratedGradientDescent(**kw).maximize(f, torch.zeros(p["m"], dtype=torch.float32, device=DEV))
+        if release:
+            with pytest.raises((RuntimeError, ValueError), match="owns its inputs"):
+                f.costs_changed()
+        return r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective), list(res.dual_objective_log), res.dual_val.clone(), out
+
+    g0, x0, o0, log0, d0, _ = run(False)
+    g1, x1, o1, log1, d1, info = run(True)
+    assert torch.equal(g0, g1) and torch.equal(x0, x1) and o0 == o1 and log0 == log1 and torch.equal(d0, d1)
+    nnz = int(p["colptr"][-1])
+    k_half = int(p["colptr"][half])
+    if order == "box_then_simplex":  # the long simplex column near the end (a K-lane slice, or a straggler moved to the pool) does not extend the prefix
+        assert k_half <= info["kept_elements"] <= k_half + 1024, (info, k_half)
+    elif order == "all_simplex":
+        assert info["kept_elements"] <= 1280, info  # 256 slots for the padding descriptors' prefetch + at most the two long columns
+    else:
+        assert info["kept_elements"] == nnz, info
+    assert info["freed"] > 0 or order == "simplex_then_box"
