@@ -132,6 +132,18 @@ __global__ void unsliced_end_kernel(int64_t n, const IdxT* __restrict__ colptr, 
     if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
 }
 
+// copies straggler columns (single-column tiles of sliced entries) into the owned arrays' pool: one block per column
+template <class T, class RowT>
+__global__ void pool_copy_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ dst, const uint64_t* __restrict__ len, const T* __restrict__ a, const T* __restrict__ c,
+                                 const RowT* __restrict__ r, T* __restrict__ oa, T* __restrict__ oc, RowT* __restrict__ orow) {
+    const uint64_t s0 = src[blockIdx.x], d0 = dst[blockIdx.x], n = len[blockIdx.x];
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        oa[d0 + i] = a[s0 + i];
+        oc[d0 + i] = c[s0 + i];
+        orow[d0 + i] = r[s0 + i];
+    }
+}
+
 static int owned_malloc(dl_matching* h, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
@@ -1017,18 +1029,6 @@ static int refresh_absmax(dl_matching* h, const void* values, double* out, hipSt
     if (!std::isfinite(v)) return fail(DL_E_ARG, "the rewritten values hold an inf or NaN: the exact fixed-point sums of the fused pass are undefined for it");
     *out = v;
     return 0;
-}
-
-// copies straggler columns (single-column tiles of sliced entries) into the owned arrays' pool: one block per column
-template <class T, class RowT>
-__global__ void pool_copy_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ dst, const uint64_t* __restrict__ len, const T* __restrict__ a, const T* __restrict__ c,
-                                 const RowT* __restrict__ r, T* __restrict__ oa, T* __restrict__ oc, RowT* __restrict__ orow) {
-    const uint64_t s0 = src[blockIdx.x], d0 = dst[blockIdx.x], n = len[blockIdx.x];
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        oa[d0 + i] = a[s0 + i];
-        oc[d0 + i] = c[s0 + i];
-        orow[d0 + i] = r[s0 + i];
-    }
 }
 
 int dl_matching_own_inputs(dl_matching* h, dl_stream_t stream) {

@@ -453,10 +453,15 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         a_bb = (T)bt;
         a_omb = (T)(float)(1.0f - bt);
     }
-    {   // latency bound (every workgroup pulls the whole dual vector from L2): twelve loads in flight per thread -- the benchmark's
-        // 10^4 duals in ONE round trip instead of three
-        constexpr int kU = 12;
-        for (int64_t i0 = tid; i0 < g.m; i0 += (int64_t)kU * kFusedThreads) {
+    // Rows to pull: all of them when their maximum matters (projections that do not bound x take their |v| bound from max |lambda|) or
+    // when this launch applies the optimiser step (workgroup 0 stores every row of the new iterate); otherwise only the rows that live
+    // in LDS -- under the hot-rows plan the cold tail is read by the tiles that need it, and staging it here cost the MovieLens shape
+    // (26 744 rows, 12 928 of them hot) a third dependent L2 round trip per launch.
+    const int64_t m_pull = (g.has_unbounded || applying || g.m_hot <= 0) ? g.m : m_lds;
+    {   // latency bound (every workgroup pulls the dual vector from L2): thirteen loads in flight per thread -- the benchmark's 10^4 duals,
+        // and the most rows a hot-rows plan keeps in LDS (< 13 312), in ONE round trip
+        constexpr int kU = 13;
+        for (int64_t i0 = tid; i0 < m_pull; i0 += (int64_t)kU * kFusedThreads) {
             T l[kU];
             if (!applying) {
 #pragma unroll
