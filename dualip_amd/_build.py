@@ -337,6 +337,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 return LIB_PATH
             if force:
                 shutil.rmtree(os.path.join(LIB_DIR, "obj"), ignore_errors=True)
+            built_from = source_hash()  # (taken BEFORE compiling: a file edited while hipcc runs must leave the library stale, not fresh)
             hipcc, objs = _compile_objects(verbose)
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs, "-ldl"]
@@ -349,7 +350,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, LIB_PATH)  # atomic: a process that already mapped the old file keeps it
             with open(HASH_PATH + ".tmp", "w") as fh:
-                fh.write(source_hash())
+                fh.write(built_from)
             os.replace(HASH_PATH + ".tmp", HASH_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

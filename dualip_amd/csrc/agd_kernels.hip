@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
         dg2 = wave_allreduce_dpp(dg2, OpAdd());
         dy2 = wave_allreduce_dpp(dy2, OpAdd());
         if constexpr (SRC == 2) {  // what this block read from the mailbox, hashed: the step that consumes the statistics adds the blocks up
-            chk_read = (unsigned long long)wave_allreduce((long long)chk_read, OpAdd());  // and compares with the announced total (agd_step.h)
+            chk_read = chk_wave_sum(chk_read);  // and compares with the announced total (agd_step.h)
             if (tid == 0) p.chk_partial[blockIdx.x] = chk_read;
         }
         if (tid == 0) {

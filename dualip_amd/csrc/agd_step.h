@@ -124,7 +124,11 @@ __device__ __forceinline__ double agd_step_scalars(const ApplyArgs<T>& p, int la
     if (writer && tid < 64 && p.chk) {  // (wave-uniform: one wavefront of one workgroup) did the exchange deliver what its senders announced?
         unsigned long long got = 0ull;
         for (int k = lane; k < p.n_blocks + 1; k += 64) got += p.chk[k];
-        got = (unsigned long long)wave_allreduce((long long)got, OpAdd());
+        {   // (mod 2^40 as two 20-bit halves: two 32-bit DPP butterflies, comm.h: chk_wave_sum)
+            const uint32_t lo = wave_allreduce_dpp((uint32_t)(got & 0xFFFFFull), OpAdd());
+            const uint32_t hi = wave_allreduce_dpp((uint32_t)((got >> 20) & 0xFFFFFull), OpAdd());
+            got = (unsigned long long)lo + ((unsigned long long)hi << 20);
+        }
         const unsigned long long expected = p.chk[p.n_blocks + 1];
         if (lane == 0 && ((got - expected) & ((1ull << 40) - 1ull)) != 0ull && *p.chk_dead == 0) *p.chk_dead = 2;  // comm.h: kDeadChecksum
     }

@@ -49,6 +49,7 @@ int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, vo
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
+size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype);
 int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const dl_proj_desc* projs, int32_t n_proj, double min_share,
                  std::vector<uint8_t>& pid_sell, std::vector<uint32_t>& desc, hipStream_t st);  // sell_build.hip
 int sell_finish(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const std::vector<uint8_t>& pid_sell, const std::vector<uint32_t>& desc,
@@ -715,9 +716,31 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         }
         if (m_hot > 0) {
             h->m_hot = m_hot;
+            h->m_lam = m_hot;
             h->lam_lds = true;
             h->grad_lds = true;
             h->lds_bytes = fused_lds_bytes(m_hot, val_dtype, true, true);
+            // Which rows get which kind of LDS?  A gather of a cold row is a dependent L2 round trip in every slice that has one
+            // (MovieLens shape, same box: 70.6 us per launch, 59.8 with the cold gathers ablated); a scatter to a cold row is a
+            // fire-and-forget global atomic (ablated: 69.9).  So when the WHOLE dual vector fits beside a still useful number of
+            // gradient rows, stage all of it and keep fewer gradient rows: no tile gathers from L2 at all.
+            // DUALIP_HIP_LAM_ALL=0 keeps the symmetric plan (m_lam = m_hot).
+            const size_t vs_l = val_dtype == DL_F32 ? 4 : 8;
+            const char* la = getenv("DUALIP_HIP_LAM_ALL");
+            if (!(la && la[0] == '0') && forced <= 0 && (size_t)m * vs_l * 100 <= kLdsBudget * 72) {
+                int64_t lo = 0, hi = m_hot;  // most gradient rows that fit beside all m dual entries
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi + 1) / 2;
+                    if (fused_lds_bytes2(mid, m, val_dtype) <= kLdsBudget) lo = mid;
+                    else hi = mid - 1;
+                }
+                const int64_t g_rows = lo / 64 * 64;
+                if (g_rows >= 1024) {
+                    h->m_hot = g_rows;
+                    h->m_lam = m;
+                    h->lds_bytes = fused_lds_bytes2(g_rows, m, val_dtype);
+                }
+            }
         }
     }
     h->mpad = (m + 63) / 64 * 64;
@@ -945,6 +968,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 15: return h->n_sell_nnz;
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
+        case 2003: return h->m_hot > 0 ? h->m_lam : (h->lam_lds ? h->m : 0);  // rows of the dual vector staged in LDS
         case 2001: return h->owns_inputs ? 1 : 0;
         case 2002: return h->owns_inputs ? h->own_count : h->unsliced_end;  // non-zeros read in place from the (caller's / owned) CSC-ordered arrays
         case 2000: return h->n_sell_lane_cols;

@@ -51,6 +51,14 @@ __host__ __device__ inline unsigned long long flag_word(unsigned long long seq, 
 __host__ __device__ inline bool flag_arrived(unsigned long long flag, unsigned long long seq) { return ((flag - seq) & kSeqMask) < (1ull << (kSeqBits - 1)); }
 __host__ __device__ inline unsigned long long flag_chk(unsigned long long flag) { return (flag >> kSeqBits) & kChkMask; }
 
+// wave-wide sum of the lanes' hash sums, mod 2^40, on the DPP unit: the 40 bits travel as two 20-bit halves in 32-bit registers (64 lanes
+// x 2^20 < 2^32), so the reduction is two 32-bit butterflies instead of twelve ds_bpermute round trips of a 64-bit one
+__device__ __forceinline__ unsigned long long chk_wave_sum(unsigned long long h) {
+    const uint32_t lo = wave_allreduce_dpp((uint32_t)(h & 0xFFFFFull), OpAdd());
+    const uint32_t hi = wave_allreduce_dpp((uint32_t)((h >> 20) & 0xFFFFFull), OpAdd());
+    return ((unsigned long long)lo + ((unsigned long long)hi << 20)) & kChkMask;
+}
+
 // Where one rank's sums go: slot (parity, my rank) of every rank's mailbox.
 struct PushArgs {
     double* dst[kMaxWorld];               // slot base in rank r's mailbox
@@ -115,7 +123,7 @@ __device__ __forceinline__ void push_finish(const PushArgs& p, unsigned long lon
     __shared__ unsigned long long push_h;
     if (threadIdx.x == 0) push_h = 0ull;
     __syncthreads();
-    h = (unsigned long long)wave_allreduce((long long)h, OpAdd());
+    h = chk_wave_sum(h);
     if ((threadIdx.x & 63) == 0 && h) atomicAdd(&push_h, h);  // (LDS; integer sums: any order)
     if (p.fenced) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope: HIP's default for __atomic_thread_fence)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have landed

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void p2p_gather_kernel(double* __restrict__ ds
     __shared__ unsigned long long gather_h;
     if (threadIdx.x == 0) gather_h = 0ull;
     __syncthreads();
-    h = (unsigned long long)wave_allreduce((long long)h, OpAdd());
+    h = chk_wave_sum(h);
     if ((threadIdx.x & 63) == 0 && h) atomicAdd(&gather_h, h);
     __syncthreads();
     if (threadIdx.x == 0 && a.ticket) {

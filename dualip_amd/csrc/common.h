@@ -118,6 +118,8 @@ struct dl_matching {
     // "hot rows" plan (dual vector / gradient too large for the LDS): rows renumbered by frequency, the m_hot most frequent
     // ones live in LDS, the cold tail goes through L2 (gathers) and 64-bit global atomics (cold_grad)
     int64_t m_hot = 0;                // 0 = plan not in use
+    int64_t m_lam = 0;                // hot-rows plan: rows whose DUAL entry is staged in LDS (>= m_hot; = m when the whole dual vector fits beside a
+                                      // smaller gradient -- then no tile ever gathers from L2, and only the scatter of the rows >= m_hot leaves the CU)
     double hot_fraction = 1.0;        // share of the non-zeros whose row is hot
     int32_t* row_inv = nullptr;       // owned, [m]: renumbered row -> caller's row
     int32_t* row_perm = nullptr;      // owned, [m]: caller's row -> renumbered row

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
             double ol = 0.0, ql = 0.0;  // (this column's sums of this thread: one rounded integer each)
             process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
-                                                      FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words);
+                                                      FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words, HOT ? gk.m_lam : (int64_t)0);
             fx_add_wide(acc, ol, ql, w.scale2);
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         }
         double ol = 0.0, ql = 0.0;
         process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
-                                            FAIR ? &fair : nullptr, desc);
+                                            FAIR ? &fair : nullptr, desc, HOT ? gk.m_lam : (int64_t)0);
         fx_add_wide(acc, ol, ql, w.scale2);
     };
     // The second binary deals single-column tiles and K-lane slices to WORKGROUPS statically (workgroup w owns slots w, w + G, ...
@@ -300,18 +300,26 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         uint32_t row[kSlots];
         T lam[kSlots];
         if constexpr (HOT) {  // (cold rows: four unconditional requests -- a hot lane reads lambda[0] -- then a select; see sell.h)
-            const uint32_t mh = (uint32_t)g.m_hot;
-            T lg[kSlots];
+            const uint32_t ml = (uint32_t)g.m_lam;  // rows whose dual entry is in LDS (all of them when the whole vector fits)
+            if (ml >= (uint32_t)g.m) {
 #pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                row[j] = (uint32_t)cur.r.v[j];
-                lg[j] = g.lambda[row[j] >= mh ? row[j] : 0u];
-            }
+                for (int j = 0; j < kSlots; ++j) {
+                    row[j] = (uint32_t)cur.r.v[j];
+                    lam[j] = w.lam_s[row[j]];
+                }
+            } else {
+                T lg[kSlots];
 #pragma unroll
-            for (int j = 0; j < kSlots; ++j) {
-                const bool cold = row[j] >= mh;
-                const T hot_val = w.lam_s[cold ? 0u : row[j]];
-                lam[j] = cold ? (T)(s * lg[j]) : hot_val;
+                for (int j = 0; j < kSlots; ++j) {
+                    row[j] = (uint32_t)cur.r.v[j];
+                    lg[j] = g.lambda[row[j] >= ml ? row[j] : 0u];
+                }
+#pragma unroll
+                for (int j = 0; j < kSlots; ++j) {
+                    const bool cold = row[j] >= ml;
+                    const T hot_val = w.lam_s[cold ? 0u : row[j]];
+                    lam[j] = cold ? (T)(s * lg[j]) : hot_val;
+                }
             }
         } else {
 #pragma unroll

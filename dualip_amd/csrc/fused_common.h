@@ -41,7 +41,8 @@ struct FusedArgs {
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
-    int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) live in LDS; 0 = every row does
+    int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) have their GRADIENT accumulator in LDS; 0 = every row does
+    int64_t m_lam;                 // hot-rows plan: rows < m_lam have their DUAL entry in LDS (m_hot <= m_lam <= m; m: no tile gathers from L2)
     long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed)
     const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
     // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 carry +f_k / -f_k on EVERY non-zero k
@@ -205,7 +206,8 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 template <class T, class RowT, bool LAM_LDS, bool WG = false>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
-                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr) {
+                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr, int64_t m_lam = 0) {
+    if (m_lam < m_hot) m_lam = m_hot;  // (rows whose dual entry is in LDS; the hot-rows plan may stage more of them than gradient rows)
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
     auto all_sum = [&](double x) -> double {
@@ -245,15 +247,16 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
         // (hot-rows plan: the cold rows' dual entries are requested for the whole batch at once, unconditionally -- a hot lane reads
         //  lambda[0] -- and chosen by a select; a load under a per-element branch waits for its own L2 round trip at every join)
         T lg[kLB];
-        if (LAM_LDS && m_hot > 0) {
+        const bool some_cold = LAM_LDS && m_hot > 0 && m_lam < g.m;  // (wave-uniform)
+        if (some_cold) {
 #pragma unroll
-            for (int u = 0; u < kLB; ++u) lg[u] = g.lambda[(int64_t)rv[u] >= m_hot ? rv[u] : 0u];
+            for (int u = 0; u < kLB; ++u) lg[u] = g.lambda[(int64_t)rv[u] >= m_lam ? rv[u] : 0u];
         }
 #pragma unroll
         for (int u = 0; u < kLB; ++u) {
             T lam;
-            if (LAM_LDS && m_hot > 0) {
-                const bool cold = (int64_t)rv[u] >= m_hot;
+            if (some_cold) {
+                const bool cold = (int64_t)rv[u] >= m_lam;
                 const T hot_val = lam_s[cold ? 0u : rv[u]];
                 lam = cold ? (T)(s * lg[u]) : hot_val;
             } else {
@@ -430,8 +433,9 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     const int64_t m_lds = g.m_hot > 0 ? g.m_hot : g.m;  // rows that live in LDS (all of them unless the hot-rows plan is on)
     w.grad_s = reinterpret_cast<long long*>(smem);
     size_t off = GRAD_LDS ? (size_t)m_lds * 8 : 0;
+    const int64_t m_lam = g.m_hot > 0 ? g.m_lam : g.m;   // rows whose dual entry is staged
     w.lam_s = reinterpret_cast<T*>(smem + off);
-    off += LAM_LDS ? (size_t)m_lds * sizeof(T) : 0;
+    off += LAM_LDS ? (size_t)m_lam * sizeof(T) : 0;
     off = (off + 15) / 16 * 16;
     w.proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
     off += (size_t)kProjLds * sizeof(ProjT<T>);
@@ -457,7 +461,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     // when this launch applies the optimiser step (workgroup 0 stores every row of the new iterate); otherwise only the rows that live
     // in LDS -- under the hot-rows plan the cold tail is read by the tiles that need it, and staging it here cost the MovieLens shape
     // (26 744 rows, 12 928 of them hot) a third dependent L2 round trip per launch.
-    const int64_t m_pull = (g.has_unbounded || applying || g.m_hot <= 0) ? g.m : m_lds;
+    const int64_t m_pull = (g.has_unbounded || applying || g.m_hot <= 0) ? g.m : m_lam;
     {   // latency bound (every workgroup pulls the dual vector from L2): thirteen loads in flight per thread -- the benchmark's 10^4 duals,
         // and the most rows a hot-rows plan keeps in LDS (< 13 312), in ONE round trip
         constexpr int kU = 13;
@@ -499,7 +503,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
                 const int64_t i = i0 + (int64_t)u * kFusedThreads;
                 if (i < g.m) {
                     if constexpr (LAM_LDS) {
-                        if (i < m_lds) w.lam_s[i] = (T)(w.s * l[u]);
+                        if (i < m_lam) w.lam_s[i] = (T)(w.s * l[u]);
                     }
                     const double al = fabs((double)l[u]);
                     lmax = al > lmax ? al : lmax;

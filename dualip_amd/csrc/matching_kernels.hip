@@ -379,6 +379,14 @@ int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* o
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
+size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype) {
+    const size_t vs = val_dtype == DL_F32 ? 4 : 8;
+    size_t off = (size_t)rows_grad * 8 + (size_t)rows_lam * vs;
+    off = (off + 15) / 16 * 16;
+    off += (size_t)kProjLds * (val_dtype == DL_F32 ? sizeof(ProjT<float>) : sizeof(ProjT<double>));
+    off += kLdsScratch;
+    return off;
+}
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad) {
     const size_t vs = val_dtype == DL_F32 ? 4 : 8;
     size_t off = (grad ? (size_t)m * 8 : 0) + (lam ? (size_t)m * vs : 0);
@@ -633,6 +641,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.timeline = h->timeline;
     args.eq_heights = h->eq_heights;
     args.m_hot = h->m_hot;
+    args.m_lam = h->m_hot > 0 ? h->m_lam : 0;
     args.cold_grad = h->cold_grad;
     args.fair = static_cast<const T*>(h->fair);
     args.lambda_orig = static_cast<const T*>(lambda);

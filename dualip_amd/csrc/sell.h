@@ -119,8 +119,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     T a[KEEP], c[KEEP], f[FAIR ? KEEP : 1], u[HM];
     uint32_t r[KEEP];
     // (developer-only timing ablations, K-lane / in-place slices of the second binary only -- results are wrong on purpose:
-    //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather,
-    //  18 = the cold-row gather of round 3: one global load per step, each under its own branch)
+    //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather)
     constexpr bool DEVAB = KLOG > 0;
     const int ab = DEVAB ? kernarg_args(g).ablate : 0;
     // Hot-rows plan: a row >= m_hot has its dual entry in global memory (L2).  Round 3 read it under a per-element branch
@@ -128,19 +127,20 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     // (the compiler's s_waitcnt insertion falls back to vmcnt(0) there), sixteen dependent round trips per slice -- 11 us per slice on
     // the MovieLens shape, four slices per wavefront.  Now ALL steps' global loads are issued together, unconditionally (a hot lane
     // reads lambda[0]: one line, broadcast), straight after the row indices arrive, and the choice is a select: two round trips per slice.
-    const uint32_t m_hot32 = HOT ? (uint32_t)g.m_hot : 0u;
+    // And when the whole dual vector fits the LDS beside a smaller gradient (g.m_lam == g.m, api.hip) no row is cold for the gather.
+    const uint32_t m_lam32 = HOT ? (uint32_t)g.m_lam : 0u;
+    const bool lam_all = HOT && m_lam32 >= (uint32_t)g.m;  // (wave-uniform)
     auto lam_cold_load = [&](uint32_t row) -> T {  // the value a cold row needs, requested unconditionally
         if (DEVAB && (ab & (1 << 17))) return (T)0;
-        return g.lambda[row >= m_hot32 ? row : 0u];
+        return g.lambda[row >= m_lam32 ? row : 0u];
     };
     auto lam_pick = [&](uint32_t row, T cold_val) -> T {
-        const bool cold = row >= m_hot32;
+        const bool cold = row >= m_lam32;
         const T hot_val = w.lam_s[cold ? 0u : row];
         return cold ? (T)(s * cold_val) : hot_val;
     };
-    const bool old_gather = DEVAB && (ab & (1 << 18));
     auto lam_of = [&](uint32_t row) -> T {
-        if constexpr (HOT) return (int64_t)row < g.m_hot ? w.lam_s[row] : (T)(s * g.lambda[row]);
+        if constexpr (HOT) return row < m_lam32 ? w.lam_s[row] : (T)(s * g.lambda[row]);
         else return LAM_LDS ? w.lam_s[row] : (T)(s * g.lambda[row]);
     };
     const T NEG = (T)(-INFINITY);
@@ -160,16 +160,15 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                 if constexpr (FAIR) f[t] = (T)0;
             }
         }
-        if constexpr (HOT) {
-            if (!old_gather) {
+        const bool gather_cold = HOT && !lam_all;  // (wave-uniform: some rows' dual entries are in L2, not in LDS)
+        if (gather_cold) {
 #pragma unroll
-                for (int t = 0; t < HM; ++t) u[t] = lam_cold_load(r[t]);  // (all in flight together; u[t] is free until the next loop writes it)
-            }
+            for (int t = 0; t < HM; ++t) u[t] = lam_cold_load(r[t]);  // (all in flight together; u[t] is free until the next loop writes it)
         }
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             T lam;
-            if constexpr (HOT) lam = old_gather ? lam_of(r[t]) : lam_pick(r[t], u[t]);
+            if constexpr (HOT) lam = gather_cold ? lam_pick(r[t], u[t]) : w.lam_s[r[t]];
             else lam = lam_of(r[t]);
             T v = (T)((T)(a[t] * lam) + (T)(s * c[t]));
             if constexpr (FAIR) v = (T)(v + (T)(sd * f[t]));
@@ -196,16 +195,15 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                     f8[q] = (T)0;
                 }
             }
-            if constexpr (HOT) {
-                if (!old_gather) {
+            const bool gather_cold = HOT && !lam_all;
+            if (gather_cold) {
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) u[t0 + q] = lam_cold_load(r8[q]);
-                }
+                for (int q = 0; q < CH; ++q) u[t0 + q] = lam_cold_load(r8[q]);
             }
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 T lam;
-                if constexpr (HOT) lam = old_gather ? lam_of(r8[q]) : lam_pick(r8[q], u[t0 + q]);
+                if constexpr (HOT) lam = gather_cold ? lam_pick(r8[q], u[t0 + q]) : w.lam_s[r8[q]];
                 else lam = lam_of(r8[q]);
                 T v = (T)((T)(a8[q] * lam) + (T)(s * c8[q]));
                 if constexpr (FAIR) v = (T)(v + (T)(sd * f8[q]));

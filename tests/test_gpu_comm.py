@@ -396,8 +396,9 @@ def _fault_loop_worker(rank, world, port, fuse, q):
         out = dict(log=np.array(res.dual_objective_log), dual=res.dual_val.cpu().numpy(), backend=comm.backend, degraded=comm.info()["degraded"], warned=warned)
         # (b) an explicitly chosen back-end has no level to move to: every rank raises
         f2 = MatchingSolverDualObjectiveFunctionDistributed(args, torch.from_numpy(p["b"]), float(gamma), host_device="cuda:0", comm_backend="p2p")
+        c2 = f2.communicator()  # (creating it is a collective call: every rank, not only the one that arms the fault)
         if rank == 0:
-            f2.communicator().inject_fault(2, 1, f2.communicator().exchanges + 30)
+            c2.inject_fault(2, 1, c2.exchanges + 30)
         try:
             AcceleratedGradientDescent(**kw).maximize(f2, lam0)
             out["explicit"] = "returned"

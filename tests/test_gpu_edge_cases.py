@@ -279,7 +279,7 @@ def _skewed_problem(m, n, mean_deg, seed):
     return dict(m=m, n=n, colptr=colptr, rowidx=rows, a=rng.uniform(0.05, 1.0, nnz), c=-rng.uniform(0.01, 0.5, nnz), b=rng.uniform(0.5, 2.0, m))
 
 
-@pytest.mark.parametrize("forced", [True, False])
+@pytest.mark.parametrize("forced", [True, False, "whole_dual_vector", "whole_dual_vector_off"])
 def test_hot_rows_plan(forced, monkeypatch):
     """Dual vector + gradient larger than the LDS: rows renumbered by frequency, the hot ones in LDS, the cold tail on L2
     gathers / global atomics.  Natural case: 30 000 dual rows; forced case: a small problem with only 128 hot rows.
@@ -289,7 +289,16 @@ def test_hot_rows_plan(forced, monkeypatch):
     from dualip_amd.optimizers.agd import AcceleratedGradientDescent
     from dualip_amd.projections.base import ProjectionEntry
 
-    if forced:
+    # (round 4) "whole_dual_vector": 20 000 rows -- in fp32 the WHOLE dual vector fits the LDS beside ~9 000 gradient rows, so the plan
+    # stages all of it (no tile gathers from L2; only the scatter of the rows beyond the gradient's share leaves the CU); DUALIP_HIP_LAM_ALL=0
+    # keeps the symmetric plan on the same problem
+    whole = isinstance(forced, str)
+    if whole:
+        if forced.endswith("_off"):
+            monkeypatch.setenv("DUALIP_HIP_LAM_ALL", "0")
+        p = _skewed_problem(20_000, 8_000, 12, seed=43)
+        forced_off, forced = forced.endswith("_off"), False
+    elif forced:
         monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "128")
         p = _skewed_problem(700, 5_000, 9, seed=41)
     else:
@@ -314,6 +323,10 @@ def test_hot_rows_plan(forced, monkeypatch):
             continue
         assert info["hot_rows"] == (128 if forced else info["hot_rows"]) and 0 < info["hot_rows"] < m, info
         assert info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1
+        if whole and dn == "f32" and not forced_off:
+            assert info["lambda_rows_in_lds"] == m and 1024 <= info["hot_rows"] < 12_000, info
+        else:
+            assert info["lambda_rows_in_lds"] == info["hot_rows"], info
         if not forced:
             assert info["hot_nnz_ppm"] > 500_000  # the frequent rows carry most of the non-zeros
     # device-resident AGD over the renumbered slabs

@@ -118,6 +118,7 @@ def test_movielens_shape_at_full_size_under_the_checker():
     f = MatchingSolverDualObjectiveFunction(matching_input_args=inp, gamma=gamma)
     info = f.info()
     assert info["layout"] == 4 and info["hot_rows"] > 0 and info["hot_rows"] < m, info        # more rows than the LDS holds
+    assert info["lambda_rows_in_lds"] == m, info  # ... but the whole dual vector fits beside the gradient's hot rows: no tile gathers from L2
     assert info["slice_lane_columns"] > 0 and info["long_columns"] > 0 and info["workgroup_columns"] > 0, info  # second binary: K-lane slices, single-column tiles, whole-workgroup columns
     solver = AcceleratedGradientDescent(max_iter=50, gamma=gamma, initial_step_size=1e-5, max_step_size=1e-3, iteration_callback=False)
     run = solver.start_device_run(f, torch.zeros(m, dtype=torch.float32, device=DEV))
