@@ -322,9 +322,11 @@ def stored_traffic(args, world, lay, phys_bytes):
     return float(rec), "profiles/traffic.json: rocprofv3 --pmc passes of this command in an earlier round (record without layout / commit: only checked to be within 10 % of the layout's bytes)"
 
 
-def measure_traffic_now():
+def measure_traffic_now(child=None, extra_counters=()):
     """HBM bytes per fused launch measured NOW: this command line re-run (3 steps, no side legs) under `rocprofv3 --pmc FETCH_SIZE` and
-    `--pmc WRITE_SIZE` (separate passes, as the guide prescribes), averaged over the fused kernel's dispatches.  Returns (bytes, details)."""
+    `--pmc WRITE_SIZE` (separate passes, as the guide prescribes), averaged over the fused kernel's dispatches.  Returns (bytes, details).
+    `child`: another command to profile instead (benchmark/movielens_like.py passes its own); `extra_counters`: more single-counter passes
+    whose per-launch means are added to the details."""
     import csv
     import glob
     import shutil
@@ -338,22 +340,32 @@ def measure_traffic_now():
         while flag in base:
             i = base.index(flag)
             del base[i:i + 2]
-    child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-late", "--no-verify", "--no-cpu-baseline"]
+    if child is None:
+        child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-late", "--no-verify", "--no-cpu-baseline"]
     vals, details = {}, {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE") + tuple(extra_counters):
         tmp = tempfile.mkdtemp(prefix="dualip_pmc_", dir="/tmp")
         try:
             env = dict(os.environ, TMPDIR="/tmp", DUALIP_BENCH_NO_EVENTS="1")
-            r = subprocess.run([rocprof, "--output-format", "csv", "--pmc", counter, "-d", tmp, "-o", "p", "--"] + child, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+            try:
+                r = subprocess.run([rocprof, "--output-format", "csv", "--pmc", counter, "-d", tmp, "-o", "p", "--"] + child, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            except subprocess.TimeoutExpired:
+                if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                    return None, {"error": f"the {counter} pass did not finish in 600 s"}
+                details[counter + "_error"] = "pass timed out"
+                continue
             rows = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if "matching_fused" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                         rows.append(float(row["Counter_Value"]))
             if not rows:
-                return None, {"error": f"no {counter} rows for the fused kernel (rocprofv3 exit {r.returncode}): {r.stderr[-300:]}"}
+                if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                    return None, {"error": f"no {counter} rows for the fused kernel (rocprofv3 exit {r.returncode}): {r.stderr[-300:]}"}
+                details[counter + "_error"] = f"no rows (rocprofv3 exit {r.returncode})"
+                continue
             vals[counter] = sum(rows) / len(rows)
-            details[counter + "_KiB_per_launch"] = vals[counter]
+            details[counter + ("_KiB_per_launch" if counter.endswith("_SIZE") else "_per_launch")] = vals[counter]
             details[counter + "_dispatches"] = len(rows)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)

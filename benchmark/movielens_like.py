@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--capacity", type=float, default=30.0)
     ap.add_argument("--gamma", type=float, default=0.1)
     ap.add_argument("--stress", action="store_true", help="start from stress_duals() instead of zero: the kernel's cost with prices that cut between tied ratings")
+    ap.add_argument("--measure-traffic", metavar="OUT.json", default=None, help="also run this script (20 iterations) under rocprofv3 --pmc, one counter per pass -- FETCH_SIZE, "
+                    "WRITE_SIZE, SQ_INSTS_VALU, SQ_INSTS_LDS, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY -- and write the fused kernel's per-launch means to OUT.json")
     ap.add_argument("--no-verify", action="store_true", help="skip the checks against the CPU oracle after the solve (they are outside every timed region)")
     args = ap.parse_args()
     from dualip_amd.objectives.matching import MatchingInputArgs
@@ -116,6 +118,20 @@ def main():
         print(f"per-workgroup tile-loop duration of the last launch (us): min {d.min():.0f} mean {d.mean():.0f} max {d.max():.0f}; kernel span {us[:, 3].max():.0f}")
     if not args.no_verify:
         verify(f, inp, args.gamma, res.dual_val, dev)
+    if args.measure_traffic:
+        import json
+
+        import bench
+
+        child = [sys.executable, os.path.abspath(__file__), "--max-iter", "20", "--no-verify"] + (["--stress"] if args.stress else [])
+        hbm, details = bench.measure_traffic_now(child, ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY"))
+        info = f.info()
+        streamed = (nnz + info["slice_elements"] - info["slice_nnz"]) * (8 + info["row_index_bytes"])
+        rec = {"command": " ".join(child), "commit": bench.current_commit(), "hbm_bytes_per_launch": hbm, "counters": details, "layout": info,
+               "values_and_rows_by_construction": streamed, "note": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 corrections, "
+               "profiles/r02_fetch_size_calibration.json); the working set (~125 MB) fits the 256 MB Infinity Cache, so HBM itself is not the bound"}
+        json.dump(rec, open(args.measure_traffic, "w"), indent=1)
+        print("measured:", json.dumps(rec)[:600])
     print(f"maximize: {args.max_iter} iterations in {dt:.3f}s ({args.max_iter / dt:.1f} iterations/s, {dt / args.max_iter * 1e3:.3f} ms each); dual objective "
           f"{res.dual_objective:.3f} (first {res.dual_objective_log[0]:.3f})")
 

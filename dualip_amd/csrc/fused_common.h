@@ -465,7 +465,29 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     {   // latency bound (every workgroup pulls the dual vector from L2): thirteen loads in flight per thread -- the benchmark's 10^4 duals,
         // and the most rows a hot-rows plan keeps in LDS (< 13 312), in ONE round trip
         constexpr int kU = 13;
-        for (int64_t i0 = tid; i0 < m_pull; i0 += (int64_t)kU * kFusedThreads) {
+        int64_t pulled = 0;
+        if (!applying && m_pull > (int64_t)kU * kFusedThreads) {  // (wave-uniform) a long dual vector -- the MovieLens shape stages all its 26 744
+            constexpr int kW = 28;                                   // rows -- still in ONE round trip: 28 loads in flight per thread (three before)
+            T lw[kW];
+#pragma unroll
+            for (int u = 0; u < kW; ++u) {
+                const int64_t i = (int64_t)tid + (int64_t)u * kFusedThreads;
+                lw[u] = g.lambda[i < g.m ? i : g.m - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < kW; ++u) {
+                const int64_t i = (int64_t)tid + (int64_t)u * kFusedThreads;
+                if (i < m_pull) {
+                    if constexpr (LAM_LDS) {
+                        if (i < m_lam) w.lam_s[i] = (T)(w.s * lw[u]);
+                    }
+                    const double al = fabs((double)lw[u]);
+                    lmax = al > lmax ? al : lmax;
+                }
+            }
+            pulled = (int64_t)kW * kFusedThreads;
+        }
+        for (int64_t i0 = pulled + tid; i0 < m_pull; i0 += (int64_t)kU * kFusedThreads) {
             T l[kU];
             if (!applying) {
 #pragma unroll

@@ -565,7 +565,10 @@ def test_release_inputs_makes_the_handle_self_contained(order):
     n, half = p["n"], p["n"] // 2
     box, simplex = ("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})
     first, second = {"box_then_simplex": (box, simplex), "simplex_then_box": (simplex, box), "all_simplex": (simplex, simplex)}[order]
-    pm = {**create_projection_map(first[0], dict(first[1]), None, indices=range(0, half)), **create_projection_map(second[0], dict(second[1]), None, indices=range(half, n))}
+    if order == "all_simplex":  # (one entry: two maps of the same operator would share their key)
+        pm = create_projection_map("simplex", {"z": 1.0}, None, indices=range(0, n))
+    else:
+        pm = {**create_projection_map(first[0], dict(first[1]), None, indices=range(0, half)), **create_projection_map(second[0], dict(second[1]), None, indices=range(half, n))}
     lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.05, p["m"])).float().to(DEV)
     kw = dict(max_iter=40, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
 
