@@ -604,21 +604,36 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         // single-column tiles of more than xlong_min non-zeros are walked by a whole workgroup (listed last): one wavefront
         // walking thousands of non-zeros alone would set the critical path of the launch
         std::vector<uint32_t> short_words, long_words, short_pid, long_pid, xlong_words, xlong_pid;
+        // (the second binary walks simplex columns of up to 2048 non-zeros by ONE wavefront as an in-place slice -- 32 steps, values
+        //  re-read for the scatter -- with every reduction on the DPP unit; the whole-workgroup walker pays two barriers per reduction,
+        //  ~14 us per ~2000 non-zeros on the MovieLens shape, and stalls the other fifteen wavefronts meanwhile.  Which binary a handle
+        //  takes depends on the split itself (>= 1 % of the non-zeros in one-wavefront tiles), so: split at 1024, decide, split again.)
+        const char* xl_env = getenv("DUALIP_HIP_XLONG_MIN");
+        bool will_use_lanes = false;
+        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !will_use_lanes; t += 4) will_use_lanes = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
+        if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) will_use_lanes = will_use_lanes || e[0] == '1';
         uint64_t xlong_min = 1024;
-        if (const char* e = getenv("DUALIP_HIP_XLONG_MIN")) xlong_min = strtoull(e, nullptr, 10);
-        for (size_t t = 0; t < tile_pid4.size(); ++t) {
-            const bool is_long = (words4[t * 12 + 1] & (1u << 19)) != 0;
-            const uint64_t len = ((uint64_t)words4[t * 12 + 3] << 32) | words4[t * 12 + 2];
-            if (is_long && len <= xlong_min) h->long_nnz += (int64_t)len;  // non-zeros walked one wavefront per column
-            std::vector<uint32_t>& wv = !is_long ? short_words : (len > xlong_min ? xlong_words : long_words);
-            std::vector<uint32_t>& pv = !is_long ? short_pid : (len > xlong_min ? xlong_pid : long_pid);
-            wv.insert(wv.end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
-            if (is_long) {  // words 4 / 5: where the column's PRIMAL goes (the caller's order) -- the same place the column is read from, until
-                            // dl_matching_own_inputs moves a straggler of a sliced entry into the handle's pool and rewrites words 0 / 1
-                wv[wv.size() - 12 + 4] = words4[t * 12];
-                wv[wv.size() - 12 + 5] = words4[t * 12 + 1] & 0xFFu;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (xl_env) xlong_min = strtoull(xl_env, nullptr, 10);
+            short_words.clear(); long_words.clear(); short_pid.clear(); long_pid.clear(); xlong_words.clear(); xlong_pid.clear();
+            h->long_nnz = 0;
+            for (size_t t = 0; t < tile_pid4.size(); ++t) {
+                const bool is_long = (words4[t * 12 + 1] & (1u << 19)) != 0;
+                const uint64_t len = ((uint64_t)words4[t * 12 + 3] << 32) | words4[t * 12 + 2];
+                if (is_long && len <= xlong_min) h->long_nnz += (int64_t)len;  // non-zeros walked one wavefront per column
+                std::vector<uint32_t>& wv = !is_long ? short_words : (len > xlong_min ? xlong_words : long_words);
+                std::vector<uint32_t>& pv = !is_long ? short_pid : (len > xlong_min ? xlong_pid : long_pid);
+                wv.insert(wv.end(), words4.begin() + (ptrdiff_t)(t * 12), words4.begin() + (ptrdiff_t)(t * 12 + 12));
+                if (is_long) {  // words 4 / 5: where the column's PRIMAL goes (the caller's order) -- the same place the column is read from, until
+                                // dl_matching_own_inputs moves a straggler of a sliced entry into the handle's pool and rewrites words 0 / 1
+                    wv[wv.size() - 12 + 4] = words4[t * 12];
+                    wv[wv.size() - 12 + 5] = words4[t * 12 + 1] & 0xFFu;
+                }
+                pv.push_back(tile_pid4[t]);
             }
-            pv.push_back(tile_pid4[t]);
+            const bool lanes_now = will_use_lanes || (h->long_nnz > 0 && h->long_nnz * 100 >= nnz);
+            if (pass == 1 || xl_env || !lanes_now || xlong_min == 2048) break;
+            xlong_min = 2048;  // the second binary: its one-wavefront in-place slices reach 2048 non-zeros (fused4_kernel.h: walk_long)
         }
         // longest first, dealt in snake order (wavefront W takes slots W, W + S, ...: reversing every other round pairs the
         // longest columns with the shortest ones); the workgroup-walked ones likewise over the workgroups
@@ -649,11 +664,12 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             snake(xlong_words, xlong_pid, (size_t)h->n_wg);
         }
         h->n_xlong = (int64_t)xlong_pid.size();
-        // what the workgroup-walked columns cost their workgroups, in slice slots (calibrated on the MovieLens-shaped problem: 13 us per
-        // ~1800 non-zeros against 0.72 us of workgroup time per 900-slot slice): the K-lane slices are dealt around it (sell_build.hip)
+        // what the workgroup-walked columns cost their workgroups, in slice slots (calibrated on the MovieLens-shaped problem: ~7 ns per
+        // non-zero -- 14 us per ~2000 -- against, since round 4, 0.38 us of workgroup time per 900-slot slice): the K-lane slices are
+        // dealt around it (sell_build.hip)
         h->wg_preload.assign((size_t)(h->n_wg > 0 ? h->n_wg : 1), 0);
         for (size_t t = 0; t < xlong_pid.size() && h->n_wg > 0; ++t)
-            h->wg_preload[t % (size_t)h->n_wg] += 9ull * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]);
+            h->wg_preload[t % (size_t)h->n_wg] += 16ull * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]);
         long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
         long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
         if (!dev_pack && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);

@@ -210,17 +210,25 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         if constexpr (LANES) {
             // a simplex column of up to 1024 non-zeros as ONE slice of one column, read in place (sell.h, KLOG = 6): every load in
             // flight at once, the values kept in registers, straight-line passes, reductions on the DPP unit
-            if (is_simplex_kind(pl.kind) && len <= 1024 && !(gk.ablate & 1024)) {
+            // (up to 1024 non-zeros the values stay in registers across the passes; 1025 .. 2048: the RELOAD variants -- only the clamped
+            //  values stay, a / c / rows are re-read for the scatter -- still one wavefront, every reduction on the DPP unit, no barrier)
+            if (is_simplex_kind(pl.kind) && len <= 2048 && !(gk.ablate & 1024)) {
                 const int L = (int)len, H = (L + 63) >> 6, Hmin = L >> 6;
                 const uint64_t kx = (((uint64_t)rl(dvl, 5) << 32) | rl(dvl, 4)) & ((1ull << 40) - 1);  // the column's place in the caller's order (primal)
                 const int len_lane = (L - lane + 63) >> 6;
                 constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
+#define DL_ORIG_CASE(HM_) sell_slice<T, RowT, HM_, (HM_ * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break
                 switch ((H + 3) >> 2) {
-                    case 1: sell_slice<T, RowT, 4, (4 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
-                    case 2: sell_slice<T, RowT, 8, (8 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
-                    case 3: sell_slice<T, RowT, 12, (12 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
-                    default: sell_slice<T, RowT, 16, (16 * kPer > 64), LAM_LDS, HOT, FAIR, 6>(gk, w, pl, k0, H, Hmin, L, len_lane, kx, true, lane, sd, eq_row, acc, fair); break;
+                    case 1: DL_ORIG_CASE(4);
+                    case 2: DL_ORIG_CASE(8);
+                    case 3: DL_ORIG_CASE(12);
+                    case 4: DL_ORIG_CASE(16);
+                    case 5: DL_ORIG_CASE(20);
+                    case 6: DL_ORIG_CASE(24);
+                    case 7: DL_ORIG_CASE(28);
+                    default: DL_ORIG_CASE(32);
                 }
+#undef DL_ORIG_CASE
                 return;
             }
         }

@@ -390,6 +390,8 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     uint32_t dv = load_desc(q0);
+    // (the L2 prefetch of the next slice, sell_touch_next, is not wired in here: the three words it carries across a slice pushed the
+    //  benchmark's instantiation -- 126 VGPRs, no scratch -- to 128 VGPRs + 16 bytes of scratch, which the build refuses, dualip_amd/_build.py)
     for (uint32_t q = q0; q < n_sell; q += S) {
         const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
         dv = load_desc(q + S);
