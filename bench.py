@@ -674,20 +674,23 @@ def main():
     compared = None
     if sharded and (world > 1 or emu) and not args.no_partition_compare:
         other = "reference" if args.partition != "reference" else "balanced"
-        bi2, nnz2, b2, ranges2 = make_shard(other)
-        for bi in bi2:
-            bi.b_vec = None
-        f2 = MatchingSolverDualObjectiveFunctionDistributed(bi2 if nb > 1 else bi2[0], b2, args.gamma, host_device=device, comm_backend=args.comm)
-        comm2 = f2.communicator()
-        if emu and comm2 is not None:
-            comm2.set_emulation(float(emu))
-        el2, ln2, kms2, xn2, xms2, _res2 = headline(f2, f2.local_objective, comm2)
-        compared = {"kind": other, "ms_per_step": el2 / args.steps * 1e3, "iterations_per_s": args.steps / el2, "kernel_avg_ms": kms2 / max(ln2, 1),
-                    "this_rank_columns": [list(r) for r in ranges2], "this_rank_nnz": int(nnz2), "us_per_exchange": (xms2 / xn2 * 1e3) if xn2 else None,
-                    "backend": comm2.backend if comm2 is not None else "torch.distributed", "window": [args.warmup + 1, args.warmup + args.steps]}
-        if comm2 is not None:
-            comm2.close()
-        del f2, bi2, b2
+        try:  # (every rank takes the same path through here; a failure must show in the line, not cost the headline number)
+            bi2, nnz2, b2, ranges2 = make_shard(other)
+            for bi in bi2:
+                bi.b_vec = None
+            f2 = MatchingSolverDualObjectiveFunctionDistributed(bi2 if nb > 1 else bi2[0], b2, args.gamma, host_device=device, comm_backend=args.comm)
+            comm2 = f2.communicator()
+            if emu and comm2 is not None:
+                comm2.set_emulation(float(emu))
+            el2, ln2, kms2, xn2, xms2, _res2 = headline(f2, f2.local_objective, comm2)
+            compared = {"kind": other, "ms_per_step": el2 / args.steps * 1e3, "iterations_per_s": args.steps / el2, "kernel_avg_ms": kms2 / max(ln2, 1),
+                        "this_rank_columns": [list(r) for r in ranges2], "this_rank_nnz": int(nnz2), "us_per_exchange": (xms2 / xn2 * 1e3) if xn2 else None,
+                        "backend": comm2.backend if comm2 is not None else "torch.distributed", "window": [args.warmup + 1, args.warmup + args.steps]}
+            if comm2 is not None:
+                comm2.close()
+            del f2, bi2, b2
+        except Exception as exc:
+            compared = {"kind": other, "error": f"{type(exc).__name__}: {exc}"}
 
     # ---- footprint: the handle self-contained, the caller's CSC tensors gone -------------------------------------------------
     footprint = None
@@ -772,7 +775,7 @@ def main():
                     "whole_iteration_GBps": alg_bytes * args.steps / elapsed / 1e9,
                 },
                 "partition": {"kind": args.partition if sharded else None, "ranks": vworld,
-                              "ms_per_step": {args.partition: elapsed / args.steps * 1e3, **({compared["kind"]: compared["ms_per_step"]} if compared else {})} if sharded else None,
+                              "ms_per_step": {args.partition: elapsed / args.steps * 1e3, **({compared["kind"]: compared.get("ms_per_step")} if compared else {})} if sharded else None,
                               "compared": compared,
                               "cost_model": "columns x dist_utils.PROJECTION_COST (simplex 1.14, point-wise 1.0)",
                               "estimated_imbalance_max_over_mean": {k: v["imbalance"] for k, v in ptable.items()},

@@ -59,6 +59,7 @@ def row_of(n_gpus, entities, d, emulate):
         "late_ms_per_step": late.get("ms_per_step"), "late_frac_per_rank": late.get("frac"),
         "whole_solve_its_per_s": whole.get("iterations_per_s"), "final_dual_objective": whole.get("final_dual_objective", a.get("final_dual_objective")),
         "collective": coll.get("backend"), "exchange_us": coll.get("us_per_exchange"), "verified": None if ver is None else bool(ver.get("ok_all_ranks", ver.get("ok"))),
+        "partition": (a.get("partition") or {}).get("kind"), "ms_per_step_by_partition": (a.get("partition") or {}).get("ms_per_step"),
     }
 
 
@@ -69,6 +70,9 @@ def main():
     ap.add_argument("--proj", default="mixed")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--reference-sweep", action="store_true", help="the reference's own grid (benchmark/run_scaling_benchmark.py:33-55): 25M .. 250M sources in steps of 25M x "
+                    "{1, 2, 3, 4} GPUs, on the reference's contiguous n // W (+1) split (bench.py --partition reference; the line carries the balanced split's "
+                    "per-rank time beside it).  250M entities on ONE GPU need ~60 GB for the generator's tensors: fits the 288 GB of an MI355X")
     ap.add_argument("--emulate", action="store_true", help="one GPU: emulate the per-rank cost of every N > 1 (rows labelled emulated; NOT results)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scaling"))
     ap.add_argument("--port", type=int, default=29561)
@@ -76,6 +80,10 @@ def main():
     args = ap.parse_args()
     import torch
 
+    if args.reference_sweep:
+        args.sizes = list(range(25_000_000, 250_000_001, 25_000_000))
+        args.gpus = [1, 2, 3, 4]
+        args.bench_args = list(args.bench_args) + ["--partition", "reference"]
     have = torch.cuda.device_count()
     rows, lines = [], []
     for entities in args.sizes:
@@ -96,14 +104,15 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump({"rows": rows, "lines": lines}, open(args.out + ".json", "w"), indent=1)
     f = lambda v, fmt: "-" if v is None else format(v, fmt)  # noqa: E731
-    md = ["| entities | GPUs | it/s (window) | ms/it | speed-up | kernel frac of 8 TB/s per rank (early / late) | whole solve it/s (speed-up) | exchange | verified |", "|---|---|---|---|---|---|---|---|---|"]
+    md = ["| entities | GPUs | it/s (window) | ms/it | speed-up | kernel frac of 8 TB/s per rank (early / late) | whole solve it/s (speed-up) | exchange | verified | ms/it by split |", "|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         if "error" in r:
-            md.append(f"| {r['entities']:,} | {r['gpus']} | {r['error']} | | | | | | |")
+            md.append(f"| {r['entities']:,} | {r['gpus']} | {r['error']} | | | | | | | |")
             continue
         tag = f"{r['gpus']} (emulated: per-rank cost only)" if r["emulated"] else str(r["gpus"])
         md.append(f"| {r['entities']:,} | {tag} | {r['its_per_s']:.0f} | {r['ms_per_step']:.4f} | {f(r.get('speedup'), '.2f')} | {r['frac_per_rank']:.3f} / {f(r.get('late_frac_per_rank'), '.3f')} | "
-                  f"{f(r.get('whole_solve_its_per_s'), '.0f')} ({f(r.get('whole_solve_speedup'), '.2f')}) | {r.get('collective') or '-'} {f(r.get('exchange_us'), '.1f')} us | {r.get('verified')} |")
+                  f"{f(r.get('whole_solve_its_per_s'), '.0f')} ({f(r.get('whole_solve_speedup'), '.2f')}) | {r.get('collective') or '-'} {f(r.get('exchange_us'), '.1f')} us | {r.get('verified')} | "
+                  f"{', '.join(f'{k} {v:.4f}' for k, v in (r.get('ms_per_step_by_partition') or {}).items() if v is not None) or '-'} |")
     open(args.out + ".md", "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 

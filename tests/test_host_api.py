@@ -496,3 +496,33 @@ def test_local_shard_says_when_balanced_cannot_be_honoured_and_builds_empty_shar
     assert any("partition='balanced'" in str(x.message) for x in w)
     assert int(sh.A.size(1)) == 2  # n // W (+1 for the first n % W ranks): 2, 2, 1, 1
     assert np.array_equal(sh.A.values().numpy(), vals.numpy()[4:8])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_bench_partitions_cover_every_entity_once_for_any_world(world):
+    """bench.py's three splits (the reference's n // W (+1) cut, the cost-weighted contiguous cut, the balanced per-block shares) for
+    the world sizes of the reference's sweep (benchmark/run_scaling_benchmark.py:33-55: 1..4, three included) and the node's eight:
+    every entity lands on exactly one rank and keeps its operator."""
+    import bench
+    from benchmark.synthetic import CHUNK_COLS
+
+    n = 25 * CHUNK_COLS + 12345
+    blocks = bench.projection_blocks("mixed", n, CHUNK_COLS)
+    for partition in ("reference", "contiguous", "balanced"):
+        seen = np.zeros(n, dtype=np.int32)
+        for rank in range(world):
+            ranges, pm = bench.shard_plan("mixed", n, world, rank, CHUNK_COLS, partition)
+            local = 0
+            for lo, hi in ranges:
+                seen[lo:hi] += 1
+                local += hi - lo
+            assert sum(len(e.indices) for e in pm.values()) == local
+            # the operator of a local column is the operator of the global column it came from
+            pos = 0
+            for lo, hi in ranges:
+                kinds = {ptype for ptype, _, blo, bhi in blocks if blo < hi and bhi > lo}
+                for e in pm.values():
+                    if e.indices.start <= pos < e.indices.stop:
+                        assert e.proj_type in kinds
+                pos += hi - lo
+        assert (seen == 1).all(), (partition, world, int((seen != 1).sum()))
