@@ -208,6 +208,21 @@ def _sgpr_pair_defects(asm_path: str):
             if sr:
                 lastdef[sr[0]], lastop[sr[0]] = idx, op
                 group.pop(sr[0], None)
+        elif op.startswith("v_") and ops:
+            # vector instructions that WRITE scalar registers: compares in their e64 form (first operand: the lane mask) and the ones
+            # with a carry / scale output (second operand) -- a 64-bit mask formed there is a pair defined together
+            sr = None
+            if op.startswith(("v_cmp", "v_cmpx")):
+                sr = _sreg(ops[0])
+            elif op.startswith(("v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_subbrev_co", "v_div_scale", "v_mad_u64_u32", "v_mad_i64_i32")) and len(ops) > 1:
+                sr = _sreg(ops[1])
+            if sr:
+                for r in range(sr[0], sr[1] + 1):
+                    lastdef[r], lastop[r] = idx, op
+                    if sr[1] > sr[0]:
+                        group[r] = (idx, sr[0], sr[1])
+                    else:
+                        group.pop(r, None)
     return out
 
 

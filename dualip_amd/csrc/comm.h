@@ -120,14 +120,15 @@ __device__ __forceinline__ void push_value(const PushArgs& p, int64_t i, double 
 
 // Called by EVERY thread of EVERY block of the pushing launch after its push_value calls, with the thread's hash sum.
 __device__ __forceinline__ void push_finish(const PushArgs& p, unsigned long long h) {
-    __shared__ unsigned long long push_h;
-    if (threadIdx.x == 0) push_h = 0ull;
-    __syncthreads();
+    __shared__ unsigned long long push_hw[16];  // one hash sum per wavefront of the block (blocks of up to 1024 threads): no zeroing, no LDS atomic
     h = chk_wave_sum(h);
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd(&push_h, h);  // (LDS; integer sums: any order)
+    if ((threadIdx.x & 63) == 0) push_hw[threadIdx.x >> 6] = h;
     if (p.fenced) __atomic_thread_fence(__ATOMIC_RELEASE);  // (system scope: HIP's default for __atomic_thread_fence)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have landed
     __syncthreads();
+    unsigned long long push_h = 0ull;
+    if (threadIdx.x == 0)
+        for (unsigned int q = 0; q < (blockDim.x + 63u) / 64u; ++q) push_h += push_hw[q];
     if (threadIdx.x == 0) {
         const unsigned long long add = ((push_h & kChkMask) << kSeqBits) | 1ull;  // (a carry out of the top drops: arithmetic mod 2^40 up there)
         unsigned long long old;
@@ -149,13 +150,12 @@ __device__ __forceinline__ void push_finish(const PushArgs& p, unsigned long lon
 // Whole block: returns once every rank's slot of this exchange has arrived (or the wait timed out: *dead = kDeadTimeout).
 // Returns (to every thread) the sum of the slots' announced checksums: what the hashes of everything read from them must add up to.
 __device__ __forceinline__ unsigned long long mail_wait(const MailArgs& a) {
-    __shared__ unsigned long long mail_expected;
-    if (threadIdx.x == 0) mail_expected = 0ull;
-    __syncthreads();
+    __shared__ unsigned long long mail_chk[kMaxWorld];  // the checksum each polled flag announced (no zeroing: every polling thread writes its own)
     if ((int)threadIdx.x < a.world) {
+        unsigned long long word = 0ull;
         if (__hip_atomic_load(a.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             const unsigned long long* f = a.flags + (size_t)threadIdx.x * kFlagStride;
-            unsigned long long word = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            word = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (!flag_arrived(word, a.seq)) {
                 const unsigned long long t0 = wall_clock64();
                 while (!flag_arrived(word = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), a.seq)) {
@@ -166,13 +166,15 @@ __device__ __forceinline__ unsigned long long mail_wait(const MailArgs& a) {
                     }
                 }
             }
-            // (the word read is exchange seq's own: a writer one exchange ahead raises the OTHER parity's flag, and none can be two ahead)
-            atomicAdd(&mail_expected, flag_chk(word));
         }
+        // (the word read is exchange seq's own: a writer one exchange ahead raises the OTHER parity's flag, and none can be two ahead)
+        mail_chk[threadIdx.x] = flag_chk(word);
     }
     __syncthreads();
     if (a.fenced) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return mail_expected & kChkMask;
+    unsigned long long expected = 0ull;
+    for (int r = 0; r < a.world; ++r) expected += mail_chk[r];
+    return expected & kChkMask;
 }
 
 // Sum of element i over the ranks' slots, in rank order (identical on every rank); `h` accumulates the hashes of the loaded

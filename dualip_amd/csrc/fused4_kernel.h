@@ -382,8 +382,8 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const T ax = (T)(cur.a.v[j] * xq);
             if (ax != (T)0) {
                 if constexpr (HOT) {
-                    if ((int64_t)row[j] < g.m_hot) scatter_fixed(w.gacc, row[j], ax, w.scale);
-                    else scatter_fixed(g.cold_grad, row[j], ax, w.scale);
+                    if ((int64_t)row[j] < g.m_hot) scatter_fixed_lds(w.gacc, row[j], ax, w.scale);
+                    else scatter_fixed_global(g.cold_grad, row[j], ax, w.scale);
                 } else {
                     scatter_fixed(w.gacc, row[j], ax, w.scale);
                 }

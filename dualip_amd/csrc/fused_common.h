@@ -192,6 +192,23 @@ __device__ __forceinline__ void scatter_fixed(long long* acc, uint32_t row, T ax
     atomicAdd(reinterpret_cast<unsigned long long*>(acc) + row, (unsigned long long)to_fixed(ax, scale));  // ds_add_u64 / global_atomic_add_x2
 }
 
+// The same with the address space SPELLED OUT.  Under the hot-rows plan a scatter is `row < m_hot ? LDS accumulator : global accumulator`;
+// written with generic pointers the compiler folds the two arms into a select of the address and ONE flat_atomic_add_x2 -- every
+// scatter of every hot-rows kernel went through the flat path (aperture check, both counters, a fraction of ds_add_u64's rate): found
+// in the device assembly in round 4 after the timing ablation "no scatter" gave 8 of 56 us on the MovieLens shape.
+template <class T>
+__device__ __forceinline__ void scatter_fixed_lds(long long* acc, uint32_t row, T ax, double scale) {
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    lds_u64* p = (lds_u64*)(reinterpret_cast<unsigned long long*>(acc) + row);
+    (void)__hip_atomic_fetch_add(p, (unsigned long long)to_fixed(ax, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64
+}
+template <class T>
+__device__ __forceinline__ void scatter_fixed_global(long long* acc, uint32_t row, T ax, double scale) {
+    typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+    glb_u64* p = (glb_u64*)(reinterpret_cast<unsigned long long*>(acc) + row);
+    (void)__hip_atomic_fetch_add(p, (unsigned long long)to_fixed(ax, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_atomic_add_x2
+}
+
 template <class P>
 __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
     return reinterpret_cast<P>(reinterpret_cast<const char*>(base) + bytes);  // SGPR base + 32-bit VGPR offset addressing
@@ -394,8 +411,12 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             }
             const T ax = (T)(av[u] * x);
             if (ax != (T)0) {
-                if (m_hot == 0 || (int64_t)rv[u] < m_hot) scatter_fixed(gacc, rv[u], ax, scale);
-                else scatter_fixed(g.cold_grad, rv[u], ax, scale);
+                if (m_hot > 0) {  // (hot-rows plan: gacc is the LDS accumulator)
+                    if ((int64_t)rv[u] < m_hot) scatter_fixed_lds(gacc, rv[u], ax, scale);
+                    else scatter_fixed_global(g.cold_grad, rv[u], ax, scale);
+                } else {
+                    scatter_fixed(gacc, rv[u], ax, scale);
+                }
             }
             obj += (double)(T)(cv[u] * x);
             ssq += (double)(T)(x * x);

@@ -85,26 +85,11 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
     return x;
 }
 
-// Software prefetch of the NEXT slice into L2 (round 4).  A wavefront walks its slices one after the other: request 10 KB, wait a
-// memory round trip, compute, scatter -- and with a handful of slices per wavefront (the MovieLens shape: four) nothing hides that wait
-// but the other fifteen wavefronts of the CU, which are in the same phase.  Registers for a second slice in flight do not exist (round 2
-// measured that variant: -6 %), but its LINES can travel: after the current slice's values are formed, three plain (cached) loads touch every
-// 128-byte line of the next slice's a / c / row runs (one lane per line, results unused); by the time the wavefront issues the real,
-// non-temporal loads they hit the L2.  `keep` carries the three loaded words to the point where the next slice's loads have been issued
-// (an empty asm consumes them there: the wait it implies covers only loads older than those).
-template <class T, class RowT>
-__device__ __forceinline__ void sell_touch_next(const FusedArgs<T>& g, uint32_t dv_next, int lane, uint32_t (&keep)[3]) {
-    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)dv_next, 0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)dv_next, 1);
-    const uint64_t base = ((uint64_t)(w1 & 0xFFu) << 32) | w0;
-    const uint32_t H = (w1 >> 8) & 0xFFu;
-    const uint32_t lines_v = (H * 64u * (uint32_t)sizeof(T) + 127u) >> 7, lines_r = (H * 64u * (uint32_t)sizeof(RowT) + 127u) >> 7;
-    const uint32_t lv = (uint32_t)lane < lines_v ? (uint32_t)lane : (lines_v ? lines_v - 1u : 0u);
-    const uint32_t lr = (uint32_t)lane < lines_r ? (uint32_t)lane : (lines_r ? lines_r - 1u : 0u);
-    keep[0] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.sell_a + base) + (size_t)lv * 128u);
-    keep[1] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.sell_c + base) + (size_t)lv * 128u);
-    keep[2] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(reinterpret_cast<const RowT*>(g.sell_r) + base) + (size_t)lr * 128u);
-}
-
+// (Round 4 tried a software prefetch of the wavefront's NEXT slice into the L2 -- three plain loads touching every 128-byte line of its
+//  a / c / row runs, issued once the current slice's values are formed, results carried in three registers to the next slice's loads --
+//  on the K-lane loop: the MovieLens shape went from 56.6 to 66.1 us per launch, same box, three alternations (and FETCH_SIZE doubled:
+//  the touched lines were fetched again by the non-temporal loads).  Wired into the one-lane loop it cost the benchmark's instantiation
+//  its last two registers (16 bytes of scratch: the build refuses that).  Removed; profiles/r04_ab_movielens_touch_negative.txt.)
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds
@@ -115,8 +100,7 @@ __device__ __forceinline__ void sell_touch_next(const FusedArgs<T>& g, uint32_t 
 // process_long_tile's batched loops.
 template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR, int KLOG = 0>
 __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, int len_lane,
-                                           uint64_t dense, bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair,
-                                           uint32_t dv_next = 0u, uint32_t (*touch)[3] = nullptr) {
+                                           uint64_t dense, bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
     const T s = w.s;
     // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
     constexpr bool ORIG = KLOG == 6;
@@ -181,7 +165,6 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
                 if constexpr (FAIR) f[t] = (T)0;
             }
         }
-        if (touch) asm volatile("" ::"v"((*touch)[0]), "v"((*touch)[1]), "v"((*touch)[2]));  // (the touches of THIS slice, issued a slice ago, end here)
         const bool gather_cold = HOT && !lam_all;  // (wave-uniform: some rows' dual entries are in L2, not in LDS)
         if (gather_cold) {
 #pragma unroll
@@ -234,10 +217,6 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: hoisting every chunk's loads would cost the registers this variant exists to save
         }
-    }
-    if (touch) {
-        if constexpr (RELOAD) asm volatile("" ::"v"((*touch)[0]), "v"((*touch)[1]), "v"((*touch)[2]));
-        sell_touch_next<T, RowT>(g, dv_next, lane, *touch);  // the next slice's lines start travelling to the L2 now
     }
     // ---- projection: per-lane recurrences ----
     T mx = (T)0, sall = (T)0;  // (padding slots hold a = c = 0, so u = 0 there: harmless for the maximum and the sum)
@@ -320,8 +299,8 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         const T ax = (T)(at * x);
         if (ax != (T)0 && !(DEVAB && (ab & (1 << 15)))) {
             if constexpr (HOT) {
-                if ((int64_t)rt < g.m_hot) scatter_fixed(w.gacc, rt, ax, w.scale);
-                else if (!(DEVAB && (ab & (1 << 14)))) scatter_fixed(g.cold_grad, rt, ax, w.scale);
+                if ((int64_t)rt < g.m_hot) scatter_fixed_lds(w.gacc, rt, ax, w.scale);
+                else if (!(DEVAB && (ab & (1 << 14)))) scatter_fixed_global(g.cold_grad, rt, ax, w.scale);
             } else {
                 scatter_fixed(w.gacc, rt, ax, w.scale);
             }
@@ -390,8 +369,6 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
     };
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     uint32_t dv = load_desc(q0);
-    // (the L2 prefetch of the next slice, sell_touch_next, is not wired in here: the three words it carries across a slice pushed the
-    //  benchmark's instantiation -- 126 VGPRs, no scratch -- to 128 VGPRs + 16 bytes of scratch, which the build refuses, dualip_amd/_build.py)
     for (uint32_t q = q0; q < n_sell; q += S) {
         const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), pid = rl(dv, 2), dense0 = rl(dv, 3);
         dv = load_desc(q + S);
@@ -474,8 +451,6 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
     auto rl = [&](uint32_t dv, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane(dv, i); };
     uint32_t j = claim();
     uint32_t dv = load_desc(j);
-    uint32_t tch[3] = {0u, 0u, 0u};
-    uint32_t(*touch)[3] = (kernarg_args(g).ablate & (1 << 18)) ? nullptr : &tch;  // (DUALIP_HIP_ABLATE bit 18: no L2 prefetch of the next slice)
     while (slot(j) < n_sell) {
         const uint32_t jn = claim();
         const uint32_t w0 = rl(dv, 0), w1 = rl(dv, 1), w2 = rl(dv, 2), dense0 = rl(dv, 3);
@@ -505,7 +480,7 @@ __device__ __forceinline__ void sell_lanes_loop(const FusedArgs<T>& g, const WgC
         // instruction count; at 40 non-zeros per column the mean height is 10 and the 12-step variant wasted a fifth); else 12 / 16
         constexpr bool kExact = sizeof(T) == 4 && !FAIR;
         const int hv = kExact ? (H < 9 ? 9 : (H > 16 ? 16 : H)) : (H <= 12 ? 12 : 16);
-#define DL_SELL_LANES_H(K_, HM_) sell_slice<T, RowT, HM_, (HM_ * kPer > 64), LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair, dv, touch); break
+#define DL_SELL_LANES_H(K_, HM_) sell_slice<T, RowT, HM_, (HM_ * kPer > 64), LAM_LDS, HOT, FAIR, K_>(g, w, pj, base, H, hmin, len, len_lane, dense, has_col, lane, sd, eq_row, acc, fair); break
 #define DL_SELL_LANES(K_) \
     switch (hv) { \
         case 9: DL_SELL_LANES_H(K_, (kExact ? 9 : 12)); \

@@ -407,6 +407,8 @@ def test_build_screens_device_assembly_for_the_half_redefined_scalar_pair():
         "other register": text.replace("s_load_dword s55, s[0:1], 0x230", "s_load_dword s56, s[0:1], 0x230").replace("s_mul_i32 s4, s55, 16", "s_mul_i32 s4, s56, 16"),
         "zero extension": text.replace("s_load_dword s55, s[0:1], 0x230", "s_mov_b32 s55, 0"),
         "never used as a pair": text.replace("s_lshl_b64 s[8:9], s[10:11], 3", "s_lshl_b32 s8, s10, 3"),
+        # (a false positive of the first version, met in a real build: the pair was re-formed as a lane mask by a VECTOR compare before the spill)
+        "pair re-formed by a vector compare": text.replace("\ts_mul_i32 s4, s55, 16\n", "\ts_mul_i32 s4, s55, 16\n\tv_cmp_lt_i32_e64 s[54:55], 27, v79\n"),
     }
     for name, var in variants.items():
         assert var != text, name
