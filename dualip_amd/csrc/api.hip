@@ -609,9 +609,16 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         //  ~14 us per ~2000 non-zeros on the MovieLens shape, and stalls the other fifteen wavefronts meanwhile.  Which binary a handle
         //  takes depends on the split itself (>= 1 % of the non-zeros in one-wavefront tiles), so: split at 1024, decide, split again.)
         const char* xl_env = getenv("DUALIP_HIP_XLONG_MIN");
-        bool will_use_lanes = false;
-        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !will_use_lanes; t += 4) will_use_lanes = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
-        if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) will_use_lanes = will_use_lanes || e[0] == '1';
+        bool has_lane_slices = false;
+        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !has_lane_slices; t += 4) has_lane_slices = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
+        // which binary the handle's launches take (matching_kernels.hip: launch_fused4): the second one for handles with K-lane slices (only it
+        // walks them) or with >= 1 % of their non-zeros in one-wavefront single-column tiles; DUALIP_HIP_LANES_BINARY=0|1 forces either on
+        // handles free to use both (testing)
+        auto takes_second_binary = [&]() {
+            bool lb = h->long_nnz > 0 && h->long_nnz * 100 >= nnz;
+            if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) lb = e[0] == '1';
+            return lb || has_lane_slices;
+        };
         uint64_t xlong_min = 1024;
         for (int pass = 0; pass < 2; ++pass) {
             if (xl_env) xlong_min = strtoull(xl_env, nullptr, 10);
@@ -631,17 +638,14 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
                 }
                 pv.push_back(tile_pid4[t]);
             }
-            const bool lanes_now = will_use_lanes || (h->long_nnz > 0 && h->long_nnz * 100 >= nnz);
-            if (pass == 1 || xl_env || !lanes_now || xlong_min == 2048) break;
+            if (pass == 1 || xl_env || !takes_second_binary() || xlong_min == 2048) break;
             xlong_min = 2048;  // the second binary: its one-wavefront in-place slices reach 2048 non-zeros (fused4_kernel.h: walk_long)
         }
         // longest first, dealt in snake order (wavefront W takes slots W, W + S, ...: reversing every other round pairs the
         // longest columns with the shortest ones); the workgroup-walked ones likewise over the workgroups
         // (handles of the fused kernel's second binary -- K-lane slices, or >= 1 % of the non-zeros in single-column tiles; same rule
         //  as matching_kernels.hip: wants_lanes_binary -- deal these tiles to the wavefronts of a workgroup dynamically: plain descending order)
-        bool lanes_binary = h->long_nnz > 0 && h->long_nnz * 100 >= nnz;
-        if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) lanes_binary = e[0] == '1';  // testing: either binary on any handle without K-lane slices
-        for (size_t t = 0; t + 4 <= sell_desc_h.size() && !lanes_binary; t += 4) lanes_binary = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;  // (only the second binary walks K-lane slices)
+        const bool lanes_binary = takes_second_binary();
         h->lanes_binary = lanes_binary;  // read once, here: the binary a launch takes and the tile order below must agree (matching_kernels.hip: launch_fused4)
         auto snake = [lanes_binary](std::vector<uint32_t>& wv, std::vector<uint32_t>& pv, size_t width) {
             const size_t nt = pv.size();
@@ -664,12 +668,20 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             snake(xlong_words, xlong_pid, (size_t)h->n_wg);
         }
         h->n_xlong = (int64_t)xlong_pid.size();
-        // what the workgroup-walked columns cost their workgroups, in slice slots (calibrated on the MovieLens-shaped problem: ~7 ns per
-        // non-zero -- 14 us per ~2000 -- against, since round 4, 0.38 us of workgroup time per 900-slot slice): the K-lane slices are
-        // dealt around it (sell_build.hip)
+        // What a workgroup's columns outside the slice table cost it, in slice slots: the K-lane slices are dealt around it (sell_build.hip:
+        // longest-processing-time first).  Whole-workgroup columns: calibrated on the MovieLens-shaped problem in round 4 -- the longest one
+        // (9 254 non-zeros) holds its workgroup for 14 us while a 900-slot slice costs a workgroup 0.6 us: ~2.5 slots per non-zero
+        // (round 3's figure of 9, from the walker before its reductions moved to the DPP unit, left those workgroups finishing 7 us early).
+        // One-wavefront single-column tiles of the second binary (dealt w, w + G, ... in descending order): their non-zeros + a fixed part.
         h->wg_preload.assign((size_t)(h->n_wg > 0 ? h->n_wg : 1), 0);
+        uint64_t xlong_cost10 = 25, long_fixed = 128;  // (DUALIP_HIP_XLONG_COST10, DUALIP_HIP_LONG_FIXED: calibration runs)
+        if (const char* e = getenv("DUALIP_HIP_XLONG_COST10")) xlong_cost10 = strtoull(e, nullptr, 10);
+        if (const char* e = getenv("DUALIP_HIP_LONG_FIXED")) long_fixed = strtoull(e, nullptr, 10);
         for (size_t t = 0; t < xlong_pid.size() && h->n_wg > 0; ++t)
-            h->wg_preload[t % (size_t)h->n_wg] += 16ull * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]);
+            h->wg_preload[t % (size_t)h->n_wg] += xlong_cost10 * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]) / 10;
+        if (lanes_binary && long_fixed < (1ull << 40))
+            for (size_t t = 0; t < long_pid.size() && h->n_wg > 0; ++t)
+                h->wg_preload[t % (size_t)h->n_wg] += (((uint64_t)long_words[t * 12 + 3] << 32) | long_words[t * 12 + 2]) + long_fixed;
         long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
         long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
         if (!dev_pack && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
@@ -985,6 +997,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 16: return h->layout == 4 ? h->desc_words : 4;
         case 17: return h->n_sell_mixed_cols;
         case 2003: return h->m_hot > 0 ? h->m_lam : (h->lam_lds ? h->m : 0);  // rows of the dual vector staged in LDS
+        case 2004: return (h->lanes_binary || h->n_sell_lane_slices > 0) ? 1 : 0;
         case 2001: return h->owns_inputs ? 1 : 0;
         case 2002: return h->owns_inputs ? h->own_count : h->unsliced_end;  // non-zeros read in place from the (caller's / owned) CSC-ordered arrays
         case 2000: return h->n_sell_lane_cols;

@@ -273,6 +273,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         names = ["tiles", "workgroups", "lds_bytes", "lambda_in_lds", "grad_in_lds", "owned_bytes", "long_columns", "row_index_bytes", "layout", "hot_rows", "hot_nnz_ppm", "workgroup_columns", "slices", "slice_columns", "slice_elements", "slice_nnz", "window_descriptor_words", "slice_mixed_columns"]
         info = {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
         info["lambda_rows_in_lds"] = int(self._lib.dl_matching_info(self._handle, 2003))  # hot-rows plan: >= hot_rows; = m when the whole dual vector is staged
+        info["second_binary"] = int(self._lib.dl_matching_info(self._handle, 2004))  # launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal)
         info["slice_lane_columns"] = int(self._lib.dl_matching_info(self._handle, 2000))  # columns dealt to K = 2 .. 32 lanes each (25 .. 512 non-zeros; a handle's few short columns join them)
         return info
 

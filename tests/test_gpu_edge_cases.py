@@ -377,15 +377,19 @@ def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
         monkeypatch.setenv("DUALIP_HIP_XLONG_MIN", "256")
     monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the walkers are the subject: keep long point-wise columns out of the window stream
     m, n = 10_000, 3_000
-    long_cols = ((2, 9000), (700, 3000), (1500, 2049), (2999, 2048), (5, 600), (2000, 5000))
+    # (round 4: the second binary walks simplex columns of up to 2048 non-zeros by ONE wavefront as in-place slices of 20 / 24 / 28 / 32 steps
+    #  -- 1100, 1500, 1700, 2048 below -- so only the columns beyond 2048 go to the whole workgroup there; 2048 | 2049 is the class edge)
+    long_cols = ((2, 9000), (700, 3000), (1500, 2049), (2999, 2048), (5, 600), (2000, 5000), (100, 1100), (200, 1500), (300, 1700))
     p = _random_problem(m, n, 10, seed=77, long_cols=long_cols, empty_every=19)
     lam = np.random.default_rng(10).uniform(0, 0.01, m)
-    want = 6 if forced else 5  # columns of more than 1024 non-zeros
+
+    def want_of(info):  # columns the whole workgroup walks: all 9 single-column tiles when forced (threshold 256), else those beyond 1024 / 2048
+        return 9 if forced else (4 if info["second_binary"] else 8)
     for dn in ("f32", "f64"):
         for pt, pp in (("simplex", {"z": 1.0}), ("simplex", {"z": 40.0}), ("box", {"lower": 0.0, "upper": 0.5})):
             f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
             info = f.info()
-            assert info["long_columns"] >= 6 and (info["layout"] != 4 or info["workgroup_columns"] == want), info  # (DUALIP_HIP_LAYOUT=1 runs: one walker only)
+            assert info["long_columns"] >= 9 and (info["layout"] != 4 or info["workgroup_columns"] == want_of(info)), info  # (DUALIP_HIP_LAYOUT=1 runs: one walker only)
         # simplex_eq, exact mode (the oracle's padded blocks differ wherever a clamped column sums to less than z): every
         # non-empty column sums to z, and columns without a deficit agree with the oracle
         td = torch.float32 if dn == "f32" else torch.float64
@@ -419,7 +423,7 @@ def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
     monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "2048")
     for dn in ("f32", "f64"):
         f = _compare(p, create_projection_map("simplex", {"z": 1.0}, n), [("simplex", {"z": 1.0})], None, 0.05, dn, lam)
-        assert f.info()["layout"] != 4 or (f.info()["hot_rows"] == 2048 and f.info()["workgroup_columns"] == want)
+        assert f.info()["layout"] != 4 or (f.info()["hot_rows"] == 2048 and f.info()["workgroup_columns"] == want_of(f.info()))
 
 
 def test_hot_rows_state_survives_outside_calls_between_iterations(monkeypatch):
