@@ -136,8 +136,15 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
             const int64_t rc = live ? col : p.m - 1;
             const bool in_slabs = !p.inv || rc < p.m_hot;
             if (!in_slabs && ws == 0) {
-                acc = p.cold[rc];
-                if (p.cold_zero && live) p.cold_zero[rc] = 0;  // consumed: ready for the next fused launch (no memset launch)
+                long long cv[kColdCopies];  // (one copy per XCD, fused_common.h: all eight loads in flight together)
+#pragma unroll
+                for (int k = 0; k < kColdCopies; ++k) cv[k] = p.cold[(int64_t)k * p.mpad + rc];
+#pragma unroll
+                for (int k = 0; k < kColdCopies; ++k) acc += cv[k];
+                if (p.cold_zero && live) {  // consumed: ready for the next fused launch (no memset launch)
+#pragma unroll
+                    for (int k = 0; k < kColdCopies; ++k) p.cold_zero[(int64_t)k * p.mpad + rc] = 0;
+                }
             }
             constexpr int kU = 16;  // (256 slabs / 16 slices: every load of a thread in flight at once)
             for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {

@@ -669,12 +669,14 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         }
         h->n_xlong = (int64_t)xlong_pid.size();
         // What a workgroup's columns outside the slice table cost it, in slice slots: the K-lane slices are dealt around it (sell_build.hip:
-        // longest-processing-time first).  Whole-workgroup columns: calibrated on the MovieLens-shaped problem in round 4 -- the longest one
-        // (9 254 non-zeros) holds its workgroup for 14 us while a 900-slot slice costs a workgroup 0.6 us: ~2.5 slots per non-zero
-        // (round 3's figure of 9, from the walker before its reductions moved to the DPP unit, left those workgroups finishing 7 us early).
-        // One-wavefront single-column tiles of the second binary (dealt w, w + G, ... in descending order): their non-zeros + a fixed part.
+        // longest-processing-time first).  Whole-workgroup columns: 16 slots per non-zero -- swept on the MovieLens-shaped problem in
+        // round 4 (same box, fused kernel per launch: 0 -> 66.8 / 67.3 us, 1.5 -> 65.4, 2.5 -> 65.1 / 63.7, 4 -> 64.2 / 62.6, 9 -> 61.5 /
+        // 59.9, 16 -> 57.3 / 57.5): far more than the column's own time would say (14 us of its workgroup for 9 254 non-zeros ~ 2.5 slots
+        // per non-zero) -- a workgroup that starts its slices late also walks them slower (its sixteen wavefronts enter the slice loop
+        // together, in step, after the walker's last barrier).  One-wavefront single-column tiles of the second binary (dealt w, w + G, ...
+        // in descending order) are counted with their non-zeros + a fixed part (no measurable effect: 0 / 128 / 512 / off within noise).
         h->wg_preload.assign((size_t)(h->n_wg > 0 ? h->n_wg : 1), 0);
-        uint64_t xlong_cost10 = 25, long_fixed = 128;  // (DUALIP_HIP_XLONG_COST10, DUALIP_HIP_LONG_FIXED: calibration runs)
+        uint64_t xlong_cost10 = 160, long_fixed = 128;  // (DUALIP_HIP_XLONG_COST10, DUALIP_HIP_LONG_FIXED: calibration runs)
         if (const char* e = getenv("DUALIP_HIP_XLONG_COST10")) xlong_cost10 = strtoull(e, nullptr, 10);
         if (const char* e = getenv("DUALIP_HIP_LONG_FIXED")) long_fixed = strtoull(e, nullptr, 10);
         for (size_t t = 0; t < xlong_pid.size() && h->n_wg > 0; ++t)
@@ -794,7 +796,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         CK(owned_malloc(h, (void**)&h->row_inv, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, (void**)&h->row_perm, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, &h->lam_perm, (size_t)m * (val_dtype == DL_F32 ? 4 : 8)));
-        CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad));
+        CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad * (size_t)kColdCopies));
+        h->cold_per_xcd = !(getenv("DUALIP_HIP_COLD_XCD") && getenv("DUALIP_HIP_COLD_XCD")[0] == '0');
     }
     if (getenv("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;

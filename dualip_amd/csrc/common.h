@@ -59,6 +59,7 @@ inline size_t bal_table_words(int n_wg) { return 4 + (size_t)n_wg + kBalTail + (
 constexpr int kBalLaunches = 8;     // first launches of a handle, which all adapt the table ...
 constexpr int kBalEvery = 16;       // ... afterwards every kBalEvery-th launch does
 constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
+constexpr int kColdCopies = 8;                 // hot-rows plan: one array of cold-row accumulators per XCD (the chip has 8; XCC_ID & 7)
 constexpr size_t kLdsScratch = 512;            // per-workgroup reduction scratch (bytes)
 constexpr int kProjLdsSlots = 256;            // projection table slots in LDS (simplex.h kProjLds)
 constexpr int kLogCols = 8;                    // doubles per iteration in the AGD log
@@ -135,7 +136,8 @@ struct dl_matching {
     double* partial_fair = nullptr;   // owned, [n_wg]
     double* dense_ax = nullptr;       // owned, [2]: (A x) of the two rows, written after every fused launch
     void* lam_perm = nullptr;         // owned, val[m]: the dual vector in renumbered order (rebuilt every launch)
-    long long* cold_grad = nullptr;   // owned, int64[mpad]: accumulators of the renumbered rows >= m_hot
+    bool cold_per_xcd = true;         // every XCD adds to its own copy of the cold accumulators through its L2 (DUALIP_HIP_COLD_XCD=0: one shared copy, device-scope atomics)
+    long long* cold_grad = nullptr;   // owned, int64[kColdCopies][mpad]: accumulators of the renumbered rows >= m_hot
     // column-per-lane slices (sell.h): short columns of simplex entries, sorted by length, 64 per slice, transposed copies of
     // their values and row indices owned by the handle
     int64_t n_sell = 0, n_sell_cols = 0, n_sell_elems = 0, n_sell_nnz = 0;  // slices, their columns, slots (with padding), non-zeros

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
             double ol = 0.0, ql = 0.0;  // (this column's sums of this thread: one rounded integer each)
             process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
-                                                      FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words, HOT ? gk.m_lam : (int64_t)0);
+                                                      FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words, HOT ? gk.m_lam : (int64_t)0, w.cold);
             fx_add_wide(acc, ol, ql, w.scale2);
         }
         if (n_xlong) __syncthreads();  // red_s is free again (the epilogue reuses it)
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
         }
         double ol = 0.0, ql = 0.0;
         process_long_tile<T, RowT, LAM_LDS>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, lane, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, nullptr, sd,
-                                            FAIR ? &fair : nullptr, desc, HOT ? gk.m_lam : (int64_t)0);
+                                            FAIR ? &fair : nullptr, desc, HOT ? gk.m_lam : (int64_t)0, w.cold);
         fx_add_wide(acc, ol, ql, w.scale2);
     };
     // The second binary deals single-column tiles and K-lane slices to WORKGROUPS statically (workgroup w owns slots w, w + G, ...
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             if (ax != (T)0) {
                 if constexpr (HOT) {
                     if ((int64_t)row[j] < g.m_hot) scatter_fixed_lds(w.gacc, row[j], ax, w.scale);
-                    else scatter_fixed_global(g.cold_grad, row[j], ax, w.scale);
+                    else scatter_fixed_cold(w.cold, g.cold_grad, row[j], ax, w.scale);
                 } else {
                     scatter_fixed(w.gacc, row[j], ax, w.scale);
                 }

@@ -43,7 +43,8 @@ struct FusedArgs {
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) have their GRADIENT accumulator in LDS; 0 = every row does
     int64_t m_lam;                 // hot-rows plan: rows < m_lam have their DUAL entry in LDS (m_hot <= m_lam <= m; m: no tile gathers from L2)
-    long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed)
+    long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed): [kColdCopies][mpad]
+    int cold_per_xcd;              // 1: every XCD adds to its own copy with L2-local atomics; 0: copy 0 only, device-scope atomics
     const int32_t* eq_heights;     // simplex_eq reference-compatibility mode: [n_proj][kEqBuckets] padded block heights, or null (exact)
     // fairness pair (dl_matching_set_fairness): rows m-2 / m-1 carry +f_k / -f_k on EVERY non-zero k
     const T* fair;                 // f, in the order of a / c, or null
@@ -206,7 +207,18 @@ template <class T>
 __device__ __forceinline__ void scatter_fixed_global(long long* acc, uint32_t row, T ax, double scale) {
     typedef __attribute__((address_space(1))) unsigned long long glb_u64;
     glb_u64* p = (glb_u64*)(reinterpret_cast<unsigned long long*>(acc) + row);
-    (void)__hip_atomic_fetch_add(p, (unsigned long long)to_fixed(ax, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_atomic_add_x2
+    (void)__hip_atomic_fetch_add(p, (unsigned long long)to_fixed(ax, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_atomic_add_x2 sc1
+}
+// the cold row's accumulator: this XCD's copy through its own L2 (workgroup scope: no sc1), or the shared copy at the memory side
+template <class T>
+__device__ __forceinline__ void scatter_fixed_cold(long long* xcd_copy, long long* shared, uint32_t row, T ax, double scale) {
+    if (xcd_copy) {  // (wave-uniform)
+        typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+        glb_u64* p = (glb_u64*)(reinterpret_cast<unsigned long long*>(xcd_copy) + row);
+        (void)__hip_atomic_fetch_add(p, (unsigned long long)to_fixed(ax, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        scatter_fixed_global(shared, row, ax, scale);
+    }
 }
 
 template <class P>
@@ -223,7 +235,8 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 template <class T, class RowT, bool LAM_LDS, bool WG = false>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
-                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr, int64_t m_lam = 0) {
+                                              double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr, int64_t m_lam = 0,
+                                              long long* cold_xcd = nullptr) {
     if (m_lam < m_hot) m_lam = m_hot;  // (rows whose dual entry is in LDS; the hot-rows plan may stage more of them than gradient rows)
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
@@ -413,7 +426,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             if (ax != (T)0) {
                 if (m_hot > 0) {  // (hot-rows plan: gacc is the LDS accumulator)
                     if ((int64_t)rv[u] < m_hot) scatter_fixed_lds(gacc, rv[u], ax, scale);
-                    else scatter_fixed_global(g.cold_grad, rv[u], ax, scale);
+                    else scatter_fixed_cold(cold_xcd, g.cold_grad, rv[u], ax, scale);
                 } else {
                     scatter_fixed(gacc, rv[u], ax, scale);
                 }
@@ -440,6 +453,7 @@ struct WgCtx {
     ProjT<T>* proj_s;
     double* red_s;
     long long* gacc;
+    long long* cold;    // hot-rows plan: THIS XCD's array of cold-row accumulators (fused_prologue); null: the shared one, device-scope atomics
     T s;           // -1/gamma rounded once to the working precision (matching.py:136)
     double scale;  // 2^shift of the fixed-point gradient
     double scale2; // 2^shift of the fixed-point scalar sums (c.x, sum x^2)
@@ -595,6 +609,15 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         g.shift_out[1] = shift2;
     }
     w.gacc = GRAD_LDS ? w.grad_s : g.partial;
+    // Cold rows of the hot-rows plan: a device-scope atomic executes at the memory side -- on this chip every one of them leaves its
+    // XCD (counters of the MovieLens shape, round 4: 64 MB of WRITE_SIZE per launch for 1.6 M of them).  Each XCD gets its own array
+    // instead (kColdCopies of them; the statistics / reduction kernels add them up) and the atomics are WORKGROUP-scope: they execute in
+    // the XCD's own L2, which every workgroup that uses this array shares.  The kernel boundary writes the dirty lines back.
+    w.cold = nullptr;
+    if (g.m_hot > 0 && g.cold_per_xcd) {
+        const unsigned int xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11)) & (unsigned int)(kColdCopies - 1);
+        w.cold = g.cold_grad + (int64_t)xcc * g.mpad;
+    }
     return w;
 }
 

@@ -300,7 +300,10 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         const int64_t rc = row < m ? row : (m > 0 ? m - 1 : 0);
         long long acc = 0;
         const bool in_slabs = !inv || rc < m_hot;
-        if (!in_slabs && ws == 0) acc = cold[rc];
+        if (!in_slabs && ws == 0) {  // (one copy per XCD: dl::kColdCopies)
+#pragma unroll
+            for (int k = 0; k < kColdCopies; ++k) acc += cold[(int64_t)k * mpad + rc];
+        }
         // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
         constexpr int kU = 8, kStride = kRedThreads / kRedRows;
         for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
@@ -643,6 +646,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.m_hot = h->m_hot;
     args.m_lam = h->m_hot > 0 ? h->m_lam : 0;
     args.cold_grad = h->cold_grad;
+    args.cold_per_xcd = h->cold_per_xcd ? 1 : 0;
     args.fair = static_cast<const T*>(h->fair);
     args.lambda_orig = static_cast<const T*>(lambda);
     args.partial_fair = h->partial_fair;
@@ -677,7 +681,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
             const unsigned blocks = (unsigned)((h->m + 255) / 256);
             hipLaunchKernelGGL(permute_vector_kernel<T>, dim3(blocks), dim3(256), 0, st, h->m, static_cast<const T*>(lambda), h->row_inv, static_cast<T*>(h->lam_perm));
             DL_HIP(hipGetLastError());
-            DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad, st));
+            DL_HIP(hipMemsetAsync(h->cold_grad, 0, sizeof(long long) * (size_t)h->mpad * (size_t)kColdCopies, st));
         }
         h->hot_ready = false;  // this launch fills the cold accumulators
         args.lambda = static_cast<const T*>(h->lam_perm);

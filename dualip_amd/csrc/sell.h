@@ -300,7 +300,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
         if (ax != (T)0 && !(DEVAB && (ab & (1 << 15)))) {
             if constexpr (HOT) {
                 if ((int64_t)rt < g.m_hot) scatter_fixed_lds(w.gacc, rt, ax, w.scale);
-                else if (!(DEVAB && (ab & (1 << 14)))) scatter_fixed_global(g.cold_grad, rt, ax, w.scale);
+                else if (!(DEVAB && (ab & (1 << 14)))) scatter_fixed_cold(w.cold, g.cold_grad, rt, ax, w.scale);
             } else {
                 scatter_fixed(w.gacc, rt, ax, w.scale);
             }
