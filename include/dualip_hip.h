@@ -116,15 +116,19 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
 /* Size/introspection: what = 0 number of wave tiles, 1 workgroups used, 2 LDS bytes per workgroup,
  * 3 lambda staged in LDS (0/1), 4 gradient privatised in LDS (0/1), 5 bytes of owned device memory,
  * 6 number of single-column ("long") tiles, 7 row-index width in bytes, 8 tile layout (non-zeros per lane: 4 or 1),
- * 9 rows kept in LDS by the hot-rows plan (0 = plan not in use: all rows or none are), 10 share of the non-zeros in those rows x 1e6,
- * 11 single-column tiles long enough (> 1024 non-zeros) to be walked by a whole workgroup instead of one wavefront,
+ * 9 rows whose GRADIENT accumulator the hot-rows plan keeps in LDS (0 = plan not in use: all rows or none are), 10 share of the
+ * non-zeros in those rows x 1e6,
+ * 11 single-column tiles long enough (> 1024 non-zeros; > 2048 for handles of the second binary) to be walked by a whole workgroup,
  * 12 column-per-lane slices (64 short columns of a simplex entry each, sorted by length; the handle owns a transposed copy of
  * their values and row indices), 13 columns in slices, 14 slice elements including padding, 15 non-zeros in slices,
  * 16 dwords per window descriptor (12; 2 when every window is point-wise: compact table; 4 for the 64-wide layout),
  * 17 columns of slices that hold more than one column length (only their length bytes are read per launch),
  * 18 + w (w < 1024): rounds of workgroup w in the window tiles' cyclic deal (-1: no table; synchronous device read),
  * 2000 columns held in slices with K = 2 .. 32 lanes per column (counted in 13 too): those of 25 .. 512 non-zeros, and a handle's
- *      FEW short columns, which join the two-lane class. */
+ *      FEW short columns, which join the two-lane class,
+ * 2001 the handle owns its inputs (dl_matching_own_inputs), 2002 elements of the caller-ordered arrays read in place (owned: kept),
+ * 2003 rows whose DUAL entry the hot-rows plan stages in LDS (>= what 9 reports; = m when the whole dual vector fits: no tile gathers
+ *      from L2), 2004 launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal inside a workgroup). */
 int64_t dl_matching_info(const dl_matching* h, int what);
 
 /* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays
