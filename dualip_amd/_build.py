@@ -20,6 +20,8 @@ FLAGS = [
     "-shared",
     "-ffp-contract=off",       # keep the reference's mul-then-add rounding (no FMA contraction)
     "-munsafe-fp-atomics",     # hardware ds_add_f32/f64 and global_atomic_add for the gradient scatter
+    "-fno-slp-vectorize",      # the SLP pass pairs independent fp32 ops of neighbouring slice steps into v_pk_* at two v_mov each (more
+                               # instructions AND more registers: the benchmark's kernel 128 -> 119 VGPRs without it)
     "-Wall",
     "-Wno-unused-function",
 ]

@@ -90,6 +90,10 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 //  on the K-lane loop: the MovieLens shape went from 56.6 to 66.1 us per launch, same box, three alternations (and FETCH_SIZE doubled:
 //  the touched lines were fetched again by the non-temporal loads).  Wired into the one-lane loop it cost the benchmark's instantiation
 //  its last two registers (16 bytes of scratch: the build refuses that).  Removed; profiles/r04_ab_movielens_touch_negative.txt.)
+// (Round 4 also measured a CHUNKED slice -- four consecutive steps of a column side by side, base + 256 (t / 4) + 4 lane + t % 4, tails
+//  of two and one: the same 64 H slots, read by 16- and 8-byte loads per lane, nine instructions for a ten-step slice instead of
+//  thirty -- on the guess that the memory pipeline prefers wide accesses.  It does not here: same box, 100M all-simplex 1.675 / 1.749 ms
+//  step-major against 1.755 / 1.809 chunked, 10M unchanged (profiles/r04d_ab_chunked_slices_negative.txt).  The slice stays step-major.)
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds
@@ -98,12 +102,15 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 // the CSC order itself, so `base` is the column's offset in g.a / g.c / g.rowidx and nothing is copied: the single-column tiles of up
 // to 64 HM non-zeros walked as one slice (all loads in flight at once, values kept in registers, straight-line passes) instead of by
 // process_long_tile's batched loops.
-template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR, int KLOG = 0>
+template <class T, class RowT, int HM, bool RELOAD, bool LAM_LDS, bool HOT, bool FAIR, int KLOG = 0, bool EXACT = false>
 __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>& w, const ProjT<T>& pj, uint64_t base, int H, int Hmin, int len, int len_lane,
                                            uint64_t dense, bool has_col, int lane, T sd, const int32_t* eq_row, FxAcc& acc, double& fair) {
     const T s = w.s;
     // wave-uniform bases (scalar registers) + one 32-bit lane offset per element width: step t is an immediate
     constexpr bool ORIG = KLOG == 6;
+    // EXACT: the variant's step count IS the slice's height (the fp32 variants 5 .. 16), so every "does this step exist" below is
+    // decided at compile time -- before, the load issue of a slice spent two scalar branches and a zero fill per step on them
+    const int Hc = EXACT ? HM : H;
     const T* __restrict__ pa = byte_offset((ORIG ? g.a : g.sell_a) + base, (uint32_t)lane * (uint32_t)sizeof(T));
     const T* __restrict__ pc = byte_offset((ORIG ? g.c : g.sell_c) + base, (uint32_t)lane * (uint32_t)sizeof(T));
     const RowT* __restrict__ pr = byte_offset(reinterpret_cast<const RowT*>(ORIG ? g.rowidx : g.sell_r) + base, (uint32_t)lane * (uint32_t)sizeof(RowT));
@@ -153,7 +160,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     if constexpr (!RELOAD) {
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
-            if (t < H) {  // wave-uniform
+            if (t < Hc) {  // wave-uniform (EXACT: known at compile time)
                 a[t] = __builtin_nontemporal_load(PA(t));
                 c[t] = __builtin_nontemporal_load(PC(t));
                 r[t] = (uint32_t)__builtin_nontemporal_load(PR(t));
@@ -188,7 +195,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int t = t0 + q;
-                if (t < H) {
+                if (t < Hc) {
                     a8[q] = *PA(t);  // (cached loads: the second pass re-reads them)
                     c8[q] = *PC(t);
                     r8[q] = (uint32_t)*PR(t);
@@ -228,9 +235,12 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     mx = group_max_nonneg<KLOG>(mx);
     sall = group_sum<KLOG>(sall);
     // slots past a column's own length (the slice's padding; none below Hmin) must not count as members
+    if constexpr (KLOG == 0) asm volatile("" : "+v"(mx), "+v"(sall));  // (the two reductions stay AHEAD of the branch: sunk below it they keep the unmasked values alive, one copy per step)
+    if (Hmin < HM) {  // (wave-uniform; all but the slices at a length-class boundary hold columns of one length: nothing to mask)
 #pragma unroll
-    for (int t = 0; t < HM; ++t)
-        if (t >= Hmin) u[t] = t < len_lane ? u[t] : NEG;
+        for (int t = 0; t < HM; ++t)
+            if (t >= Hmin) u[t] = t < len_lane ? u[t] : NEG;
+    }
     // first support {u > theta_0}, theta_0 = the larger of two lower bounds of the threshold: max - z (the reference's top-2
     // shortcut: only the maximum above it <=> vertex) and (sum of all - z) / length (Michelot's start).  Late in a solve, when
     // most of a column is in its support, the second one is close to the answer and saves a pass or two; a single member can
@@ -315,13 +325,20 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     uint64_t k0 = 0;
     if (xo && has_col) k0 = (ORIG ? dense : gk.sell_colstart[dense]) + (uint64_t)(lane & ((1 << KLOG) - 1));  // (ORIG: `dense` IS the column's place in the caller's order)  // this lane's first element of the column
     if constexpr (!RELOAD) {
-        // (splitting this loop on `xo` -- no per-step branch when the primal is not requested -- lets the scheduler overlap all steps and
-        //  costs 9 more registers: 12 bytes of scratch, +6 % kernel time; measured, left as it is)
+        // The primal, when requested (the last launch of a solve), is written by a loop of its OWN ahead of the scatter: one wave-uniform
+        // branch per slice instead of a mask, a test and a branch per STEP inside the scatter loop, whose steps the scheduler can now
+        // overlap.  (Round 2 had split the scatter loop itself on `xo` -- two copies of it -- for 9 more registers, 12 bytes of scratch
+        // and +6 % kernel time; this costs none: the values are recomputed from u and theta, same expression, same bits.)
+        if (xo) {
 #pragma unroll
-        for (int t = 0; t < HM; ++t) {
-            const T x = finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
-            if (xo && has_col && t < len_lane) xo[k0 + ((uint64_t)t << KLOG)] = x;
+            for (int t = 0; t < HM; ++t) {
+                const T xg = relu((T)(u[t] - theta));
+                const T x = (vertex && u[t] > theta) ? pj.z : xg;
+                if (has_col && t < len_lane) xo[k0 + ((uint64_t)t << KLOG)] = x;
+            }
         }
+#pragma unroll
+        for (int t = 0; t < HM; ++t) (void)finish(t, a[t], c[t], r[t], FAIR ? f[t] : (T)0);
     } else {
 #pragma unroll
         for (int t0 = 0; t0 < HM; t0 += CH) {
@@ -330,7 +347,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int t = t0 + q;
-                if (t < H) {
+                if (t < Hc) {
                     a8[q] = __builtin_nontemporal_load(PA(t));
                     c8[q] = __builtin_nontemporal_load(PC(t));
                     r8[q] = (uint32_t)__builtin_nontemporal_load(PR(t));
@@ -391,29 +408,31 @@ __device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>&
         // need more than 64 of them re-read the slice for the scatter instead (RELOAD)
         constexpr int kPer = (2 + (FAIR ? 1 : 0)) * (int)(sizeof(T) / 4) + 1 + (int)(sizeof(T) / 4);
         constexpr bool R4 = 4 * kPer > 64, R8 = 8 * kPer > 64, R12 = 12 * kPer > 64, R16 = 16 * kPer > 64;
-#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR>(g, w, pj, base, H, hmin, len, len, dense, has_col, lane, sd, eq_row, acc, fair); break
+#define DL_SELL_CASE(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR, 0, false>(g, w, pj, base, H, hmin, len, len, dense, has_col, lane, sd, eq_row, acc, fair); break
+#define DL_SELL_EXACT(HM_, R_) sell_slice<T, RowT, HM_, R_, LAM_LDS, HOT, FAIR, 0, kExact>(g, w, pj, base, H, hmin, len, len, dense, has_col, lane, sd, eq_row, acc, fair); break
         // The fp32 kernels without the fairness stream (the benchmark's) have one variant per height from 5 to 16: a step past the
         // slice's height costs every pass its full instruction count (a slice of 9 in the 12-step variant: +33 %), and at ten
         // non-zeros per column that padding was ~13 % of the slices' vector instructions.  The others step by four.
         constexpr bool kExact = sizeof(T) == 4 && !FAIR;
-        const int hv = (kExact && !(g.ablate & 64) && H > 4 && H <= 16) ? H : 4 * sell_chunks(H);  // (DUALIP_HIP_ABLATE=64: steps of four everywhere)
+        const int hv = (kExact && H > 4 && H <= 16) ? H : 4 * sell_chunks(H);  // (kExact: cases 5 .. 16 are entered with H == the case)
         switch (hv) {
             case 4: DL_SELL_CASE(4, R4);
-            case 5: DL_SELL_CASE(kExact ? 5 : 8, R8);
-            case 6: DL_SELL_CASE(kExact ? 6 : 8, R8);
-            case 7: DL_SELL_CASE(kExact ? 7 : 8, R8);
-            case 8: DL_SELL_CASE(8, R8);
-            case 9: DL_SELL_CASE(kExact ? 9 : 12, R12);
-            case 10: DL_SELL_CASE(kExact ? 10 : 12, R12);
-            case 11: DL_SELL_CASE(kExact ? 11 : 12, R12);
-            case 12: DL_SELL_CASE(12, R12);
-            case 13: DL_SELL_CASE(kExact ? 13 : 16, R16);
-            case 14: DL_SELL_CASE(kExact ? 14 : 16, R16);
-            case 15: DL_SELL_CASE(kExact ? 15 : 16, R16);
-            case 16: DL_SELL_CASE(16, R16);
+            case 5: DL_SELL_EXACT(kExact ? 5 : 8, R8);
+            case 6: DL_SELL_EXACT(kExact ? 6 : 8, R8);
+            case 7: DL_SELL_EXACT(kExact ? 7 : 8, R8);
+            case 8: DL_SELL_EXACT(8, R8);
+            case 9: DL_SELL_EXACT(kExact ? 9 : 12, R12);
+            case 10: DL_SELL_EXACT(kExact ? 10 : 12, R12);
+            case 11: DL_SELL_EXACT(kExact ? 11 : 12, R12);
+            case 12: DL_SELL_EXACT(12, R12);
+            case 13: DL_SELL_EXACT(kExact ? 13 : 16, R16);
+            case 14: DL_SELL_EXACT(kExact ? 14 : 16, R16);
+            case 15: DL_SELL_EXACT(kExact ? 15 : 16, R16);
+            case 16: DL_SELL_EXACT(16, R16);
             default: DL_SELL_CASE(24, true);
         }
 #undef DL_SELL_CASE
+#undef DL_SELL_EXACT
     }
 }
 
