@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             const uint64_t len = ((uint64_t)rl(dvl, 3) << 32) | rl(dvl, 2);
             const int32_t* eq_row = (gk.eq_heights && pidl != kNoProj && pidl != 0xFFFFFFFFu) ? gk.eq_heights + (size_t)pidl * kEqBuckets : nullptr;
             double ol = 0.0, ql = 0.0;  // (this column's sums of this thread: one rounded integer each)
-            process_long_tile<T, RowT, LAM_LDS, true>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
+            process_long_tile<T, RowT, LAM_LDS, true, (LANES ? 16 : 8)>(gk, pl, k0, len, w.lam_s, w.gacc, s, w.scale, tid, ol, ql, eq_row, HOT ? gk.m_hot : (int64_t)0, w.red_s, sd,
                                                       FAIR ? &fair : nullptr, gk.long32 + (size_t)(gk.n_long + xt) * kDesc4Words, HOT ? gk.m_lam : (int64_t)0, w.cold);
             fx_add_wide(acc, ol, ql, w.scale2);
         }

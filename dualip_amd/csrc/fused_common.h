@@ -232,7 +232,7 @@ __device__ __forceinline__ P byte_offset(P base, uint32_t bytes) {
 // WG = true: the same walk by the whole workgroup (columns of thousands of non-zeros: one wavefront walking them alone sets
 // the critical path of the launch).  `lane` is then the thread index, strides are kFusedThreads wide, reductions go through
 // `red` (>= kFusedWaves doubles of LDS) with workgroup barriers -- every thread of the workgroup must make the call.
-template <class T, class RowT, bool LAM_LDS, bool WG = false>
+template <class T, class RowT, bool LAM_LDS, bool WG = false, int KRB_WG = 8>
 __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const ProjT<T> pj, uint64_t k0, uint64_t len, const T* lam_s, long long* gacc, T s,
                                               double scale, int lane, double& obj, double& ssq, const int32_t* eq_row = nullptr, int64_t m_hot = 0,
                                               double* red = nullptr, T sd = (T)0, double* fair_acc = nullptr, const uint32_t* desc = nullptr, int64_t m_lam = 0,
@@ -240,27 +240,27 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
     if (m_lam < m_hot) m_lam = m_hot;  // (rows whose dual entry is in LDS; the hot-rows plan may stage more of them than gradient rows)
     constexpr int kLB = 4;
     constexpr uint32_t kStride = WG ? (uint32_t)kFusedThreads : 64u;
-    auto all_sum = [&](double x) -> double {
+    // WG: two quantities through ONE exchange (a pass of the walker used to spend two barrier pairs on its sum and two on its count --
+    // for a column of thousands of tied values, ten passes: the barriers, not the data, were its time); the same per-wavefront partials
+    // summed in the same fixed order, so no bit changes.  `red` holds >= 2 kFusedWaves doubles.
+    auto all_pair = [&](double& x, double& y, bool y_is_max) {
         x = wave_allreduce_dpp(x, OpAdd());
+        y = y_is_max ? wave_allreduce_dpp(y, OpMax()) : wave_allreduce_dpp(y, OpAdd());
         if constexpr (WG) {
-            __syncthreads();  // the previous reduction's readers are done
-            if ((lane & 63) == 0) red[lane >> 6] = x;
+            __syncthreads();  // the previous exchange's readers are done
+            if ((lane & 63) == 0) {
+                red[lane >> 6] = x;
+                red[kFusedWaves + (lane >> 6)] = y;
+            }
             __syncthreads();
             x = red[0];
-            for (int q = 1; q < kFusedWaves; ++q) x += red[q];  // fixed order
+            y = red[kFusedWaves];
+            for (int q = 1; q < kFusedWaves; ++q) {  // fixed order
+                x += red[q];
+                const double yq = red[kFusedWaves + q];
+                y = y_is_max ? (yq > y ? yq : y) : y + yq;
+            }
         }
-        return x;
-    };
-    auto all_max = [&](double x) -> double {
-        x = wave_allreduce_dpp(x, OpMax());
-        if constexpr (WG) {
-            __syncthreads();
-            if ((lane & 63) == 0) red[lane >> 6] = x;
-            __syncthreads();
-            x = red[0];
-            for (int q = 1; q < kFusedWaves; ++q) x = red[q] > x ? red[q] : x;
-        }
-        return x;
     };
     const bool is_simplex = is_simplex_kind(pj.kind);
     // v = a * (-lambda/gamma) + (-c/gamma) for the elements o0 + lane + kStride u (ok[u]: inside the column)
@@ -306,7 +306,10 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
     bool projected = false, onehot = false;
     // columns of up to kRB strides keep their clamped values in registers across the Newton passes (-inf outside the column);
     // longer ones re-read the arrays (L2-hot) in every pass
-    constexpr int kRB = WG ? 8 : 16;
+    // (WG: KRB_WG strides of 1024.  The second binary asks for 16 -- at 8 the MovieLens shape's longest column, 9 254 non-zeros, re-read its
+    //  arrays in every pass; the benchmark's binary stays at 8: with 16 its hot loop lost its last registers, 20 bytes of scratch, and the
+    //  build refuses that)
+    constexpr int kRB = WG ? KRB_WG : 16;
     const bool cached = len <= (uint64_t)kStride * kRB && !(g.ablate & 8);
     T vr[kRB];
     if (is_simplex) {
@@ -345,8 +348,10 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
             }
         }
         if constexpr (WG) {  // (wavefront partials combined in double, rounded once)
-            S = (T)all_sum((double)S);
-            v1 = (T)all_max((double)v1);
+            double Sd = (double)S, v1d = (double)v1;
+            all_pair(Sd, v1d, true);
+            S = (T)Sd;
+            v1 = (T)v1d;
         } else {
             S = wave_allreduce_dpp(S, OpAdd());
             v1 = wave_allreduce_dpp(v1, OpMax());
@@ -386,8 +391,10 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
                 }
                 long long cntw;
                 if constexpr (WG) {
-                    sumA = (T)all_sum((double)sumA);
-                    cntw = (long long)all_sum((double)cntl);
+                    double sd2 = (double)sumA, cd2 = (double)cntl;
+                    all_pair(sd2, cd2, false);
+                    sumA = (T)sd2;
+                    cntw = (long long)cd2;
                 } else {
                     sumA = wave_allreduce_dpp(sumA, OpAdd());
                     cntw = (long long)wave_allreduce_dpp((uint32_t)cntl, OpAdd());  // (a lane counts at most the column's strides: 32 bits)

@@ -94,6 +94,11 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 //  of two and one: the same 64 H slots, read by 16- and 8-byte loads per lane, nine instructions for a ten-step slice instead of
 //  thirty -- on the guess that the memory pipeline prefers wide accesses.  It does not here: same box, 100M all-simplex 1.675 / 1.749 ms
 //  step-major against 1.755 / 1.809 chunked, 10M unchanged (profiles/r04d_ab_chunked_slices_negative.txt).  The slice stays step-major.)
+// (Also measured there, same box, and not kept -- profiles/r04g_ab_isolation_after_issue.txt: the request for the next descriptor and the LDS
+//  read of the projection entry moved BEHIND the slice's own loads (they stand between a wavefront's slices, a round trip each, with
+//  nothing of its own in flight) together with the primal pointer's scalar load: +1.2 ... 1.5 % on all-simplex maps; the Newton loop's
+//  control carried as a wave-uniform ballot instead of a per-lane flag (five vector instructions per pass less) and the window tile's
+//  four slots as hand-written v_pk pairs: no measurable difference.)
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds

@@ -35,3 +35,7 @@ for k, name in enumerate(["start", "stamp1", "loop_done", "end"]):
     print(f"{name:10s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
 print("phase durations (mean / max): 0->1 %.1f / %.1f   1->2 %.1f / %.1f   2->3 %.1f / %.1f" % (
     (us[:, 1] - us[:, 0]).mean(), (us[:, 1] - us[:, 0]).max(), (us[:, 2] - us[:, 1]).mean(), (us[:, 2] - us[:, 1]).max(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
+end = us[:, 3]
+order = np.argsort(-end)
+print("percentiles of end: 50 %% %.1f  90 %% %.1f  99 %% %.1f  max %.1f" % tuple(np.percentile(end, [50, 90, 99, 100])))
+print("latest workgroups (index: stamp1 / loop_done / end):", "  ".join("%d: %.1f / %.1f / %.1f" % (w, us[w, 1], us[w, 2], us[w, 3]) for w in order[:12]))
