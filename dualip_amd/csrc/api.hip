@@ -175,6 +175,7 @@ static void matching_free(dl_matching* h) {
     if (h->cold_grad) (void)hipFree(h->cold_grad);
     if (h->bal) (void)hipFree(h->bal);
     if (h->bal_stamps) (void)hipFree(h->bal_stamps);
+    if (h->sell_bal) (void)hipFree(h->sell_bal);
     if (h->sell_lane_begin) (void)hipFree(h->sell_lane_begin);
     for (void* p : {(void*)h->sell_desc, (void*)h->sell_len, (void*)h->sell_colstart, h->sell_a, h->sell_c, h->sell_r, h->sell_f})
         if (p) (void)hipFree(p);
@@ -965,6 +966,40 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
                 CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
             }
             CKH(hipStreamSynchronize(st));  // (tab is a host temporary)
+            // ---- two-phase deal of the one-lane slices (fused4_kernel.h): handles whose WINDOWS do not adapt (too few rounds of them, or
+            //      none: all-simplex maps) but whose slices are many rounds per wavefront.  First binary only; DUALIP_HIP_SELL_BALANCE=0: off. ----
+            const char* se = getenv("DUALIP_HIP_SELL_BALANCE");
+            const int64_t n_plain = h->n_sell - h->n_sell_lane_slices;
+            const int64_t rs = S > 0 ? n_plain / S : 0;
+            const bool sell_adapt = !(se && se[0] == '0') && !(be && be[0] == '0') && !adapt && !h->lanes_binary && h->n_sell_lane_slices == 0 && h->n_wg >= 2 && h->n_wg <= 1024 &&
+                                    h->n_wg % 2 == 0 && n_plain < (1ll << 31);
+            // (DUALIP_HIP_SELL_BALANCE_PPM=<share>: tests -- a fixed second phase of that share for the even workgroups, never adapted, any size)
+            const char* fe = getenv("DUALIP_HIP_SELL_BALANCE_PPM");
+            const int64_t forced = fe ? atoll(fe) : -1;
+            // (same threshold as the windows' deal: at 38 rounds per wavefront -- 10M entities, all-simplex -- the second phase is two rounds of half
+            //  the launch, and its quantisation cost what the balance won: 0.1811 -> 0.1825 ms per launch, three alternations)
+            if (sell_adapt && (forced >= 0 || rs >= (int64_t)h->bal_min_rounds)) {
+                std::vector<int32_t> sb(4 + (size_t)h->n_wg, -1);
+                sb[0] = (int32_t)n_plain;  // everything in the first phase to start with
+                sb[1] = 0;
+                sb[2] = 0;
+                sb[3] = 0;
+                if (forced > 0) {
+                    const int64_t tail = n_plain * std::min<int64_t>(forced, 900000) / 1000000;
+                    sb[0] = (int32_t)(n_plain - tail);
+                    sb[1] = (h->n_wg / 2) * kFusedWaves;
+                    sb[2] = (int32_t)std::min<int64_t>(forced, 900000);
+                    for (int w = 0; w < h->n_wg; w += 2) sb[4 + (size_t)w] = w / 2;
+                }
+                h->sell_bal_frozen = forced >= 0;
+                CK(owned_malloc(h, (void**)&h->sell_bal, sizeof(int32_t) * sb.size()));
+                CKH(hipMemcpyAsync(h->sell_bal, sb.data(), sizeof(int32_t) * sb.size(), hipMemcpyHostToDevice, st));
+                if (!h->bal_stamps) {
+                    CK(owned_malloc(h, (void**)&h->bal_stamps, sizeof(unsigned long long) * 4 * (size_t)h->n_wg));
+                    CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
+                }
+                CKH(hipStreamSynchronize(st));
+            }
         }
     }
 #undef CK
@@ -1004,6 +1039,13 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 2001: return h->owns_inputs ? 1 : 0;
         case 2002: return h->owns_inputs ? h->own_count : h->unsliced_end;  // non-zeros read in place from the (caller's / owned) CSC-ordered arrays
         case 2000: return h->n_sell_lane_cols;
+        case 2005:    // share of the one-lane slices in the second phase of their deal, ppm (synchronous read; -1: even deal only)
+        case 2006: {  // updates of that deal so far
+            if (!h->sell_bal) return -1;
+            int32_t v[4] = {0, 0, 0, 0};
+            if (hipMemcpy(v, h->sell_bal, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            return what == 2005 ? v[2] : v[3];
+        }
         default:
             if (what >= 18 && what < 18 + 1024) {  // rounds of workgroup (what - 18) in the window tiles' deal (synchronous read; -1: no table)
                 if (!h->bal_stamps || what - 18 >= h->n_wg) return -1;

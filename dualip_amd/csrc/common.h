@@ -94,6 +94,9 @@ struct dl_matching {
     // from per-workgroup stamps; null = every workgroup takes the same number of rounds
     int32_t* bal = nullptr;                  // owned, device, bal_table_words(n_wg) ints
     unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, wavefront 0's windows done, all done
+    int32_t* sell_bal = nullptr;             // owned, device, 4 + n_wg ints: the two-phase deal of the one-lane slices (fused4_kernel.h / matching_kernels.hip:
+                                             // sell_balance_kernel) -- { slices dealt to everybody, wavefronts of the second phase, share in ppm, updates ; rank[n_wg] }
+    bool sell_bal_frozen = false;            // (DUALIP_HIP_SELL_BALANCE_PPM: a fixed table, for tests)
     double bal_gain = 0.3;                   // (DUALIP_HIP_BALANCE_GAIN)
     int bal_launches = 0;                    // launches of the handle so far
     int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)

@@ -422,7 +422,39 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     }
     {
         // (second binary: its handles may have few one-lane slices -- one per workgroup before any workgroup gets a second)
-        sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, LANES ? (uint32_t)wave * (uint32_t)gridDim.x + (uint32_t)wg : (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave, S, lane, sd, acc, fair);
+        // Two-phase deal (first binary): slices [0, n1) go to every wavefront of the launch as before; the rest -- a few per cent, the
+        // table's tail -- only to the workgroups that have been finishing EARLY (rank rk among them, s2 wavefronts in all).  The XCDs
+        // of this part do not stream at the same speed (all-simplex 100M, even deal: odd XCDs finish 5 % after even ones, the launch
+        // ends 4 % after its workgroups' mean); window tiles have their weighted deal for that (Deal), the slices had nothing -- and a
+        // weighted deal INSIDE their loop had cost more scalar state than it won (section 3.1).  Here the loop is the same loop, run
+        // twice with other bounds; sell_balance_kernel (matching_kernels.hip) moves n1 and the membership from the launches' stamps.
+        const uint32_t n_sell_all = g.n_sell;
+        uint32_t n1 = n_sell_all, s2 = 0u;
+        int32_t rk = -1;
+        if constexpr (!LANES) {
+            const int32_t* sb = kernarg_args(g).sell_bal;
+            if (sb) {
+                n1 = (uint32_t)__builtin_amdgcn_readfirstlane(sb[0]);
+                s2 = (uint32_t)__builtin_amdgcn_readfirstlane(sb[1]);
+                rk = __builtin_amdgcn_readfirstlane(sb[4 + wg]);
+                n1 = n1 < n_sell_all ? n1 : n_sell_all;
+            }
+        }
+#pragma nounroll
+        for (int ph = 0; ph < 2; ++ph) {  // (ONE copy of the walker: see above)
+            uint32_t q0, Sp, end;
+            if (ph == 0) {
+                q0 = LANES ? (uint32_t)wave * (uint32_t)gridDim.x + (uint32_t)wg : (uint32_t)wg * (uint32_t)kFusedWaves + (uint32_t)wave;
+                Sp = S;
+                end = n1;
+            } else {
+                if (rk < 0 || s2 == 0u || n1 >= n_sell_all) break;
+                q0 = n1 + (uint32_t)rk * (uint32_t)kFusedWaves + (uint32_t)wave;
+                Sp = s2;
+                end = n_sell_all;
+            }
+            sell_loop<T, RowT, LAM_LDS, HOT, FAIR>(g, w, q0, Sp, end, lane, sd, acc, fair);
+        }
     }
     if (sell_first) {
         open_windows();

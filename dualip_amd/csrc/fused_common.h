@@ -39,6 +39,7 @@ struct FusedArgs {
     const uint32_t* __restrict__ long32;  // layout 4: the single-column tiles' descriptors (12 dwords each)
     const int32_t* balance;               // layout 4: the window tiles' weighted deal (Deal: rounds per workgroup + tables), or null (same for all)
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
+    const int32_t* sell_bal;              // layout 4, first binary: two-phase deal of the one-lane slices (common.h), or null (one even deal)
     int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) have their GRADIENT accumulator in LDS; 0 = every row does

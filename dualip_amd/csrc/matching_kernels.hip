@@ -580,6 +580,76 @@ __global__ __launch_bounds__(1024) void wg_balance_kernel(int32_t* __restrict__ 
     }
 }
 
+// Two-phase deal of the one-lane slices (fused4_kernel.h): tab = { n1, wavefronts of phase 2, share in ppm, updates ; rank[n_wg] }.
+// st as above (stamp 0: prologue done, stamp 2: all done).  With the share phi of the slices in the second phase and half of the
+// workgroups its members, workgroup w's part of the work is (1 - phi) / n [+ phi / (n / 2)]; its SLOWNESS s_w = time / work.  The new
+// members are the half with the smallest slowness, and the share that would make both halves finish together is
+// phi* = (s_slow - s_fast) / (s_slow + s_fast) (means of the halves): phi moves half of the way there.  At the fixed point both halves
+// finish together whatever a slice of the tail costs relative to the rest (the tail holds the tallest slices).  One workgroup.
+__global__ __launch_bounds__(1024) void sell_balance_kernel(int32_t* __restrict__ tab, const unsigned long long* __restrict__ st, int n_wg, uint32_t n_sell, double gain) {
+    __shared__ double red[16];
+    __shared__ double slow_s[1024];
+    const int w = threadIdx.x, lane = w & 63, wave = w >> 6;
+    const bool live = w < n_wg;
+    auto block_sum = [&](double x) -> double {
+        x = wave_allreduce(x, OpAdd());
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += red[q];
+        return t;
+    };
+    const uint32_t n1_old = (uint32_t)tab[0];
+    const int members_old = tab[1] / kFusedWaves;
+    const double phi_old = (members_old > 0 && n1_old < n_sell) ? (double)(n_sell - n1_old) / (double)n_sell : 0.0;
+    double d = 0.0;
+    bool ok = true, member = false;
+    if (live) {
+        const unsigned long long a = st[4 * (size_t)w], c = st[4 * (size_t)w + 2];
+        ok = c > a;
+        d = ok ? (double)(c - a) : 0.0;
+        member = tab[4 + w] >= 0;
+    }
+    if (block_sum(ok ? 0.0 : 1.0) > 0.0) return;  // (no stamps from this launch: keep the deal)
+    const int half = n_wg / 2;
+    const double work = (1.0 - phi_old) / (double)n_wg + ((member && phi_old > 0.0) ? phi_old / (double)half : 0.0);
+    const double slow = live ? d / work : 1e300;
+    slow_s[w] = slow;
+    __syncthreads();
+    // The members are chosen ONCE, from the first stamped launch (an even deal: every workgroup did the same work, so the times rank the
+    // workgroups themselves -- in effect the XCDs, whose skew is persistent); afterwards only the share moves.  Re-ranking at every update
+    // was measured to flip-flop: the tail holds the tallest slices, so by the count model above a member looks slower than it is, loses
+    // its membership to a workgroup of the slow half, and the launch ends 10 % late (profiles/r04m_*).
+    const bool first = tab[3] == 0 || members_old == 0;
+    int smaller = 0;
+    if (live && first)
+        for (int q = 0; q < n_wg; ++q) smaller += (slow_s[q] < slow || (slow_s[q] == slow && q < w)) ? 1 : 0;
+    const bool fast = live && (first ? smaller < half : member);  // (ranked by workgroup index below)
+    const double s_fast = block_sum(fast ? slow : 0.0) / (double)half, s_slow = block_sum((live && !fast) ? slow : 0.0) / (double)(n_wg - half);
+    if (!(s_fast > 0.0) || !(s_slow > 0.0)) return;
+    double target = (s_slow - s_fast) / (s_slow + s_fast);
+    target = target < 0.0 ? 0.0 : target;
+    double phi = phi_old + gain * (target - phi_old);
+    phi = phi < 0.0 ? 0.0 : (phi > 0.2 ? 0.2 : phi);
+    if (phi < 0.002) phi = 0.0;  // (not worth a second phase)
+    // rank among the members, by workgroup index
+    __shared__ int cnt_wave[16];
+    const unsigned long long bal = __ballot(fast);
+    if (lane == 0) cnt_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    for (int q = 0; q < wave; ++q) before += cnt_wave[q];
+    if (live) tab[4 + w] = fast ? before + __popcll(bal & ((1ull << lane) - 1ull)) : -1;  // (kept while the share is 0: the kernel tests n1)
+    if (w == 0) {
+        const uint32_t tail = (uint32_t)(phi * (double)n_sell);
+        tab[0] = (int32_t)(n_sell - tail);
+        tab[1] = half * kFusedWaves;
+        tab[2] = (int32_t)(phi * 1e6);
+        tab[3] += 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restrict__ partial_fair, int n_wg, double* __restrict__ dense_ax) {
     __shared__ double sh[4];
     double v = 0.0;
@@ -663,6 +733,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.sell_f = static_cast<const T*>(h->sell_f);
     args.n_sell = (uint32_t)(h->n_sell - h->n_sell_lane_slices);
     args.balance = h->bal;
+    args.sell_bal = h->sell_bal;
     // (the first launches of a handle adapt every time, later ones every kBalEvery-th: the balance point moves during a solve -- the
     //  slices get slower as the Newton passes multiply, the windows do not)
     // (not with the fairness stream: its sum f.x is a per-workgroup double, so an adapting deal would put the measured timings into the
@@ -710,6 +781,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
         hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
         DL_HIP(hipGetLastError());
+        if (h->sell_bal && !h->sell_bal_frozen) {  // (handles whose windows do not adapt: the slices' two-phase deal does)
+            hipLaunchKernelGGL(sell_balance_kernel, dim3(1), dim3(1024), 0, st, h->sell_bal, h->bal_stamps, h->n_wg, (uint32_t)(h->n_sell - h->n_sell_lane_slices), 0.5);
+            DL_HIP(hipGetLastError());
+        }
     }
     if (h->bal_stamps) h->bal_launches += 1;
     if (h->fair) {

@@ -99,6 +99,10 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 //  nothing of its own in flight) together with the primal pointer's scalar load: +1.2 ... 1.5 % on all-simplex maps; the Newton loop's
 //  control carried as a wave-uniform ballot instead of a per-lane flag (five vector instructions per pass less) and the window tile's
 //  four slots as hand-written v_pk pairs: no measurable difference.)
+// (And packed arithmetic -- a * lambda', s * c, their sum, u - theta and a * x for two steps per v_pk_mul_f32 / v_pk_add_f32, register
+//  pairs allocated without a single extra move: 4.3 % fewer vector instructions in the slice loop, NO difference in time on any shape,
+//  three alternations, profiles/r04i_ab_packed_slice_arithmetic_neutral.txt.  After the scalar clean-up above the slices are no longer
+//  bound by their vector instruction count.)
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds
@@ -381,8 +385,8 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
 // into this loop, measured +2.5 ... 4.6 % on all-simplex maps whatever its table -- more scalar state across fourteen variants --
 // and the slices' own imbalance is small); the next descriptor travels while the current slice is processed.
 template <class T, class RowT, bool LAM_LDS, bool HOT, bool FAIR>
-__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, int lane, T sd, FxAcc& acc, double& fair) {
-    const uint32_t n_sell = g.n_sell;
+__device__ __forceinline__ void sell_loop(const FusedArgs<T>& g, const WgCtx<T>& w, uint32_t q0, uint32_t S, uint32_t n_sell, int lane, T sd, FxAcc& acc, double& fair) {
+    // (n_sell: the end of the range this deal covers -- the table's length, or the end of the first phase of a two-phase deal)
     if (q0 >= n_sell) return;
     const uint32_t dlane = (uint32_t)lane < (uint32_t)kSellDescWords ? (uint32_t)lane : (uint32_t)kSellDescWords - 1u;
     auto load_desc = [&](uint32_t q) -> uint32_t {

@@ -274,6 +274,8 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         info = {k: int(self._lib.dl_matching_info(self._handle, i)) for i, k in enumerate(names)}
         info["lambda_rows_in_lds"] = int(self._lib.dl_matching_info(self._handle, 2003))  # hot-rows plan: >= hot_rows; = m when the whole dual vector is staged
         info["second_binary"] = int(self._lib.dl_matching_info(self._handle, 2004))  # launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal)
+        info["slice_balance_ppm"] = int(self._lib.dl_matching_info(self._handle, 2005))  # share of the one-lane slices dealt only to the early-finishing half of the workgroups (-1: even deal)
+        info["slice_balance_updates"] = int(self._lib.dl_matching_info(self._handle, 2006))
         info["slice_lane_columns"] = int(self._lib.dl_matching_info(self._handle, 2000))  # columns dealt to K = 2 .. 32 lanes each (25 .. 512 non-zeros; a handle's few short columns join them)
         return info
 

@@ -128,7 +128,9 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
  *      FEW short columns, which join the two-lane class,
  * 2001 the handle owns its inputs (dl_matching_own_inputs), 2002 elements of the caller-ordered arrays read in place (owned: kept),
  * 2003 rows whose DUAL entry the hot-rows plan stages in LDS (>= what 9 reports; = m when the whole dual vector fits: no tile gathers
- *      from L2), 2004 launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal inside a workgroup). */
+ *      from L2), 2004 launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal inside a workgroup),
+ * 2005 share (ppm) of the one-lane slices that only the early-finishing half of the workgroups walks (two-phase deal of handles whose
+ *      window tiles do not adapt, e.g. all-simplex maps; -1: even deal; synchronous device read), 2006 updates of that share so far. */
 int64_t dl_matching_info(const dl_matching* h, int what);
 
 /* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays

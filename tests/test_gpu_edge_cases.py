@@ -524,6 +524,63 @@ def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
     print("tables seen", len(tables))
 
 
+def test_two_phase_deal_of_the_slices_keeps_every_slice(monkeypatch):
+    """The one-lane slices of a handle whose window tiles do not adapt (an all-simplex map) are dealt in two phases (csrc/fused4_kernel.h):
+    everything up to n1 to every wavefront, the table's tail only to the workgroups that have been finishing early (csrc/matching_kernels.hip:
+    sell_balance_kernel moves the cut and the membership from the launches' stamps).  Whatever the table, every slice keeps exactly one
+    slot: gradient (integer fixed point), primal and -- the slices add one rounded integer per lane -- the objective are bit-identical to a
+    handle with the even deal.  Fixed shares (the test switch) of 0.1 %, 5 %, 33 % and 90 %, then the adapting table at a lowered threshold."""
+    import os
+
+    from benchmark.synthetic import generate_matching_problem
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SELL") == "0":
+        pytest.skip("no column-per-lane slices under this switch")
+    n, m = 1_500_000, 2_000
+    prob = generate_matching_problem(n, m, 5e-3, seed=9, device=torch.device(DEV), dtype=torch.float32)
+    inp = prob["input_args"]
+    inp.projection_map = create_projection_map("simplex", {"z": 1.0}, n, indices=range(n))
+    lam = torch.rand(m, device=DEV) * 0.01
+    monkeypatch.setenv("DUALIP_HIP_SELL_BALANCE", "0")
+    even = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    assert even.info()["slice_balance_ppm"] == -1
+    want = even.calculate(lam, save_primal=True)
+    wg, wx, wo = want.dual_gradient.clone(), want.primal_var.clone(), float(want.dual_objective)
+    monkeypatch.delenv("DUALIP_HIP_SELL_BALANCE")
+    for ppm in (1000, 50_000, 330_000, 900_000):
+        monkeypatch.setenv("DUALIP_HIP_SELL_BALANCE_PPM", str(ppm))
+        f = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+        info = f.info()
+        if info["second_binary"]:
+            pytest.skip("this handle takes the second binary (its own dynamic deal)")
+        assert info["slice_balance_ppm"] == ppm
+        for it in range(3):
+            got = f.calculate(lam, save_primal=(it == 0))
+            assert torch.equal(got.dual_gradient, wg), ppm
+            if it == 0:
+                assert torch.equal(got.primal_var, wx), ppm
+            assert float(got.dual_objective) == wo, ppm
+        assert f.info()["slice_balance_updates"] == 0  # (a fixed table is never adapted)
+    monkeypatch.delenv("DUALIP_HIP_SELL_BALANCE_PPM")
+    monkeypatch.setenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS", "4")
+    f = MatchingSolverDualObjectiveFunction(inp, 1e-2)
+    assert f.info()["slice_balance_ppm"] == 0
+    shares = set()
+    for it in range(12):  # the first 8 launches adapt
+        got = f.calculate(lam, save_primal=(it % 4 == 0))
+        assert torch.equal(got.dual_gradient, wg)
+        if it % 4 == 0:
+            assert torch.equal(got.primal_var, wx)
+        assert float(got.dual_objective) == wo
+        i2 = f.info()
+        assert 0 <= i2["slice_balance_ppm"] <= 200_000
+        shares.add(i2["slice_balance_ppm"])
+    assert f.info()["slice_balance_updates"] >= 8
+    print("shares seen (ppm)", sorted(shares))
+
+
 def test_non_finite_values_are_refused_and_rescaled_costs_keep_the_objective_exact():
     """The gradient, c.x and sum x^2 are exact fixed-point sums whose grids come from max |a|, max |c| (fused_common.h).  A value array
     with an inf or NaN has no such grid: the handle refuses it (the reference would return NaN) instead of logging integer garbage.
