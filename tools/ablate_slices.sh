@@ -1,3 +1,10 @@
+#!/bin/bash
+# developer aid: timing ablations of the ONE-lane slices on the 100M all-simplex map (results wrong on purpose).  The committed kernel honours
+# the DUALIP_HIP_ABLATE bits 14 .. 17 only in the K-lane / in-place slices of the second binary; this script expects a scratch tree _ab/abl
+# (tools/ab.sh snapshot HEAD abl, then in its csrc/sell.h: `constexpr bool DEVAB = true;`, after `if (... (1 << 16))) act = false;` a line
+# `if (ab & (1 << 18)) { act = false; theta = 0; vertex = false; }`, `lam = (ab & (1 << 19)) ? 0.5f + r[t] : lam_of(r[t])` in pass 1, and
+# after the two group reductions `if (ab & (1 << 20)) { fx_add(acc, sall, mx, w.scale2); return; }`; rebuild it) -- what profiles/r04j_*, r04l_* ran.
+#   bits: 15 no scatter, 16 no Newton passes, 18 no projection, 19 no lambda gather, 20 nothing after pass 1.   ABLATES="0 65536 ..." overrides the list.
 export TMPDIR=/tmp
 cd _ab/abl
 line() { python -c "
