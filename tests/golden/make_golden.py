@@ -365,7 +365,7 @@ def make_g3(name, p, seed):
     keys = []
     gamma, iters, s0, s1 = 0.02, 40, 1e-3, 1e-1
     out["params"] = np.array([gamma, iters, s0, s1])
-    for world in (2, 4):
+    for world in (2, 4, 8):  # 8 = the target machine's world size (benchmark/run_matching_benchmark_dist.py:33-193)
         for dn in DT:
             r = run_dist(p, dn, even_shards(n, world, "simplex", {"z": 1.0}), gamma, iters, s0, s1, lam_single=lam)
             key = f"simplex1|w{world}|{dn}"
@@ -383,6 +383,16 @@ def make_g3(name, p, seed):
         ]
         r = run_dist(p, dn, shards, gamma, iters, s0, s1, lam_single=lam)
         key = f"mixed|w2|{dn}"
+        keys.append(key)
+        for kk, vv in r.items():
+            out[f"{key}|{kk}"] = vv
+    # the same mixed map on 8 ranks: four ranks share the box half, four the simplex half (every rank still single-key)
+    for dn in DT:
+        shards = []
+        for lo0, hi0, pt, pp in ((0, half, "box", {"lower": 0.0, "upper": 1.0}), (half, n, "simplex", {"z": 1.0})):
+            shards += [(lo0 + lo, lo0 + hi, pm) for lo, hi, pm in even_shards(hi0 - lo0, 4, pt, pp)]
+        r = run_dist(p, dn, shards, gamma, iters, s0, s1, lam_single=lam)
+        key = f"mixed|w8|{dn}"
         keys.append(key)
         for kk, vv in r.items():
             out[f"{key}|{kk}"] = vv
@@ -458,6 +468,9 @@ def make_g7(seed):
 def main():
     torch.manual_seed(0)
     syn = problem_synthetic(2000, 50, 0.1, 42)
+    if "--only-g3" in sys.argv:  # (every fixture is a pure function of its seeds: regenerating one leaves the others as they are)
+        make_g3("syn2000", syn, seed=10)
+        return
     print("syn2000 nnz", syn["rowidx"].shape[0], "max col nnz", np.diff(syn["colptr"]).max(), "empty", (np.diff(syn["colptr"]) == 0).sum())
     make_g1("syn2000", syn, gammas=[1e-3, 0.02, 0.1], maps=list(SINGLE_MAPS), seed=7)
     longp = problem_synthetic(150, 400, 0.35, 43)

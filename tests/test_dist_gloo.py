@@ -146,3 +146,19 @@ def test_mixed_map_split_over_two_ranks():
     assert relerr(out["single_grad"], z[f"{key}|single_grad"]) < 1e-9
     assert relerr(out["dual_obj_log"], z[f"{key}|dual_obj_log"]) < 1e-8
     assert relerr(out["dual_val"], z[f"{key}|dual_val"]) < 1e-7
+
+
+def test_eight_ranks_match_reference_distributed_trace():
+    """World 8 = the target node (benchmark/run_matching_benchmark_dist.py:33-193): the reference's own 8-rank gloo trace; the
+    contiguous n // W (+1) cut, the re-based maps and the one sum-all-reduce with eight contributions."""
+    from tests.helpers import load, relerr
+
+    z = load("g3_syn2000.npz")
+    out = _run({"kind": "simplex", "dtype": "f64"}, world=8)
+    key = "simplex1|w8|f64"
+    assert relerr(out["single_grad"], z[f"{key}|single_grad"]) < 1e-9
+    assert relerr(out["single_scal"][[0, 1, 3, 4, 5]], z[f"{key}|single_scal"][[0, 1, 3, 4, 5]]) < 1e-9
+    assert relerr(out["dual_obj_log"], z[f"{key}|dual_obj_log"]) < 1e-8
+    assert np.allclose(out["step_log"], z[f"{key}|step_log"], rtol=1e-6)
+    assert relerr(out["dual_val"], z[f"{key}|dual_val"]) < 1e-7
+    assert len(out["all_dual_vals"]) == 8 and all(np.array_equal(out["all_dual_vals"][0], v) for v in out["all_dual_vals"][1:])

@@ -3,9 +3,9 @@
 One-GPU box: several processes share cuda:0.  RCCL refuses that, the P2P back-end (hipIpc-mapped fine-grained mailboxes)
 does not -- every word of its protocol runs: remote-process stores into a mailbox, system-scope release, flags, local
 polling, acquire, rank-ordered sums.  Checked here:
-  * stand-alone all-reduce, 2 and 4 processes, exact sums over many rounds with UNEVEN load between the ranks (a rank that
+  * stand-alone all-reduce, 2, 4 and 8 processes (8 = the target node), exact sums over many rounds with UNEVEN load between the ranks (a rank that
     arrives early must wait; a rank two exchanges ahead must not overwrite a slot still being read);
-  * the C loop against the reference's 2- and 4-rank golden traces (g3_syn2000.npz), ranks bit-identical;
+  * the C loop against the reference's 2-, 4- and 8-rank golden traces (g3_syn2000.npz), ranks bit-identical;
   * the C loop with one rank (P2P and RCCL back-ends, split shard) bit-identical to the single-device loop.
 """
 import os
@@ -66,10 +66,13 @@ def _allreduce_worker(rank, world, port, q, backend="p2p", expect=None, fail="")
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend,expect,fail", [(2, "p2p", "p2p", ""), (4, "p2p", "p2p", ""), (2, "p2p-fenced", "p2p-fenced", ""), (2, "auto", "p2p-fenced", "p2p")])
+@pytest.mark.parametrize("world,backend,expect,fail", [(2, "p2p", "p2p", ""), (4, "p2p", "p2p", ""), (8, "p2p", "p2p", ""), (8, "p2p-fenced", "p2p-fenced", ""),
+                                                        (2, "p2p-fenced", "p2p-fenced", ""), (2, "auto", "p2p-fenced", "p2p")])
 def test_p2p_allreduce_is_exact_under_uneven_load(world, backend, expect, fail):
     """Both orderings of the exchange (comm.h): the default one and the fenced, by-the-book one; and the creation-time
-    fallback auto -> p2p (soak test made to fail by the test hook) -> p2p-fenced, after which the exchange must be exact."""
+    fallback auto -> p2p (soak test made to fail by the test hook) -> p2p-fenced, after which the exchange must be exact.
+    World 8 is the target machine's (benchmark/run_matching_benchmark_dist.py:33-193): mail_sum's batch of eight loads in
+    flight is only full there, and the mailbox holds eight slots per parity."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
@@ -78,7 +81,7 @@ def test_p2p_allreduce_is_exact_under_uneven_load(world, backend, expect, fail):
         p.start()
     got = [q.get() for _ in procs]
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=300)
         assert p.exitcode == 0
     for rank, bad, exchanges in got:
         assert bad == 0, f"rank {rank}: {bad} wrong words"
@@ -150,7 +153,7 @@ def _loop_worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4), ("simplex-nocomm", 2), ("simplex-emptyrank", 2)])
+@pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4), ("simplex", 8), ("mixed", 8), ("simplex-nocomm", 2), ("simplex-emptyrank", 2)])
 def test_sharded_c_loop_matches_reference_goldens(kind, world):
     from tests.helpers import load, relerr
 
@@ -168,7 +171,7 @@ def test_sharded_c_loop_matches_reference_goldens(kind, world):
         p.join(timeout=180)
         assert p.exitcode == 0
     z = load("g3_syn2000.npz")
-    key = f"simplex1|w{world}|f64" if kind.startswith("simplex") else "mixed|w2|f64"
+    key = f"simplex1|w{world}|f64" if kind.startswith("simplex") else f"mixed|w{world}|f64"
     want_log, want_dual = z[f"{key}|dual_obj_log"], z[f"{key}|dual_val"]
     for r in range(world):
         assert out[r][2] == ("torch.distributed" if kind.endswith("-nocomm") else "p2p") and out[r][3] >= len(want_log)
@@ -274,7 +277,7 @@ def test_step_applied_in_the_next_launch_prologue_is_bit_identical(dn):
 # the fenced ordering and repeats the solve.  Fault injection: dl_comm_inject_fault damages one rank's contribution to one
 # exchange as it is stored into one other rank's mailbox (a flipped bit / dropped data stores = a stale slot behind a raised flag).
 # ---------------------------------------------------------------------------------------------------------
-def _fault_allreduce_worker(rank, world, port, q):
+def _fault_allreduce_worker(rank, world, port, q, flipper=1, flip_victim=0, staler=0, stale_victim=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -303,9 +306,9 @@ def _fault_allreduce_worker(rank, world, port, q):
 
         assert rounds(10) == 0
         comm.meet()  # healthy: passes on every rank
-        # 1. rank 1 stores one element with a flipped bit into rank 0's mailbox: rank 0 must notice, BOTH ranks must raise
-        if rank == 1:
-            comm.inject_fault(1, 0)
+        # 1. rank `flipper` stores one element with a flipped bit into rank `flip_victim`'s mailbox: the victim must notice, EVERY rank must raise
+        if rank == flipper:
+            comm.inject_fault(1, flip_victim)
         bad = rounds(1)
         events.append(("flip", bad, comm.status()))
         try:
@@ -317,9 +320,9 @@ def _fault_allreduce_worker(rank, world, port, q):
         events.append(("degrade", comm.degrade(), comm.backend, comm.info()["degraded"] is not None))
         events.append(("after", rounds(10), comm.status()))
         comm.meet()
-        # 3. rank 0 raises its flag in rank 1's mailbox WITHOUT the data (a stale slot): rank 1 must notice; no level left to move to
-        if rank == 0:
-            comm.inject_fault(2, 1)
+        # 3. rank `staler` raises its flag in rank `stale_victim`'s mailbox WITHOUT the data (a stale slot): the victim must notice; no level left to move to
+        if rank == staler:
+            comm.inject_fault(2, stale_victim)
         rounds(1)
         try:
             comm.meet()
@@ -334,25 +337,32 @@ def _fault_allreduce_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops():
+@pytest.mark.parametrize("world,flipper,flip_victim,staler,stale_victim", [(2, 1, 0, 0, 1), (8, 7, 0, 3, 7)])
+def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops(world, flipper, flip_victim, staler, stale_victim):
+    """World 8: the damaged slot is the LAST one of a mailbox (rank 7's contribution, then rank 7's own mailbox) -- the end of the
+    batch of eight loads of comm.h:mail_sum and of the flag line array."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_fault_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_fault_allreduce_worker, args=(r, world, port, q, flipper, flip_victim, staler, stale_victim)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict((r, (ev, c)) for r, ev, c in [q.get() for _ in procs])
     for p in procs:
-        p.join(timeout=180)
+        p.join(timeout=300)
         assert p.exitcode == 0
     CHK = got[0][1]
-    ev0, ev1 = dict((e[0], e[1:]) for e in got[0][0]), dict((e[0], e[1:]) for e in got[1][0])
-    assert ev0["flip"][0] > 0 and ev0["flip"][1] == CHK, ev0   # rank 0 read the damaged element AND its reader noticed
-    assert ev1["flip"] == (0, 0), ev1                           # rank 1's own mailbox was fine
-    assert ev0["meet"] == ([CHK, 0],) and ev1["meet"] == ([CHK, 0],)  # ... yet both ranks stop, with the same picture
-    for ev in (ev0, ev1):
+    evs = [dict((e[0], e[1:]) for e in got[r][0]) for r in range(world)]
+    codes1 = [CHK if r == flip_victim else 0 for r in range(world)]
+    codes2 = [CHK if r == stale_victim else 0 for r in range(world)]
+    for r, ev in enumerate(evs):
+        if r == flip_victim:
+            assert ev["flip"][0] > 0 and ev["flip"][1] == CHK, ev   # the victim read the damaged element AND its reader noticed
+        else:
+            assert ev["flip"] == (0, 0), ev                          # every other rank's own mailbox was fine
+        assert ev["meet"] == (codes1,), ev                           # ... yet all ranks stop, with the same picture
         assert ev["degrade"] == (True, "p2p-fenced", True) and ev["after"] == (0, 0), ev
-        assert ev["meet2"] == ([0, CHK],) and ev["degrade2"] == (False,), ev
+        assert ev["meet2"] == (codes2,) and ev["degrade2"] == (False,), ev
 
 
 def _fault_loop_worker(rank, world, port, fuse, q):

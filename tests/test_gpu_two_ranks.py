@@ -264,3 +264,30 @@ def test_bench_spawns_its_own_ranks():
         if partition == "contiguous":  # mixed map, cost-weighted cuts: rank 0's range ends past the count-balanced middle... of the box half
             cuts = d["aux"]["partition"]["cuts"]
             assert cuts[0] == 0 and cuts[-1] == 2000000 and 1000000 < cuts[1] < 1100000, cuts
+
+
+def test_bench_harness_with_eight_ranks_on_one_gpu():
+    """The target machine's world size (benchmark/run_matching_benchmark_dist.py:33-193: eight ranks) through the whole harness before
+    an 8-GPU node ever runs it: ``bench.py --gpus 8`` spawning its own ranks, all on cuda:0 (developer mode; the number means
+    nothing).  The exchange must have passed its soak self-test with EIGHT slots per mailbox, agreed with torch.distributed,
+    the line must carry both partitions' records, and every rank's duals must be bit-identical (``verified.ok_all_ranks``)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DUALIP_BENCH_ONE_DEVICE="1", DUALIP_COMM_SOAK_ROUNDS="200")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--entities", "800000", "--steps", "4", "--warmup", "2", "--no-late"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "column-shard x8" and d["config"]["entities"] == 800000
+    coll = d["aux"]["collective"]
+    assert coll["backend"] in ("p2p", "p2p-fenced") and coll["selftest"]["ok"] is True, coll
+    part = d["aux"]["partition"]
+    assert part["kind"] == "balanced" and part["ranks"] == 8, part
+    cmp_ = part["compared"]  # the library default n // W (+1) (dist_utils.py:53-57) measured beside the benchmark's split
+    assert cmp_["kind"] == "reference" and "error" not in cmp_ and cmp_["ms_per_step"] > 0, cmp_
+    assert d["aux"]["verified"]["ok_all_ranks"] is True, d["aux"]["verified"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1000.0) < 1e-3

@@ -134,11 +134,12 @@ def test_mixed_map_matches_key_boundary_split():
     projs = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})]
     for dn, dt in NP_DT.items():
         grad, x, scal = _calc(p, projs, z["lam"], 0.02, dt, col_proj=col_proj)
-        key = f"mixed|w2|{dn}"
-        assert relerr(grad, z[f"{key}|single_grad"]) < RTOL[dn]
-        assert relerr(x, z[f"{key}|single_x"]) < RTOL[dn]
-        want = z[f"{key}|single_scal"]
-        assert relerr(scal[[0, 1, 3, 4, 5]], want[[0, 1, 3, 4, 5]]) < RTOL[dn]
+        for world in (2, 8):  # (the reference's 2-rank run split at the key boundary, and its 8-rank run: 4 + 4 ranks)
+            key = f"mixed|w{world}|{dn}"
+            assert relerr(grad, z[f"{key}|single_grad"]) < RTOL[dn]
+            assert relerr(x, z[f"{key}|single_x"]) < RTOL[dn]
+            want = z[f"{key}|single_scal"]
+            assert relerr(scal[[0, 1, 3, 4, 5]], want[[0, 1, 3, 4, 5]]) < RTOL[dn]
 
 
 def test_movielens_like_trace_f64():
