@@ -51,7 +51,7 @@ def source_hash() -> str:
 
 
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(os.path.join(LIB_DIR, "build_manifest.json")):  # (the record of the screens is part of a build)
         return True
     try:
         with open(HASH_PATH) as fh:
@@ -108,6 +108,7 @@ def _spill_defects(asm_path: str):
     return out
 
 
+_META_FIELD = __import__("re").compile(r"^  (- |  )(\.[A-Za-z_]+):\s*(.*)$")  # a kernel-level field of .amdgpu_metadata ("  - .x: v" opens an item)
 _SREG = __import__("re").compile(r"^s(\d+)$|^s\[(\d+):(\d+)\]$")
 # instructions whose FIRST operand is a scalar destination (everything s_* that writes, plus the lane reads)
 _NO_SDST = ("s_waitcnt", "s_nop", "s_branch", "s_cbranch", "s_barrier", "s_endpgm", "s_sleep", "s_setprio", "s_cmp", "s_bitcmp", "s_setreg", "s_sendmsg",
@@ -236,16 +237,37 @@ def _kernel_resources(asm_path: str):
     a, b = text.find(".amdgpu_metadata"), text.find(".end_amdgpu_metadata")
     if a < 0 or b < 0:
         return {}
-    import yaml
-
+    # The few integer fields wanted here are read line by line: the block is YAML, but PyYAML is not a dependency of this package, and
+    # the layout -- one "  - " item per kernel under amdhsa.kernels with its scalar fields four columns in and the nested argument
+    # lists deeper -- is what the AMDGPU backend prints for every code-object version hipcc emits.
     body = text[text.index("\n", a) + 1:b]
-    end = body.rfind("\n...")  # (the YAML document's end marker; what follows is the assembler directive's own indentation)
-    meta = yaml.safe_load(body[:end] if end >= 0 else body) or {}
+    k0 = body.find("amdhsa.kernels:")
+    if k0 < 0:
+        return {}
+    items, cur = [], None
+    for line in body[k0:].split("\n")[1:]:
+        if line and not line.startswith(" "):  # the next top-level key (amdhsa.target, amdhsa.version) or the document's end marker
+            break
+        m = _META_FIELD.match(line)
+        if not m:
+            continue
+        if m.group(1) == "- ":
+            cur = {}
+            items.append(cur)
+        if cur is not None:
+            cur[m.group(2)] = m.group(3).strip().strip("'\"")
+
+    def num(k, key, default=None):
+        try:
+            return int(k[key])
+        except (KeyError, ValueError):
+            return default
+
     out = {}
-    for k in meta.get("amdhsa.kernels", []):
-        out[k.get(".name", "?")] = {"vgpr_count": k.get(".vgpr_count"), "agpr_count": k.get(".agpr_count"), "sgpr_count": k.get(".sgpr_count"),
-                                    "vgpr_spill_count": k.get(".vgpr_spill_count", 0), "sgpr_spill_count": k.get(".sgpr_spill_count", 0),
-                                    "scratch_bytes": k.get(".private_segment_fixed_size", 0), "lds_bytes": k.get(".group_segment_fixed_size", 0)}
+    for k in items:
+        out[k.get(".name", "?")] = {"vgpr_count": num(k, ".vgpr_count"), "agpr_count": num(k, ".agpr_count"), "sgpr_count": num(k, ".sgpr_count"),
+                                    "vgpr_spill_count": num(k, ".vgpr_spill_count", 0), "sgpr_spill_count": num(k, ".sgpr_spill_count", 0),
+                                    "scratch_bytes": num(k, ".private_segment_fixed_size", 0), "lds_bytes": num(k, ".group_segment_fixed_size", 0)}
     return out
 
 

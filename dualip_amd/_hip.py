@@ -184,6 +184,53 @@ def require_device(t: torch.Tensor, what: str) -> None:
         )
 
 
+_stage_logged = False
+
+
+def compute_device() -> torch.device:
+    """The ROCm device CPU-resident inputs are staged to: the process's current one (one process per GPU sets it per rank)."""
+    if not torch.cuda.is_available():
+        raise HipLibraryError(
+            "dualip_amd computes on an AMD GPU through libdualip_hip.so only (there is no CPU fallback) and this process sees no ROCm device: "
+            "host_device='cpu' inputs are staged to a GPU, not computed on the host"
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stage(t, what: str, device=None):
+    """``t`` on a ROCm device.  The reference's callers default to ``host_device="cpu"`` (examples/movielens_matching/
+    movies_lens_matching.py:227, examples/miplib_2017/solve_miplib_dataset.py:58) and its tests build CPU tensors: such inputs are COPIED
+    to the current ROCm device (said once in the log) and the results handed back on the caller's device -- the arithmetic still runs in
+    libdualip_hip.so only.  Without a GPU this raises, like every other entry point."""
+    global _stage_logged
+    if t is None or t.is_cuda:
+        return t
+    dev = compute_device() if device is None else device
+    if not _stage_logged:
+        _stage_logged = True
+        import logging
+
+        logging.getLogger("dualip_amd").warning("%s lives on '%s': staging CPU inputs to %s for the HIP path and returning results on the caller's device "
+                                                "(no CPU compute path exists; said once)", what, t.device, dev)
+    return t.to(dev)
+
+
+def result_to(res, device):
+    """An ObjectiveResult / SolverResult whose tensors live on ``device`` (the caller's, when its inputs were staged)."""
+    import dataclasses
+
+    if res is None or device is None:
+        return res
+    moved = {}
+    for f in dataclasses.fields(res):
+        v = getattr(res, f.name)
+        if isinstance(v, torch.Tensor):
+            moved[f.name] = v.to(device)
+        elif dataclasses.is_dataclass(v) and not isinstance(v, type):
+            moved[f.name] = result_to(v, device)
+    return dataclasses.replace(res, **moved) if moved else res
+
+
 def stream_ptr(device=None) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 

@@ -961,6 +961,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             tab[0] = n0;  // minimum = every workgroup's rounds: no tail tables in use
             for (int w = 0; w < h->n_wg; ++w) tab[4 + (size_t)w] = n0;
             CKH(hipMemcpyAsync(h->bal, tab.data(), sizeof(int32_t) * words, hipMemcpyHostToDevice, st));
+            h->bal_adapts = adapt;
             if (adapt) {
                 CK(owned_malloc(h, (void**)&h->bal_stamps, sizeof(unsigned long long) * 4 * (size_t)h->n_wg));
                 CKH(hipMemsetAsync(h->bal_stamps, 0, sizeof(unsigned long long) * 4 * (size_t)h->n_wg, st));
@@ -1079,6 +1080,8 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
         return 0;
     }
     if (h->m < 2) return fail(DL_E_ARG, "the fairness pair needs at least its own two rows");
+    // (the mirror of dl_matching_own_inputs' refusal: after it the straggler tiles read at pool offsets while f stays in the caller's order)
+    if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): the fairness stream is read at the caller's offsets, which its straggler tiles no longer use -- build a new handle");
     if ((h->n_tiles > 0 || h->n_sell > 0) && (h->layout != 4 || !h->lam_lds || !h->grad_lds))
         return fail(DL_E_STATE, "the fairness pair needs the 256-wide tile layout with the dual vector and the gradient in LDS (16-byte aligned values, nnz >= 1024)");
     if ((reinterpret_cast<uintptr_t>(f_values) & 15u) != 0) return fail(DL_E_ARG, "fairness values must be 16-byte aligned");

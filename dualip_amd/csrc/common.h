@@ -93,6 +93,7 @@ struct dl_matching {
     // Balance (fused_common.h: Deal): rounds of the window tiles' cyclic deal per workgroup + the tables of the last rounds, adapted
     // from per-workgroup stamps; null = every workgroup takes the same number of rounds
     int32_t* bal = nullptr;                  // owned, device, bal_table_words(n_wg) ints
+    bool bal_adapts = false;                 // the WINDOWS' deal adapts (wg_balance_kernel rewrites `bal`); stamps alone do not say so: the slices' deal shares them
     unsigned long long* bal_stamps = nullptr;  // owned, device, [n_wg][4]: prologue done, wavefront 0's windows done, all done
     int32_t* sell_bal = nullptr;             // owned, device, 4 + n_wg ints: the two-phase deal of the one-lane slices (fused4_kernel.h / matching_kernels.hip:
                                              // sell_balance_kernel) -- { slices dealt to everybody, wavefronts of the second phase, share in ppm, updates ; rank[n_wg] }

@@ -779,8 +779,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
-        hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
-        DL_HIP(hipGetLastError());
+        if (h->bal_adapts) {  // (a table declared non-adapting holds 0x7FFFFFFF rounds: never rewritten from it)
+            hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
+            DL_HIP(hipGetLastError());
+        }
         if (h->sell_bal && !h->sell_bal_frozen) {  // (handles whose windows do not adapt: the slices' two-phase deal does)
             hipLaunchKernelGGL(sell_balance_kernel, dim3(1), dim3(1024), 0, st, h->sell_bal, h->bal_stamps, h->n_wg, (uint32_t)(h->n_sell - h->n_sell_lane_slices), 0.5);
             DL_HIP(hipGetLastError());

@@ -141,9 +141,14 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
             raise ValueError("Both A and c must be CSC-format sparse tensors")
         if A.shape != c.shape or A.values().shape != c.values().shape:
             raise ValueError("A and c must share the same sparsity pattern")
-        _hip.require_device(A.values(), "A")
-        _hip.require_device(c.values(), "c")
+        # CPU-resident inputs (the reference's default host_device, run_solver.py / its tests): copied to the current ROCm device; the
+        # arithmetic is libdualip_hip.so's either way and calculate() hands its results back on the device of the duals it was given
+        if not A.values().is_cuda or not c.values().is_cuda:
+            dev = _hip.compute_device() if not (A.values().is_cuda or c.values().is_cuda) else (A.values().device if A.values().is_cuda else c.values().device)
+            A, c = _hip.stage(A, "A", dev), _hip.stage(c, "c", dev)
         b_in = matching_input_args.b_vec
+        if b_in is not None and b_in.device != A.values().device:
+            b_in = _hip.stage(b_in, "b_vec", A.values().device) if not b_in.is_cuda else b_in.to(A.values().device)
         # Jacobi pre-conditioning (run_solver.py:136-144 expects the objective to carry ``use_jacobi_precondition`` and
         # ``invert_jacobi_precondition``; preprocessing/precondition.py:8-28): rows of A and b scaled by 1 / ||A_i||_2 -- on
         # COPIES, the caller's tensors stay as they are.  ``row_norms`` given = the norms of the WHOLE matrix when this
@@ -175,7 +180,6 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         self.m, self.n = int(A.shape[0]), int(A.shape[1])
         self.nnz = int(A.values().shape[0])
         if self.b_vec is not None:
-            _hip.require_device(self.b_vec, "b_vec")
             if self.b_vec.dtype != self.dtype:
                 raise ValueError("b_vec must have the dtype of A")
 
@@ -344,7 +348,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         return self._primal
 
     def _check_dual(self, dual_val: torch.Tensor) -> torch.Tensor:
-        _hip.require_device(dual_val, "dual_val")
+        dual_val = _hip.stage(dual_val, "dual_val", self.device)
         if dual_val.dtype != self.dtype or dual_val.shape != (self.m,):
             raise ValueError(f"dual_val must be a {self.dtype} vector of length {self.m}")
         return dual_val.contiguous()
@@ -414,7 +418,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         if save_primal:
             res.primal_var = x_out
             res.primal_objective = packed[self.m].to(self.dtype)
-        return res
+        return res if dual_val.is_cuda else _hip.result_to(res, dual_val.device)  # (a CPU caller gets CPU results)
 
 
 class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
@@ -535,4 +539,5 @@ class MatchingSolverDualObjectiveFunctionDistributed(BaseObjective):
             raise NotImplementedError("save_primal=True is not yet supported in distributed mode")
         packed = self.calculate_packed(dual_val, gamma)
         self.local_objective.gamma = self.gamma
-        return self.local_objective.finish(packed, dual_val, self.b_vec)
+        res = self.local_objective.finish(packed, dual_val, self.b_vec)
+        return res if (dual_val.is_cuda or self.device.type != "cuda") else _hip.result_to(res, dual_val.device)

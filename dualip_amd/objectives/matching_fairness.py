@@ -69,6 +69,11 @@ class MatchingFairnessDualObjectiveFunction(BaseObjective):
 
     def __init__(self, matching_input_args: MatchingInputArgs, gamma: float, group_ratio: float = 0.5, A_fairness: Optional[torch.Tensor] = None, batching: bool = True,
                  native: Optional[bool] = None):
+        if not matching_input_args.A.values().is_cuda:  # CPU-resident inputs: staged to the current ROCm device (dualip_amd/_hip.py: stage)
+            dev = _hip.compute_device()
+            _hip.stage(matching_input_args.A.values(), "A", dev)
+            matching_input_args = matching_input_args.to(dev)
+            A_fairness = None if A_fairness is None else A_fairness.to(dev)
         A, c = matching_input_args.A, matching_input_args.c
         self.k = int(A.shape[0])
         self.m = self.k + 2
@@ -174,16 +179,17 @@ class MatchingFairnessDualObjectiveFunction(BaseObjective):
         return ObjectiveResult(dual_gradient=grad, dual_objective=s[0], reg_penalty=s[1], dual_val_times_grad=s[3], max_pos_slack=s[4], sum_pos_slack=s[5])
 
     def calculate(self, dual_val: torch.Tensor, gamma: float = None, save_primal: bool = False, **kwargs) -> ObjectiveResult:
-        _hip.require_device(dual_val, "dual_val")
+        caller = None if dual_val.is_cuda else dual_val.device
+        dual_val = _hip.stage(dual_val, "dual_val", self.device)
         if dual_val.dtype != self.dtype or dual_val.shape != (self.m,):
             raise ValueError(f"dual_val must be a {self.dtype} vector of length {self.m}")
         if self.native:
             if gamma is not None:
                 self.gamma = gamma
-            return self.inner.calculate(dual_val, self.gamma, save_primal)
+            return _hip.result_to(self.inner.calculate(dual_val, self.gamma, save_primal), caller)
         packed = self.calculate_packed(dual_val, gamma)
         res = self.finish(packed, dual_val, self.b_vec)
         if save_primal:
             res.primal_var = self.inner._primal_buffer()
             res.primal_objective = packed[self.m].to(self.dtype)
-        return res
+        return _hip.result_to(res, caller)

@@ -84,13 +84,14 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
     def __init__(self, miplib_input_args: MIPLIBInputArgs, use_jacobi_precondition: bool = False):
         args = miplib_input_args
         self.A = args.A
-        self.c = args.c
-        self.b_vec = args.b_vec
+        # CPU-resident inputs (solve_miplib_dataset.py:58 runs with host_device="cpu"): c and b are copied to the current ROCm device (A's
+        # CSC / CSR forms are built on the host and moved there in any case); calculate() answers on the device of the duals it is given
+        dev = args.c.device if args.c.is_cuda else (args.b_vec.device if args.b_vec.is_cuda else _hip.compute_device())
+        self.c = _hip.stage(args.c, "c", dev)
+        self.b_vec = _hip.stage(args.b_vec, "b_vec", dev)
         self.projection_map = args.projection_map
         self.equality_mask = args.equality_mask
         self.use_jacobi_precondition = bool(use_jacobi_precondition)
-        _hip.require_device(self.c, "c")
-        _hip.require_device(self.b_vec, "b_vec")
         self.device = self.c.device
         self.dtype = self.c.dtype
         if self.dtype not in (torch.float32, torch.float64):
@@ -209,7 +210,7 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
         return self._primal
 
     def _check_dual(self, dual_val: torch.Tensor) -> torch.Tensor:
-        _hip.require_device(dual_val, "dual_val")
+        dual_val = _hip.stage(dual_val, "dual_val", self.device)
         if dual_val.dtype != self.dtype or dual_val.shape != (self.m,):
             raise ValueError(f"dual_val must be a {self.dtype} vector of length {self.m}")
         return dual_val.contiguous()
@@ -255,7 +256,7 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
             res.primal_var = x_out
         else:
             res.primal_objective = None
-        return res
+        return res if dual_val.is_cuda else _hip.result_to(res, dual_val.device)
 
     def invert_jacobi_precondition(self, dual_val: torch.Tensor, dual_grad: torch.Tensor):
         """Duals / gradient of the ORIGINAL rows from those of the row-normalised problem (run_solver.py:136-144):

@@ -124,8 +124,13 @@ class AcceleratedGradientDescent:
 
     # ---- entry point ----------------------------------------------------------------------------------------
     def maximize(self, f: BaseObjective, initial_value: torch.Tensor, rank: int = 0) -> SolverResult:
-        if getattr(f, "_dualip_native", False) and self.gamma is not None and initial_value.is_cuda:
-            return self._maximize_native(f, initial_value, rank)
+        if getattr(f, "_dualip_native", False) and self.gamma is not None:
+            if initial_value.is_cuda:
+                return self._maximize_native(f, initial_value, rank)
+            if getattr(getattr(f, "device", None), "type", None) == "cuda":
+                # a CPU caller of an objective that lives on the GPU (its CPU inputs were staged there, dualip_amd/_hip.py: stage): the same
+                # device-resident loop, and the result's tensors on the caller's device
+                return _hip.result_to(self._maximize_native(f, initial_value, rank), initial_value.device)
         return self._maximize_generic(f, initial_value, rank)
 
     # ---- route 3: generic torch path ---------------------------------------------------------------------------

@@ -14,8 +14,15 @@ from dualip_amd import _hip
 
 def _jacobi_call(A: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     vals = A.values()
-    _hip.require_device(vals, "A")
-    _hip.require_device(b, "b")
+    if not vals.is_cuda or not b.is_cuda:  # CPU-resident A / b: scaled on the current ROCm device, written back IN PLACE (the reference's contract)
+        dev = vals.device if vals.is_cuda else (b.device if b.is_cuda else _hip.compute_device())
+        A_dev, b_dev = _hip.stage(A, "A", dev) if not vals.is_cuda else A, _hip.stage(b, "b", dev) if not b.is_cuda else b
+        norms = _jacobi_call(A_dev, b_dev)
+        if not vals.is_cuda:
+            vals.copy_(A_dev.values())
+        if not b.is_cuda:
+            b.copy_(b_dev)
+        return norms.to(vals.device)
     rowidx = A.row_indices().contiguous()
     norms = torch.empty(A.size(0), dtype=vals.dtype, device=vals.device)
     with torch.cuda.device(vals.device):

@@ -44,7 +44,8 @@ class ProjectionOperator(ABC):
 
 
 def _apply_dense(op: "ProjectionOperator", x: torch.Tensor, force_2d: bool = False) -> torch.Tensor:
-    _hip.require_device(x, "projection input")
+    if not x.is_cuda:  # a CPU vector / block (the reference's tests): projected on the current ROCm device, answered on the CPU
+        return _apply_dense(op, _hip.stage(x, "projection input"), force_2d).to(x.device)
     lib = _hip.load()
     squeeze = x.ndim == 1
     x2 = x.unsqueeze(1) if squeeze else x

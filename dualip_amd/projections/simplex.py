@@ -51,3 +51,27 @@ class SimplexIneq(_SimplexBase):
 @register("simplex_eq")
 class SimplexEq(_SimplexBase):
     _kind = _hip.PROJ_SIMPLEX_EQ
+
+
+def _dense_in_working_precision(op: _SimplexBase, x: torch.Tensor) -> torch.Tensor:
+    """``op`` on a [L, B] block whose dtype the library has no kernel for (bfloat16 / float16: the reference's tests project such blocks):
+    projected in float32 and rounded back once -- never less accurate than the reference's arithmetic in the narrow type."""
+    if x.dtype in (torch.float32, torch.float64):
+        return _apply_dense(op, x, force_2d=True)
+    return _apply_dense(op, x.to(torch.float32), force_2d=True).to(x.dtype)
+
+
+def _duchi_proj(x: torch.Tensor, z: float, inequality: bool = False, tol: float = 1e-6, cols_per_chunk: int = 10000) -> torch.Tensor:
+    """The reference's module-level function (simplex.py:126-236), which its own tests import: every column of the [L, B] block ``x``
+    projected onto {w >= 0, sum w = z} (``inequality=True``: sum w <= z).  One ``dl_project_dense`` launch; ``tol`` is the reference's
+    1e-6 feasibility slack (fixed in the kernel) and ``cols_per_chunk`` bounded the reference's temporaries -- neither changes the result."""
+    assert z > 0, "Simplex radius z must be positive."
+    if tol != 1e-6:
+        raise ValueError("the kernel's feasibility slack is the reference's default 1e-6")
+    return _dense_in_working_precision((SimplexIneq if inequality else SimplexEq)(z=z, method="duchi"), x)
+
+
+def _proj_via_bisection_search(x: torch.Tensor, z: float = 1.0, inequality: bool = False, tol: float = 1e-6, max_iter: int = 50) -> torch.Tensor:
+    """The reference's bisection variant (simplex.py:6-123) under its own name: ``project_dense_bisect_kernel`` through ``dl_project_dense``."""
+    assert z > 0, "Simplex radius z must be positive."
+    return _dense_in_working_precision((SimplexIneq if inequality else SimplexEq)(z=z, method="bisection_search"), x)

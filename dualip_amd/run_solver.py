@@ -14,6 +14,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from dualip_amd import _hip
 from dualip_amd.objectives.base import BaseInputArgs
 from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunction
 from dualip_amd.objectives.matching import (
@@ -168,6 +169,15 @@ def run_solver(
 def _run_solver(input_args, solver_args, compute_args, objective_args) -> SolverResult:
     host_device = compute_args.host_device
     sharded = compute_args.compute_device_num > 1
+    # host_device="cpu" (the default of the reference's examples: movies_lens_matching.py:227, solve_miplib_dataset.py:58) names where the
+    # CALLER keeps its tensors, not where the arithmetic runs: the inputs are staged to this process's current ROCm device, the solve is
+    # libdualip_hip.so's as always, and the SolverResult comes back on the CPU.  Without a GPU this raises (there is no CPU compute path).
+    caller_device = None
+    if torch.device(host_device).type == "cpu":
+        caller_device = torch.device(host_device)
+        host_device = _hip.compute_device()
+        _hip.stage(input_args.b_vec, "run_solver inputs (host_device='cpu')", host_device)  # (says it once in the log; raises without a GPU)
+        compute_args = dataclasses.replace(compute_args, host_device=str(host_device))
     if not sharded:
         input_args = transfer_tensors_to_device(input_args, host_device)
     objective = build_objective(input_args, solver_args, compute_args, objective_args)
@@ -192,4 +202,4 @@ def _run_solver(input_args, solver_args, compute_args, objective_args) -> Solver
         dual_val, dual_grad = objective.invert_jacobi_precondition(result.dual_val, result.objective_result.dual_gradient)
         result.dual_val = dual_val
         result.objective_result.dual_gradient = dual_grad
-    return result
+    return _hip.result_to(result, caller_device)

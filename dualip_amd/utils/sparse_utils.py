@@ -3,16 +3,47 @@
 Inside a solve the per-iteration primitives of that module -- left_multiply_sparse, elementwise_csc, apply_F_to_columns,
 row_sums_csc -- do not run as separate operations here: their work is fused into ``dl_matching_calculate``
 (csrc/matching_kernels4.hip).  They are still offered stand-alone, with the reference's signatures, each as ONE HIP launch
-(csrc/csc_ops.hip) for device tensors; there is no CPU implementation (``HipLibraryError`` on CPU tensors).  Callables the
+(csrc/csc_ops.hip).  There is no CPU implementation: CPU tensors (the reference's tests, ``host_device="cpu"`` callers) are copied to
+the current ROCm device, the launch runs there, and the result -- or the ``output_tensor`` written in place -- comes back on the CPU
+(``_cpu_callers`` below; ``HipLibraryError`` when the process sees no GPU).  Callables the
 library has no kernel for (an arbitrary ``op`` / ``F_batch``) are applied with the caller's own torch code on the device.
 """
 import ctypes
+import functools
+import inspect
 import operator
 from typing import Callable, List, Optional, Sequence
 
 import torch
 
 from dualip_amd import _hip
+
+
+def _cpu_callers(fn):
+    """CPU tensors among the arguments: every tensor argument is copied to one ROCm device (that of a device argument if there is one, else
+    the current device), ``fn`` runs there, and the caller gets what the reference's CPU code would have given it: a CPU result, and an
+    ``output_tensor`` whose values were overwritten in place (the return value is then that tensor's values, as in the reference)."""
+    sig = inspect.signature(fn)
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        bound = sig.bind(*args, **kwargs)
+        tens = [v for v in bound.arguments.values() if isinstance(v, torch.Tensor)]
+        if not tens or all(t.is_cuda for t in tens):
+            return fn(*args, **kwargs)
+        dev = next((t.device for t in tens if t.is_cuda), None) or _hip.compute_device()
+        out_cpu = bound.arguments.get("output_tensor")
+        home = next(t.device for t in tens if not t.is_cuda)
+        for k, v in list(bound.arguments.items()):
+            if isinstance(v, torch.Tensor) and not v.is_cuda:
+                bound.arguments[k] = _hip.stage(v, f"{fn.__name__}({k})", dev)
+        res = fn(*bound.args, **bound.kwargs)
+        if isinstance(out_cpu, torch.Tensor) and not out_cpu.is_cuda:
+            out_cpu.values().copy_(bound.arguments["output_tensor"].values())
+            return out_cpu.values()
+        return res.to(home) if isinstance(res, torch.Tensor) else res
+
+    return wrapper
 
 
 def _require_csc(M: torch.Tensor, name: str = "M") -> None:
@@ -81,7 +112,7 @@ def row_norms_csc(A: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------
 def _csc_parts(M: torch.Tensor, name: str = "M"):
     vals = M.values()
-    _hip.require_device(vals, name)
+    _hip.require_device(vals, name)  # (CPU callers were staged by _cpu_callers before this point)
     if not vals.is_contiguous():
         raise ValueError("CSC value arrays must be contiguous")
     return M.ccol_indices().contiguous(), M.row_indices().contiguous(), vals
@@ -119,6 +150,7 @@ _OPS = {torch.add: 0, operator.add: 0, torch.sub: 1, torch.subtract: 1, operator
         torch.div: 3, torch.divide: 3, torch.true_divide: 3, operator.truediv: 3}
 
 
+@_cpu_callers
 def elementwise_csc(A: torch.Tensor, B: torch.Tensor, op, output_tensor: Optional[torch.Tensor] = None):
     """``op`` applied to the values of two CSC tensors with identical pattern (reference :26-51).  torch / operator add, sub, mul
     and div run as one HIP launch; any other callable is applied to the two value tensors on the device."""
@@ -137,6 +169,7 @@ def elementwise_csc(A: torch.Tensor, B: torch.Tensor, op, output_tensor: Optiona
     return _finish(A, out, output_tensor)
 
 
+@_cpu_callers
 def left_multiply_sparse(v: torch.Tensor, M: torch.Tensor, output_tensor: Optional[torch.Tensor] = None):
     """diag(v) @ M for a CSC matrix, pattern preserved (reference :54-85)."""
     if M.layout != torch.sparse_csc:
@@ -151,6 +184,7 @@ def left_multiply_sparse(v: torch.Tensor, M: torch.Tensor, output_tensor: Option
     return _finish(M, out, output_tensor)
 
 
+@_cpu_callers
 def right_multiply_sparse(M: torch.Tensor, v: torch.Tensor, output_tensor: Optional[torch.Tensor] = None):
     """M @ diag(v) for a CSC matrix, pattern preserved (reference :88-130; no per-column host loop)."""
     if M.layout != torch.sparse_csc:
@@ -165,6 +199,7 @@ def right_multiply_sparse(M: torch.Tensor, v: torch.Tensor, output_tensor: Optio
     return _finish(M, out, output_tensor)
 
 
+@_cpu_callers
 def row_sums_csc(A: torch.Tensor) -> torch.Tensor:
     """Dense vector of the row sums of a CSC matrix (reference :223-243), accumulated in float64 and rounded once."""
     _require_csc(A, "A")
@@ -176,6 +211,7 @@ def row_sums_csc(A: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_cpu_callers
 def apply_F_to_columns(M: torch.Tensor, F_batch: Callable[[torch.Tensor], torch.Tensor], buckets: Sequence[torch.Tensor], output_tensor: Optional[torch.Tensor] = None):
     """Replace the values of every column listed in ``buckets`` by ``F_batch`` of them (reference :133-220).
 

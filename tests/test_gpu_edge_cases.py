@@ -657,6 +657,14 @@ def test_release_inputs_makes_the_handle_self_contained(order):
         if release:
             with pytest.raises((RuntimeError, ValueError), match="owns its inputs"):
                 f.costs_changed()
+            # own-then-fairness (the order dl_matching_own_inputs' own refusal does not cover): the fairness stream would be read at pool
+            # offsets by the straggler tiles while f stays in the caller's order -- refused, not silently wrong
+            from dualip_amd import _hip
+
+            fv = torch.zeros(f.nnz + 8, dtype=torch.float32, device=DEV)
+            with torch.cuda.device(f.device):
+                rc = f._lib.dl_matching_set_fairness(f._handle, _hip.ptr(fv), _hip.stream_ptr(f.device))
+            assert rc == 4 and "owns its inputs" in _hip.last_error(), (rc, _hip.last_error())  # DL_E_STATE
         return r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective), list(res.dual_objective_log), res.dual_val.clone(), out
 
     g0, x0, o0, log0, d0, _ = run(False)
