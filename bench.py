@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--measure-traffic", action="store_true", help="measure roofline.traffic in THIS invocation: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a "
                     "3-step run of the same workload as child processes, 2 x FETCH_SIZE + WRITE_SIZE KiB per fused launch (gfx950 corrections of "
                     "MI355X_MICROARCH.md; calibration profiles/r02_fetch_size_calibration.json)")
+    ap.add_argument("--no-traffic-fallback", action="store_true", help="do not run the counter passes when profiles/traffic.json has no record of this build (roofline.traffic is then the bytes by construction)")
     ap.add_argument("--record-traffic", action="store_true", help="with --measure-traffic: store the figure, the commit and the kernel layout it belongs to in profiles/traffic.json")
     ap.add_argument("--release-inputs", action="store_true", help="N = 1: after every other leg, make the kernel handle self-contained (objective.release_inputs()), drop the "
                     "generator's tensors, and time the window again -- aux.footprint: resident bytes before / after next to the bytes one launch streams")
@@ -191,14 +192,18 @@ def _cpu_sample(args, inp, pm_local, n_cols):
                 col_proj=np.concatenate(col_proj_parts), projs=projs, b=inp.b_vec.cpu().numpy(), m=A.shape[0], n_entries=len(entries))
 
 
-def read_ceiling_gbps(device, nbytes=4 << 30, reps=5):
-    """Streaming READ rate of this box (16-byte non-temporal loads, the fused kernel's access): what `physical_frac` should be
-    held against besides the 8 TB/s of the data sheet (the fused kernel is read dominated; torch's copy reads AND writes)."""
+def read_ceiling_gbps(device, nbytes=10 << 30, reps=5):
+    """Streaming READ rate of this box, best of four access shapes (16-byte non-temporal loads; one stream, or the fused kernel's three
+    streams side by side with two, four or eight steps of a lane in flight -- dl_measure_read_bandwidth): a PROBE, not a proven ceiling.
+    The default buffer is as large as the headline launch's stream (10 GiB; the 4 GiB, two-deep probe of round 4 read 5 % slower than the
+    kernel it was held against).  `physical_frac` should be read against it besides the 8 TB/s of the data sheet."""
     import ctypes
 
     from dualip_amd import _hip
 
-    buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+    free, _ = torch.cuda.mem_get_info(device)
+    nbytes = int(min(nbytes, max(1 << 20, free // 2))) // 4096 * 4096
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device).fill_(0.5)
     out = ctypes.c_double(0.0)
     with torch.cuda.device(device):
         _hip.check(_hip.load().dl_measure_read_bandwidth(_hip.ptr(buf), nbytes, reps, ctypes.byref(out), _hip.stream_ptr(device)))
@@ -277,7 +282,20 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
     return out
 
 
-TRAFFIC_LAYOUT_KEYS = ("tiles", "long_columns", "workgroup_columns", "slices", "slice_elements", "slice_lane_columns", "window_descriptor_words", "row_index_bytes", "hot_rows", "layout", "workgroups")
+TRAFFIC_LAYOUT_KEYS = ("tiles", "long_columns", "workgroup_columns", "slices", "slice_elements", "slice_lane_columns", "window_descriptor_words", "row_index_bytes", "hot_rows", "layout", "workgroups",
+                       "slab_bytes")
+
+
+def library_source_hash():
+    """Digest of the sources libdualip_hip.so was built from (dualip_amd/_build.py: every .hip / .h and the flags).  A traffic record belongs
+    to ONE such digest: any kernel edit, whether or not it changes the layout dl_matching_info reports, retires the record."""
+    from dualip_amd import _build
+
+    try:
+        with open(_build.HASH_PATH) as fh:
+            return fh.read().strip()
+    except OSError:
+        return _build.source_hash()
 
 
 def traffic_key(args, world):
@@ -312,11 +330,15 @@ def stored_traffic(args, world, lay, phys_bytes):
     if rec is None:
         return None, "no counter pass recorded for this configuration"
     if isinstance(rec, dict):
+        have = library_source_hash()
+        if rec.get("srchash") != have:
+            return None, (f"the record of commit {rec.get('commit')} was taken on another build of the kernels (source hash {str(rec.get('srchash'))[:12]} against {have[:12]} "
+                          "of this library): refused")
         diff = {k: (rec.get("layout", {}).get(k), lay.get(k)) for k in TRAFFIC_LAYOUT_KEYS if rec.get("layout", {}).get(k) != lay.get(k)}
         if diff:
             return None, f"the record of commit {rec.get('commit')} was taken on another kernel layout ({diff}): refused"
         return float(rec["bytes"]), (f"profiles/traffic.json: rocprofv3 --pmc passes of this command at commit {rec.get('commit')} ({rec.get('file', 'bench.py --measure-traffic --record-traffic')}), "
-                                     "2 x FETCH_SIZE + WRITE_SIZE (gfx950 corrections), same kernel layout as this run")
+                                     f"2 x FETCH_SIZE + WRITE_SIZE (gfx950 corrections), same kernel sources (hash {have[:12]}) and layout as this run")
     if abs(float(rec) - phys_bytes) > 0.1 * phys_bytes:
         return None, "the (round 1-3, layout-less) record is more than 10 % from this launch's bytes by construction: refused"
     return float(rec), "profiles/traffic.json: rocprofv3 --pmc passes of this command in an earlier round (record without layout / commit: only checked to be within 10 % of the layout's bytes)"
@@ -334,14 +356,14 @@ def measure_traffic_now(child=None, extra_counters=()):
     import tempfile
 
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    drop = {"--measure-traffic", "--record-traffic"}
+    drop = {"--measure-traffic", "--record-traffic", "--no-traffic-fallback"}
     base = [a for a in sys.argv[1:] if a not in drop]
     for flag in ("--steps", "--warmup"):  # (value flags the child gets its own of)
         while flag in base:
             i = base.index(flag)
             del base[i:i + 2]
     if child is None:
-        child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-late", "--no-verify", "--no-cpu-baseline"]
+        child = [sys.executable, os.path.abspath(__file__)] + base + ["--steps", "3", "--warmup", "1", "--no-late", "--no-verify", "--no-cpu-baseline", "--no-traffic-fallback"]
     vals, details = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE") + tuple(extra_counters):
         tmp = tempfile.mkdtemp(prefix="dualip_pmc_", dir="/tmp")
@@ -564,7 +586,7 @@ def main():
     per_nnz = 2 * vs + lay["row_index_bytes"]
     desc_bytes = 4 * lay.get("window_descriptor_words", 12 if lay["layout"] == 4 else 4)
     phys_bytes = (nnz_first + lay.get("slice_elements", 0) - lay.get("slice_nnz", 0)) * per_nnz + (lay["tiles"] - lay["long_columns"]) * desc_bytes \
-        + lay["long_columns"] * (48 if lay["layout"] == 4 else 16) + lay.get("slices", 0) * 16 + lay.get("slice_mixed_columns", 0) + lay["workgroups"] * (m * 8 + 16)
+        + lay["long_columns"] * (48 if lay["layout"] == 4 else 16) + lay.get("slices", 0) * 16 + lay.get("slice_mixed_columns", 0) + lay["workgroups"] * (m * lay.get("slab_bytes", 8) + 16)
 
     # roofline.traffic: HBM bytes per launch from the PMC counters -- measured in this invocation (--measure-traffic), else the record
     # of profiles/traffic.json IF it was taken on this very kernel layout, else what the launch moves by construction (phys_bytes)
@@ -579,11 +601,22 @@ def main():
                     table = json.load(open(tpath))
                 except Exception:
                     table = {}
-                table[traffic_key(args, world)] = {"bytes": traffic, "commit": current_commit(), "layout": {k: lay.get(k) for k in TRAFFIC_LAYOUT_KEYS},
+                table[traffic_key(args, world)] = {"bytes": traffic, "commit": current_commit(), "srchash": library_source_hash(), "layout": {k: lay.get(k) for k in TRAFFIC_LAYOUT_KEYS},
                                                    "by_construction": phys_bytes, "counters": traffic_details, "file": "bench.py --measure-traffic --record-traffic"}
                 json.dump(table, open(tpath, "w"), indent=1)
     if not traffic and not sharded:  # (the recorded passes are single-GPU runs of the whole problem)
         traffic, traffic_source = stored_traffic(args, world, lay, phys_bytes)
+        headline = args.entities == 100_000_000 and args.destinations == 10_000 and args.sparsity == 1e-3 and args.proj == "mixed" and args.dtype == "f32"
+        if not traffic and rank == 0 and headline and not args.no_traffic_fallback and os.environ.get("DUALIP_BENCH_NO_EVENTS") != "1":
+            # the driver's configuration and no record of THIS build: measure now (two counter passes of three steps of this command) rather than
+            # quote bytes by construction (other sizes -- tests, tools -- keep the by-construction figure, labelled as such)
+            refused = traffic_source
+            traffic, traffic_details = measure_traffic_now()
+            if traffic:
+                traffic_source = (f"measured in this run (fallback: {refused}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (3 steps), kernel source hash "
+                                  f"{library_source_hash()[:12]}, 2 x FETCH_SIZE + WRITE_SIZE KiB per launch")
+            else:
+                traffic_source = f"{refused}; the fallback counter passes failed ({(traffic_details or {}).get('error')})"
     if not traffic:
         why = traffic_source or "sharded run"
         traffic = float(phys_bytes)
@@ -716,8 +749,8 @@ def main():
         ws = max(1 << 20, int(phys_bytes) // 4096 * 4096)
         ceil_ws = read_ceiling_gbps(device, nbytes=ws, reps=20)
         cache_resident = {"working_set_bytes": ws, "note": "the launch's bytes fit the 256 MB Infinity Cache: the fraction of the HBM peak is not the yardstick; "
-                          "read_ceiling_GBps = dl_measure_read_bandwidth (one launch of the streaming-read probe) over a buffer of the same size, read repeatedly",
-                          "read_ceiling_GBps": ceil_ws, "kernel_GBps": achieved, "kernel_frac_of_ceiling": achieved / ceil_ws if ceil_ws > 0 else None,
+                          "read_probe_GBps = dl_measure_read_bandwidth (one launch of the streaming-read probe) over a buffer of the same size, read repeatedly",
+                          "read_probe_GBps": ceil_ws, "kernel_GBps": achieved, "kernel_frac_of_probe": achieved / ceil_ws if ceil_ws > 0 else None,
                           "ceiling_launch_us": ws / ceil_ws / 1e3 if ceil_ws > 0 else None, "kernel_launch_us": avg_kernel_s * 1e6}
 
     if rank == 0:
@@ -759,7 +792,7 @@ def main():
                 "event_stride": stride,
                 "physical_bytes_per_launch": phys_bytes,
                 "window": [args.warmup + 1, args.warmup + args.steps],
-                "frac_of_read_ceiling": None,
+                "frac_of_read_probe": None,
             },
             "aux": {
                 "generate_s": t_gen,
@@ -787,14 +820,16 @@ def main():
                 "verified": verified,
                 "collective": collective,
                 "copy_ceiling_GBps": copy_ceiling_gbps(device),
-                "read_ceiling_GBps": read_ceiling_gbps(device),
+                "read_probe_GBps": read_ceiling_gbps(device),
                 "traffic_counters": traffic_details,
                 "cache_resident": cache_resident,
                 "footprint": footprint,
             },
         }
-        rc_gbps = out["aux"]["read_ceiling_GBps"]
-        out["roofline"]["frac_of_read_ceiling"] = achieved / rc_gbps if rc_gbps else None  # (same box, same run: what a plain streaming read reaches)
+        rc_gbps = out["aux"]["read_probe_GBps"]
+        out["roofline"]["frac_of_read_probe"] = achieved / rc_gbps if rc_gbps else None  # (same box, same run: what a plain streaming read reaches)
+        fastest = max([achieved] + ([late["achieved_GBps"]] if (late and late.get("achieved_GBps")) else []))
+        out["roofline"]["read_probe_beaten_by_kernel"] = bool(rc_gbps and fastest > rc_gbps)  # (true: the probe is a lower bound of the box's read rate, nothing more)
         if comm is not None:
             out["aux"]["collective"] = {**(collective or {}), **comm.info(), "emulated_world": emu or None, "emulated_rank": emu_rank if emu else None,
                                         "exchanges": comm.exchanges, "us_per_exchange": (xms / xn * 1e3) if xn else None,

@@ -35,6 +35,10 @@ def _hipcc():
 
 
 HASH_PATH = LIB_PATH + ".srchash"
+# the developer build (tools/ only): the same sources with -DDL_DEVTOOLS -- ablation switches that skip work inside the kernels and the
+# tuning constants behind profiles/ become readable from the environment.  Never loaded unless DUALIP_DEV_LIBRARY=1 asks for it (_hip.py).
+DEV_LIB_PATH = os.path.join(LIB_DIR, "libdualip_hip_dev.so")
+DEV_FLAG = "-DDL_DEVTOOLS"
 
 
 def source_hash() -> str:
@@ -164,8 +168,10 @@ def _sgpr_pair_defects(asm_path: str):
         # a pending pair used as a 64-bit operand?
         if pending:
             keep = []
+            # (a scalar instruction's FIRST operand is its destination: `s_lshl_b64 s[6:7], s[0:1], 2` overwrites s[6:7], it does not read it)
+            read_part = " ".join(ops[1:]) if (op.startswith("s_") and not op.startswith(_NO_SDST)) else t
             for P, desc, until in pending:
-                if f"s[{P}:{P + 1}]" in t and not (op.startswith("v_readlane") and False):
+                if f"s[{P}:{P + 1}]" in read_part:
                     out.append(f"{kernel} {desc}; the pair is then used as s[{P}:{P + 1}] by `{t}`")
                     continue
                 if idx < until:
@@ -199,6 +205,10 @@ def _sgpr_pair_defects(asm_path: str):
             continue
         if op.startswith("s_") and not op.startswith(_NO_SDST) and ops:
             sr = _sreg(ops[0])
+            if sr and pending:
+                # one half of a reloaded pair REDEFINED before any 64-bit use (the use of this very instruction was checked above): e.g. a reloaded
+                # 32-bit value zero-extended by `s_mov_b32 s7, 0` ahead of `s_lshl_b64 s[6:7], s[6:7], 3` -- the stale half never reaches the operand
+                pending = [(P, desc, until) for P, desc, until in pending if not (sr[0] <= P <= sr[1] or sr[0] <= P + 1 <= sr[1])]
             if sr:
                 for r in range(sr[0], sr[1] + 1):
                     lastdef[r], lastop[r] = idx, op
@@ -277,14 +287,14 @@ BENCHMARK_KERNEL = "_ZN2dl22matching_fused_kernel4IftLb1ELb1ELb0ELb0ELb0EEEvNS_9
 MANIFEST_PATH = os.path.join(LIB_DIR, "build_manifest.json")
 
 
-def _compile_objects(verbose: bool):
+def _compile_objects(verbose: bool, dev: bool = False):
     """One object per source, compiled in parallel and kept by content hash: editing one file rebuilds one object."""
     from concurrent.futures import ThreadPoolExecutor
 
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj_dev" if dev else "obj")
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    cflags = [f for f in FLAGS if f != "-shared"]
+    cflags = [f for f in FLAGS if f != "-shared"] + ([DEV_FLAG] if dev else [])
     jobs, objs = [], []
     for name in SOURCES:
         obj = os.path.join(obj_dir, f"{os.path.splitext(name)[0]}.{_object_hash(name)}.o")
@@ -351,6 +361,8 @@ def _compile_objects(verbose: bool):
                 os.remove(full)
             except OSError:
                 pass
+    if dev:
+        return hipcc, objs
     # what the screens saw, per kernel: registers, spills, scratch (from the code object's metadata) -- checked by tests/test_host_api.py
     manifest = {"flags": FLAGS, "benchmark_kernel": BENCHMARK_KERNEL, "objects": []}
     for obj in objs:
@@ -396,5 +408,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_dev(force: bool = False, verbose: bool = False) -> str:
+    """libdualip_hip_dev.so: the developer build (DEV_FLAG).  Same screens, its own object cache; rebuilt when the sources changed."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    stamp = DEV_LIB_PATH + ".srchash"
+    want = source_hash()
+    if not force and os.path.exists(DEV_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return DEV_LIB_PATH
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force:
+                shutil.rmtree(os.path.join(LIB_DIR, "obj_dev"), ignore_errors=True)
+            hipcc, objs = _compile_objects(verbose, dev=True)
+            tmp = f"{DEV_LIB_PATH}.{os.getpid()}.tmp"
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs, "-ldl"], capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc (link, developer build) failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, DEV_LIB_PATH)
+            with open(stamp + ".tmp", "w") as fh:
+                fh.write(want)
+            os.replace(stamp + ".tmp", stamp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return DEV_LIB_PATH
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    if "--dev" in sys.argv:
+        print(build_dev(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force=True, verbose=True))

@@ -17,7 +17,7 @@ DL_F32, DL_F64 = 0, 1
 DL_I32, DL_I64 = 0, 1
 PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLEX_EQ = range(6)
 LOG_COLS = 8
-ABI_VERSION = 300  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
+ABI_VERSION = 301  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
 PROJ_FLAG_BISECTION = 1
 PROJ_FLAG_NO_SLICES = 2
 
@@ -35,6 +35,7 @@ class ProjDesc(ctypes.Structure):
 _SIGNATURES = {
     "dl_last_error_string": (ctypes.c_char_p, []),
     "dl_version": (_c_int, []),
+    "dl_switch_name": (ctypes.c_char_p, [_c_int]),
     "dl_matching_create": (
         _c_int,
         [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, ctypes.POINTER(ProjDesc), ctypes.c_int32, _c_vp, _c_vp],
@@ -112,6 +113,17 @@ def load():
     if _lib is not None:
         return _lib
     stale = None
+    if os.environ.get("DUALIP_DEV_LIBRARY", "0") not in ("", "0"):
+        # tools/ only: the developer build, whose ablation switches skip work inside the kernels (wrong results on purpose)
+        import warnings
+
+        warnings.warn("DUALIP_DEV_LIBRARY=1: loading libdualip_hip_dev.so (developer build: DUALIP_HIP_ABLATE and the tuning switches are live)", RuntimeWarning)
+        handle = ctypes.CDLL(_build.build_dev())
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+        return _lib
     try:
         path = _build.build()
     except Exception as exc:  # no silent fallback: the HIP path is the product

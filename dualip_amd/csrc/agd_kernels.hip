@@ -88,6 +88,10 @@ struct StatsArgs {
     const long long* __restrict__ partial_scal;  // fixed point, exponent shift_in[1]
     const int* __restrict__ shift_in;
     int n_slabs, n_scal;
+    int slab32;  // the slabs are int32 low words, high words of the workgroups stamped with this launch's epoch (common.h: dl_matching::slab32)
+    const int32_t* __restrict__ slab_hi;
+    const unsigned long long* __restrict__ slab_ovf;
+    unsigned long long slab_epoch;
     int64_t mpad;
     // hot-rows plan of the matching handle (inv != null): slab column p is the caller's row inv[p]; columns >= m_hot are in `cold`
     const int32_t* __restrict__ inv;
@@ -147,15 +151,26 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
                 }
             }
             constexpr int kU = 16;  // (256 slabs / 16 slices: every load of a thread in flight at once)
-            for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
-                long long v[kU];
+            auto sum_slabs = [&](auto* slabs) {
+                for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
+                    long long v[kU];
 #pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const int w = w0 + kStatSlices * u;
-                    v[u] = p.partial[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
+                    for (int u = 0; u < kU; ++u) {
+                        const int w = w0 + kStatSlices * u;
+                        v[u] = (long long)slabs[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) acc += (w0 + kStatSlices * u < p.n_slabs) ? v[u] : 0ll;
                 }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) acc += (w0 + kStatSlices * u < p.n_slabs) ? v[u] : 0ll;
+            };
+            if (p.slab32) {
+                sum_slabs(reinterpret_cast<const int32_t*>(p.partial));
+                if (in_slabs && p.slab_ovf[p.n_slabs] == p.slab_epoch) {  // (uniform, rare: fused_common.h, epilogue)
+                    for (int w0 = ws; w0 < p.n_slabs; w0 += kStatSlices)
+                        if (p.slab_ovf[w0] == p.slab_epoch) acc += (long long)p.slab_hi[(int64_t)w0 * p.mpad + rc] * 4294967296ll;
+                }
+            } else {
+                sum_slabs(p.partial);
             }
         }
         shi[tid] = acc;
@@ -498,6 +513,10 @@ static int agd_stats_typed(dl_agd* s, const StepSource& src, const void* b, hipS
         sa.shift_in = f ? f->shift_dev : nullptr;
         sa.n_slabs = f ? (f->grad_lds ? f->n_wg : 1) : 0;
         sa.n_scal = f ? f->n_wg : 0;
+        sa.slab32 = (f && f->slab32) ? 1 : 0;
+        sa.slab_hi = f ? f->slab_hi : nullptr;
+        sa.slab_ovf = f ? f->slab_ovf : nullptr;
+        sa.slab_epoch = f ? f->slab_epoch : 0;
         sa.mpad = f ? f->mpad : 0;
         sa.inv = (f && f->m_hot > 0) ? f->row_inv : nullptr;
         sa.m_hot = f ? f->m_hot : 0;

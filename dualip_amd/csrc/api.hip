@@ -19,6 +19,12 @@ namespace dl {
 
 static thread_local char g_err[512] = "";
 
+const char* plan_env(const char* name) {
+    for (int i = 0; i < kNumPlanSwitches; ++i)
+        if (strcmp(name, kPlanSwitches[i]) == 0) return getenv(name);
+    return nullptr;  // not registered in common.h: does not exist
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -48,6 +54,7 @@ size_t agd_partial_stats_bytes(int64_t m);
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
+int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
 size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype);
 int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const dl_proj_desc* projs, int32_t n_proj, double min_share,
@@ -162,6 +169,7 @@ static void matching_free(dl_matching* h) {
     if (h->wg_tile_begin) (void)hipFree(h->wg_tile_begin);
     if (h->projs) (void)hipFree(h->projs);
     if (h->partial) (void)hipFree(h->partial);
+    if (h->slab_ovf) (void)hipFree(h->slab_ovf);
     if (h->partial_scal) (void)hipFree(h->partial_scal);
     if (h->shift_dev) (void)hipFree(h->shift_dev);
     if (h->absmax_dev) (void)hipFree(h->absmax_dev);
@@ -404,7 +412,20 @@ using namespace dl;
 extern "C" {
 
 const char* dl_last_error_string(void) { return g_err; }
-int dl_version(void) { return 300; }  // ABI version: _hip.py ABI_VERSION must agree
+int dl_version(void) { return 301; }  // ABI version: _hip.py ABI_VERSION must agree
+
+// 32-bit slabs: what a workgroup's share of one row is expected to stay below, as a sum of |a| -- kSlabHeadroom mean shares of the largest row
+// L1 norm of A (deal-invariant: the grid, and with it every rounded sum, does not depend on who walks which tile), at least one max |a|.
+static int slab_refresh_bound(dl_matching* h, hipStream_t st) {
+    double l1 = -1.0;
+    int rc = launch_row_l1_max(h->nnz, h->rowidx, h->row_bytes, static_cast<const float*>(h->a), h->m, &l1, st);
+    if (rc) return rc;
+    if (l1 < 0.0) l1 = h->amax * (double)(h->row_count_max > 0 ? h->row_count_max : 1);  // (rows beyond the LDS table: the count-based bound)
+    h->slab_abound = std::max(h->amax, kSlabHeadroom * l1 / (double)(h->n_wg > 0 ? h->n_wg : 1));
+    const char* se = plan_env("DUALIP_HIP_SLAB32");
+    if (se && se[0] == 't') h->slab_abound = h->amax / 256.0;  // "tiny": the test hook -- every workgroup's shares overflow
+    return 0;
+}
 
 int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx, int idx_dtype,
                        const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj, const int32_t* col_proj,
@@ -435,9 +456,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     h->a = a;
     h->c = c;
     h->n_proj = n_proj;
-    const char* nodpp = getenv("DUALIP_HIP_NO_DPP");
+    const char* nodpp = plan_env("DUALIP_HIP_NO_DPP");
     h->use_dpp = !(nodpp && nodpp[0] == '1');
-    const char* abl = getenv("DUALIP_HIP_ABLATE");
+    const char* abl = dev_env("DUALIP_HIP_ABLATE");  // (null in the shipped library)
     h->ablate = abl ? atoi(abl) : 0;
     (void)hipGetDevice(&h->device);
     int rc = 0;
@@ -459,7 +480,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     } while (0)
 
     // developer aid: DUALIP_HIP_TIMING=1 prints the wall time of every set-up phase to stderr
-    const bool timing = getenv("DUALIP_HIP_TIMING") != nullptr;
+    const bool timing = plan_env("DUALIP_HIP_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_phase = now();
     auto phase = [&](const char* name) {
@@ -470,7 +491,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         t_phase = t;
     };
     // layout 4 (16-byte loads) needs 16-byte aligned value arrays and at least one full quad; DUALIP_HIP_LAYOUT=1 forces layout 1
-    const char* lay_env = getenv("DUALIP_HIP_LAYOUT");
+    const char* lay_env = plan_env("DUALIP_HIP_LAYOUT");
     const bool want4 = !(lay_env && lay_env[0] == '1');
     const bool aligned = (((uintptr_t)a | (uintptr_t)c) & 15u) == 0;
     h->layout = (want4 && aligned && nnz >= 1024) ? 4 : 1;
@@ -479,15 +500,15 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     std::vector<uint8_t> pid_sell;
     std::vector<uint32_t> sell_desc_h;
     if (h->layout == 4) {
-        const char* se = getenv("DUALIP_HIP_SELL");
+        const char* se = plan_env("DUALIP_HIP_SELL");
         double min_share = -1.0;  // default: 0.9, or none when columns of up to 255 non-zeros can be sliced (sell_build.hip)
-        if (const char* ms = getenv("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
+        if (const char* ms = plan_env("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
         if (!(se && se[0] == '0')) CK(sell_prepare(h, colptr, idx_dtype, col_proj, projs_host, n_proj, min_share, pid_sell, sell_desc_h, st));
     }
     // point-wise entries (box, cone, identity): their windows need not hold whole columns (pack_build.hip); DUALIP_HIP_FLAT=0 keeps
     // whole-column windows.  Element n_proj: columns with no entry.
     std::vector<uint8_t> pid_flat;
-    const char* flat_env = getenv("DUALIP_HIP_FLAT");  // 0: whole-column windows everywhere; 1: cut every 256 from the run's start; default: at multiples of 256
+    const char* flat_env = plan_env("DUALIP_HIP_FLAT");  // 0: whole-column windows everywhere; 1: cut every 256 from the run's start; default: at multiples of 256
     if (h->layout == 4 && !(flat_env && flat_env[0] == '0')) {
         const uint8_t mode = (flat_env && flat_env[0] == '1') ? 1 : 2;
         pid_flat.assign((size_t)n_proj + 1, 0);
@@ -501,7 +522,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // Window tiles are packed on the device (pack_build.hip) unless the map has BOTH instruction-bound window tiles (a simplex
     // entry that is not sliced) and memory-bound ones -- those want the host's interleaved schedule (schedule_tiles4) -- or
     // DUALIP_HIP_HOST_PACK=1 asks for the host path (kept as the independent implementation for cross-checks).
-    bool dev_pack = h->layout == 4 && !getenv("DUALIP_HIP_HOST_PACK") && n < (1ll << 31);
+    bool dev_pack = h->layout == 4 && !plan_env("DUALIP_HIP_HOST_PACK") && n < (1ll << 31);
     for (int32_t q = 0; q < n_proj && dev_pack; ++q) {
         const int k = projs_host[q].kind;
         if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q]) && n_proj > 1) dev_pack = false;
@@ -566,7 +587,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         std::vector<uint32_t> long_list;
         // compact window table (2 dwords instead of 12): every entry that can have windows is point-wise (a sliced simplex entry has
         // none: its long columns are single-column tiles).  DUALIP_HIP_COMPACT=0 keeps the 12-dword table.
-        bool compact = !pid_flat.empty() && pid_flat.back() != 0 && !(getenv("DUALIP_HIP_COMPACT") && getenv("DUALIP_HIP_COMPACT")[0] == '0');
+        bool compact = !pid_flat.empty() && pid_flat.back() != 0 && !(plan_env("DUALIP_HIP_COMPACT") && plan_env("DUALIP_HIP_COMPACT")[0] == '0');
         for (int32_t q = 0; q < n_proj && compact; ++q)
             if (!pid_flat[(size_t)q] && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q])) compact = false;
         h->desc_words = compact ? 2 : 12;
@@ -594,7 +615,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     hipDeviceProp_t prop;
     CKH(hipGetDeviceProperties(&prop, h->device));
     int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const char* wg_env = getenv("DUALIP_HIP_NUM_WG");
+    const char* wg_env = dev_env("DUALIP_HIP_NUM_WG");
     if (wg_env && atoi(wg_env) > 0) n_cu = atoi(wg_env);
     int64_t want = (h->n_tiles + h->n_sell + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
     h->n_wg = (int)(want < n_cu ? want : n_cu);
@@ -609,7 +630,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         //  re-read for the scatter -- with every reduction on the DPP unit; the whole-workgroup walker pays two barriers per reduction,
         //  ~14 us per ~2000 non-zeros on the MovieLens shape, and stalls the other fifteen wavefronts meanwhile.  Which binary a handle
         //  takes depends on the split itself (>= 1 % of the non-zeros in one-wavefront tiles), so: split at 1024, decide, split again.)
-        const char* xl_env = getenv("DUALIP_HIP_XLONG_MIN");
+        const char* xl_env = plan_env("DUALIP_HIP_XLONG_MIN");
         bool has_lane_slices = false;
         for (size_t t = 0; t + 4 <= sell_desc_h.size() && !has_lane_slices; t += 4) has_lane_slices = ((sell_desc_h[t + 2] >> 8) & 7u) != 0;
         // which binary the handle's launches take (matching_kernels.hip: launch_fused4): the second one for handles with K-lane slices (only it
@@ -617,7 +638,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         // handles free to use both (testing)
         auto takes_second_binary = [&]() {
             bool lb = h->long_nnz > 0 && h->long_nnz * 100 >= nnz;
-            if (const char* e = getenv("DUALIP_HIP_LANES_BINARY")) lb = e[0] == '1';
+            if (const char* e = plan_env("DUALIP_HIP_LANES_BINARY")) lb = e[0] == '1';
             return lb || has_lane_slices;
         };
         uint64_t xlong_min = 1024;
@@ -664,7 +685,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             wv.swap(w2);
             pv.swap(p2);
         };
-        if (!getenv("DUALIP_HIP_NO_SNAKE")) {
+        if (!dev_env("DUALIP_HIP_NO_SNAKE")) {
             snake(long_words, long_pid, (size_t)h->n_wg * (size_t)kFusedWaves);
             snake(xlong_words, xlong_pid, (size_t)h->n_wg);
         }
@@ -678,8 +699,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         // in descending order) are counted with their non-zeros + a fixed part (no measurable effect: 0 / 128 / 512 / off within noise).
         h->wg_preload.assign((size_t)(h->n_wg > 0 ? h->n_wg : 1), 0);
         uint64_t xlong_cost10 = 160, long_fixed = 128;  // (DUALIP_HIP_XLONG_COST10, DUALIP_HIP_LONG_FIXED: calibration runs)
-        if (const char* e = getenv("DUALIP_HIP_XLONG_COST10")) xlong_cost10 = strtoull(e, nullptr, 10);
-        if (const char* e = getenv("DUALIP_HIP_LONG_FIXED")) long_fixed = strtoull(e, nullptr, 10);
+        if (const char* e = dev_env("DUALIP_HIP_XLONG_COST10")) xlong_cost10 = strtoull(e, nullptr, 10);
+        if (const char* e = dev_env("DUALIP_HIP_LONG_FIXED")) long_fixed = strtoull(e, nullptr, 10);
         for (size_t t = 0; t < xlong_pid.size() && h->n_wg > 0; ++t)
             h->wg_preload[t % (size_t)h->n_wg] += xlong_cost10 * (((uint64_t)xlong_words[t * 12 + 3] << 32) | xlong_words[t * 12 + 2]) / 10;
         if (lanes_binary && long_fixed < (1ull << 40))
@@ -687,7 +708,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
                 h->wg_preload[t % (size_t)h->n_wg] += (((uint64_t)long_words[t * 12 + 3] << 32) | long_words[t * 12 + 2]) + long_fixed;
         long_words.insert(long_words.end(), xlong_words.begin(), xlong_words.end());
         long_pid.insert(long_pid.end(), xlong_pid.begin(), xlong_pid.end());
-        if (!dev_pack && !getenv("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
+        if (!dev_pack && !dev_env("DUALIP_HIP_NO_INTERLEAVE")) schedule_tiles4(short_words, short_pid, projs_host, n_proj, h->n_wg);
         h->n_short = dev_pack ? n_win_dev : (int64_t)short_pid.size();
         words4 = short_words;  // (device path: empty -- the window descriptors are already on the device)
         words4.resize(words4.size() + 12, 0u);
@@ -711,7 +732,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     phase("schedule (host)");
     // ---- LDS plan ----
     auto lds_need = [&](bool lam, bool grad) { return fused_lds_bytes(m, val_dtype, lam, grad); };
-    const char* mode_env = getenv("DUALIP_HIP_LDS_MODE");  // "both" | "grad" | "none": force a smaller plan (testing)
+    const char* mode_env = plan_env("DUALIP_HIP_LDS_MODE");  // "both" | "grad" | "none": force a smaller plan (testing)
     int max_mode = 2;
     if (mode_env) max_mode = !strcmp(mode_env, "none") ? 0 : (!strcmp(mode_env, "grad") ? 1 : 2);
     if (max_mode >= 2 && lds_need(true, true) <= kLdsBudget) {
@@ -729,7 +750,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // frequency and keep the m_hot most frequent ones in LDS; the cold tail goes through L2 gathers and global atomics.
     // DUALIP_HIP_HOT_ROWS: "0" disables the plan, "N" forces m_hot = N (testing).
     {
-        const char* hot_env = getenv("DUALIP_HIP_HOT_ROWS");
+        const char* hot_env = plan_env("DUALIP_HIP_HOT_ROWS");
         int64_t forced = hot_env ? atoll(hot_env) : -1;
         const bool allowed = h->layout == 4 && nnz > 0 && max_mode >= 2 && forced != 0;
         int64_t m_hot = 0;
@@ -757,7 +778,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             // gradient rows, stage all of it and keep fewer gradient rows: no tile gathers from L2 at all.
             // DUALIP_HIP_LAM_ALL=0 keeps the symmetric plan (m_lam = m_hot).
             const size_t vs_l = val_dtype == DL_F32 ? 4 : 8;
-            const char* la = getenv("DUALIP_HIP_LAM_ALL");
+            const char* la = plan_env("DUALIP_HIP_LAM_ALL");
             if (!(la && la[0] == '0') && forced <= 0 && (size_t)m * vs_l * 100 <= kLdsBudget * 72) {
                 int64_t lo = 0, hi = m_hot;  // most gradient rows that fit beside all m dual entries
                 while (lo < hi) {
@@ -779,7 +800,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
 
     // ---- device metadata ----
     h->row_bytes = m <= 65536 ? 2 : 4;
-    const char* row_env = getenv("DUALIP_HIP_ROW32");
+    const char* row_env = plan_env("DUALIP_HIP_ROW32");
     if (row_env && row_env[0] == '1') h->row_bytes = 4;
     CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
     const size_t win_bytes = dev_pack ? sizeof(uint32_t) * (size_t)h->desc_words * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
@@ -798,9 +819,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         CK(owned_malloc(h, (void**)&h->row_perm, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, &h->lam_perm, (size_t)m * (val_dtype == DL_F32 ? 4 : 8)));
         CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad * (size_t)kColdCopies));
-        h->cold_per_xcd = !(getenv("DUALIP_HIP_COLD_XCD") && getenv("DUALIP_HIP_COLD_XCD")[0] == '0');
+        h->cold_per_xcd = !(plan_env("DUALIP_HIP_COLD_XCD") && plan_env("DUALIP_HIP_COLD_XCD")[0] == '0');
     }
-    if (getenv("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    if (plan_env("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
@@ -944,14 +965,33 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             default: h->has_unbounded = true; break;
         }
     }
+    {   // 32-bit gradient slabs (common.h: slab32).  fp32 handles only (an fp64 handle is a parity run: its 61-bit grid stays); the whole
+        // gradient in LDS (under the hot-rows plan the cold rows' global accumulators share the grid).  DUALIP_HIP_SLAB32=0: 64-bit slabs.
+        const char* se = plan_env("DUALIP_HIP_SLAB32");
+        // Every projection must bound x itself (box, simplex): with a one-sided operator the bound is |v|'s -- (amax lmax + cmax) / gamma -- which
+        // typical elements sit orders of magnitude below, and a grid taken from it would round them away.
+        const bool can = val_dtype == DL_F32 && h->layout == 4 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg;
+        h->slab32 = can && !(se && se[0] == '0');
+        if (h->slab32) {
+            int rc_l1 = slab_refresh_bound(h, st);
+            if (rc_l1) {
+                matching_free(h);
+                return rc_l1;
+            }
+            // (the slab allocation was sized for int64: its first half holds the low words, its second half the high words)
+            h->slab_hi = static_cast<int32_t*>(h->partial) + (size_t)h->n_wg * (size_t)h->mpad;
+            CK(owned_malloc(h, (void**)&h->slab_ovf, sizeof(unsigned long long) * ((size_t)h->n_wg + 1)));
+            CKH(hipMemsetAsync(h->slab_ovf, 0, sizeof(unsigned long long) * ((size_t)h->n_wg + 1), st));
+        }
+    }
     // ---- balance of the window tiles (fused_common.h: Deal): rounds per workgroup, even to start with, adapted from the launches' stamps.
     //      Only where a round is a small share of a wavefront's work (>= kBalMinRounds rounds).  DUALIP_HIP_XCD_BALANCE=0: even deal. ----
     {
-        const char* be = getenv("DUALIP_HIP_XCD_BALANCE");
+        const char* be = plan_env("DUALIP_HIP_XCD_BALANCE");
         const int64_t S = (int64_t)h->n_wg * kFusedWaves;
         const int64_t rw = S > 0 ? (h->n_short + S - 1) / S : 0;
-        if (const char* mr = getenv("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
-        if (const char* gn = getenv("DUALIP_HIP_BALANCE_GAIN")) h->bal_gain = atof(gn) > 0.0 ? atof(gn) : h->bal_gain;
+        if (const char* mr = plan_env("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
+        if (const char* gn = dev_env("DUALIP_HIP_BALANCE_GAIN")) h->bal_gain = atof(gn) > 0.0 ? atof(gn) : h->bal_gain;
         const bool adapt = !(be && be[0] == '0') && h->n_wg >= 2 && h->n_wg <= 1024 && rw >= h->bal_min_rounds;
         if (h->layout == 4) {  // (every layout-4 handle has a table; only those that adapt have stamps)
             const size_t words = bal_table_words(h->n_wg > 0 ? h->n_wg : 1);
@@ -969,13 +1009,13 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
             CKH(hipStreamSynchronize(st));  // (tab is a host temporary)
             // ---- two-phase deal of the one-lane slices (fused4_kernel.h): handles whose WINDOWS do not adapt (too few rounds of them, or
             //      none: all-simplex maps) but whose slices are many rounds per wavefront.  First binary only; DUALIP_HIP_SELL_BALANCE=0: off. ----
-            const char* se = getenv("DUALIP_HIP_SELL_BALANCE");
+            const char* se = plan_env("DUALIP_HIP_SELL_BALANCE");
             const int64_t n_plain = h->n_sell - h->n_sell_lane_slices;
             const int64_t rs = S > 0 ? n_plain / S : 0;
             const bool sell_adapt = !(se && se[0] == '0') && !(be && be[0] == '0') && !adapt && !h->lanes_binary && h->n_sell_lane_slices == 0 && h->n_wg >= 2 && h->n_wg <= 1024 &&
                                     h->n_wg % 2 == 0 && n_plain < (1ll << 31);
             // (DUALIP_HIP_SELL_BALANCE_PPM=<share>: tests -- a fixed second phase of that share for the even workgroups, never adapted, any size)
-            const char* fe = getenv("DUALIP_HIP_SELL_BALANCE_PPM");
+            const char* fe = plan_env("DUALIP_HIP_SELL_BALANCE_PPM");
             const int64_t forced = fe ? atoll(fe) : -1;
             // (same threshold as the windows' deal: at 38 rounds per wavefront -- 10M entities, all-simplex -- the second phase is two rounds of half
             //  the launch, and its quantisation cost what the balance won: 0.1811 -> 0.1825 ms per launch, three alternations)
@@ -1005,6 +1045,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     }
 #undef CK
 #undef CKH
+    for (int i = 0; i < kNumPlanSwitches; ++i)  // what dl_matching_info(h, 2100) reports
+        if (getenv(kPlanSwitches[i])) h->switches |= 1u << i;
     *out = h;
     return 0;
 }
@@ -1014,9 +1056,27 @@ int dl_matching_destroy(dl_matching* h) {
     return 0;
 }
 
+const char* dl_switch_name(int bit) { return (bit >= 0 && bit < dl::kNumPlanSwitches) ? dl::kPlanSwitches[bit] : nullptr; }
+
 int64_t dl_matching_info(const dl_matching* h, int what) {
     if (!h) return -1;
     switch (what) {
+        case 2007: return h->slab32 ? 4 : 8;  // bytes per element of the gradient slabs
+        case 2008: {  // workgroups whose shares left 32 bits in the LAST fused launch (their high words travelled too); synchronous device read
+            if (!h->slab32) return 0;
+            std::vector<unsigned long long> ep((size_t)h->n_wg + 1);
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(ep.data(), h->slab_ovf, sizeof(unsigned long long) * ep.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            int64_t k = 0;
+            for (int w = 0; w < h->n_wg; ++w) k += ep[(size_t)w] == h->slab_epoch ? 1 : 0;
+            return k;
+        }
+        case 2100: return (int64_t)h->switches;
+        case 2101:
+#ifdef DL_DEVTOOLS
+            return 1;  // a developer build: ablation switches are live (results may be wrong on purpose)
+#else
+            return 0;
+#endif
         case 0: return h->n_tiles;
         case 1: return h->n_wg;
         case 2: return (int64_t)h->lds_bytes;
@@ -1230,6 +1290,7 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream) {
     if (h->nnz > 0) {  // max |a| scales the fixed-point gradient; max |c| as in dl_matching_update_costs
         int rc = refresh_absmax(h, h->a, &h->amax, st);
         if (!rc) rc = refresh_absmax(h, h->c, &h->cmax, st);
+        if (!rc && h->slab32) rc = slab_refresh_bound(h, st);  // (the grid of the 32-bit slabs follows the rows' L1 norms)
         if (rc) return rc;
     }
     int rc = sell_refill_values(h, st);

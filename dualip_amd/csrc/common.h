@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -21,6 +22,31 @@ int hip_fail(hipError_t e, const char* what);
         hipError_t _e = (expr);                               \
         if (_e != hipSuccess) return ::dl::hip_fail(_e, #expr); \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// environment switches
+// ---------------------------------------------------------------------------------------------------------
+// PLAN switches force one of a handle's kernel plans -- every plan computes the same function, and the GPU test-suite is re-run under
+// each of them (INTEGRATION.md lists them).  The shipped library honours them and REPORTS them: dl_matching_info(h, 2100) is the mask of
+// the ones that were set when the handle was created (bit i = dl_switch_name(i)).
+// DEVELOPER switches -- ablations that skip work and give wrong results on purpose, launch-shape and tuning constants behind the
+// measurements of profiles/ -- exist only in a library compiled with -DDL_DEVTOOLS (libdualip_hip_dev.so, built by
+// `python -m dualip_amd._build --dev` for tools/): the shipped library never reads them and compiles their branches out.
+constexpr const char* kPlanSwitches[] = {
+    "DUALIP_HIP_LAYOUT", "DUALIP_HIP_SELL", "DUALIP_HIP_SELL_MIN_SHARE", "DUALIP_HIP_SELL_LANES", "DUALIP_HIP_SELL_LANES_MIN_SHARE", "DUALIP_HIP_SELL_MERGE_SHORT",
+    "DUALIP_HIP_LANES_BINARY", "DUALIP_HIP_FLAT", "DUALIP_HIP_COMPACT", "DUALIP_HIP_HOST_PACK", "DUALIP_HIP_LDS_MODE", "DUALIP_HIP_HOT_ROWS", "DUALIP_HIP_LAM_ALL",
+    "DUALIP_HIP_ROW32", "DUALIP_HIP_COLD_XCD", "DUALIP_HIP_XLONG_MIN", "DUALIP_HIP_NO_DPP", "DUALIP_HIP_XCD_BALANCE", "DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS",
+    "DUALIP_HIP_SELL_BALANCE", "DUALIP_HIP_SELL_BALANCE_PPM", "DUALIP_HIP_FUSE_APPLY", "DUALIP_HIP_TIMING", "DUALIP_HIP_TIMELINE", "DUALIP_HIP_SLAB32",
+};
+constexpr int kNumPlanSwitches = (int)(sizeof(kPlanSwitches) / sizeof(kPlanSwitches[0]));
+const char* plan_env(const char* name);  // getenv of a name of the table above (anything else: null -- a switch is registered or it does not exist)
+#ifdef DL_DEVTOOLS
+inline const char* dev_env(const char* name) { return getenv(name); }
+#define DL_ABLATE(word, bits) ((word) & (bits))
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#define DL_ABLATE(word, bits) 0
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // wave tiles: the unit of work of one 64-lane wavefront
@@ -53,6 +79,8 @@ struct ProjDev {
 
 constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
 constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int kSlabMinWg = 128;      // 32-bit slabs: fewest workgroups of a handle that gets them
+constexpr double kSlabHeadroom = 4.0; // ... and how many mean shares of the fullest row a workgroup's share may reach before its high words travel
 constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
 constexpr int kBalTail = 64;       // balance: most rounds by which two workgroups may differ (fused_common.h: Deal, table layout)
 inline size_t bal_table_words(int n_wg) { return 4 + (size_t)n_wg + kBalTail + (size_t)kBalTail * (size_t)n_wg; }
@@ -108,6 +136,19 @@ struct dl_matching {
     bool lam_lds = false, grad_lds = false;
     size_t lds_bytes = 0;
     int64_t mpad = 0;          // row stride of the partial slabs (elements)
+    // 32-bit slabs (fp32 handles of the 256-wide layout, whole gradient in LDS, every projection bounding x): a workgroup flushes the LOW
+    // words of its 64-bit LDS accumulators, and -- only when one of them does not fit 32 bits -- the high words to `slab_hi` as well, stamping
+    // `slab_ovf[wg]` (and [n_wg]: "any") with the launch's epoch; the m-sized kernels add the low words of every slab and the high words of
+    // the stamped ones.  The fixed-point grid is chosen so that a workgroup's share of a row NORMALLY fits (bound: slab_bcnt elements of
+    // the largest row L1 norm); nothing depends on that estimate but the speed -- the integer sums are exact for any deal of the tiles.
+    // Only handles that fill the chip (>= kSlabMinWg workgroups): below, a workgroup's share IS most of a row, the grid would be the whole
+    // row's, and there is nothing to win.
+    bool slab32 = false;
+    double slab_abound = 0.0;                  // sum of |a| a workgroup's share of one row is expected to stay below: kSlabHeadroom mean shares of the
+                                               // largest row L1 norm of A (a deal-invariant property of the matrix), at least max |a|
+    int32_t* slab_hi = nullptr;                // the second half of `partial`, [n_wg][mpad]: high words (written by a workgroup only in a launch where it overflowed)
+    unsigned long long* slab_ovf = nullptr;    // owned, [n_wg + 1]: epoch of the last launch in which workgroup w overflowed; [n_wg]: any workgroup
+    unsigned long long slab_epoch = 0;         // fused launches of this handle so far
     void* partial = nullptr;   // owned: int64 fixed point, [n_wg][mpad] (grad_lds) or [1][mpad] (global atomics)
     unsigned long long* absmax_dev = nullptr;  // owned: scratch word of dl_matching_update_costs / _values (allocated on first use)
     int* shift_dev = nullptr;  // owned: fixed-point exponents of the latest launch ([0] gradient rows, [1] scalar sums)
@@ -119,7 +160,8 @@ struct dl_matching {
     long long* partial_scal = nullptr;  // owned: [n_wg][2], c.x and sum x^2 per workgroup in fixed point (exponent shift_dev[1])
     size_t owned_bytes = 0;
     bool use_dpp = true;
-    int ablate = 0;  // developer-only timing ablations, see FusedArgs
+    int ablate = 0;  // developer-only timing ablations, see FusedArgs (always 0 in the shipped library)
+    uint32_t switches = 0;  // plan switches set in the environment when the handle was created (bit i = kPlanSwitches[i])
     // "hot rows" plan (dual vector / gradient too large for the LDS): rows renumbered by frequency, the m_hot most frequent
     // ones live in LDS, the cold tail goes through L2 (gathers) and 64-bit global atomics (cold_grad)
     int64_t m_hot = 0;                // 0 = plan not in use

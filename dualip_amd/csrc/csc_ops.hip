@@ -172,6 +172,30 @@ __global__ __launch_bounds__(1024) void read_stream3_kernel(const read_vec4* __r
     if (acc == 12345.678f) *sink = acc;
 }
 
+// the three-stream shape with DEPTH steps of a lane in flight (160 bytes per lane at DEPTH 4, 320 at 8: two to four times what the fused
+// kernel keeps in flight per lane) and two workgroups' worth of wavefronts per CU when the registers allow: the probe must not be the
+// thing that runs out of outstanding requests before the memory does (round 4's two-deep probe was beaten by the kernel it judged)
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void read_stream3_deep_kernel(const read_vec4* __restrict__ pa, const read_vec4* __restrict__ pc, const read_vec2* __restrict__ pr, size_t n,
+                                                                 float* __restrict__ sink) {
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (DEPTH - 1) * stride < n; i += DEPTH * stride) {
+        read_vec4 a[DEPTH], c[DEPTH];
+        read_vec2 r[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            a[u] = __builtin_nontemporal_load(pa + i + u * stride);
+            c[u] = __builtin_nontemporal_load(pc + i + u * stride);
+            r[u] = __builtin_nontemporal_load(pr + i + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) acc += a[u][0] + c[u][0] + r[u][0];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
 static int grid_for(int64_t n, int threads) {
     const int64_t b = (n + threads - 1) / threads;
     return (int)(b > 8192 ? 8192 : (b > 0 ? b : 1));
@@ -200,19 +224,27 @@ int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, doub
     DL_HIP(hipMalloc((void**)&sink, sizeof(float)));
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    // two access shapes, the better one is reported: one stream of 16-byte loads, and three streams side by side (40 bytes per lane)
-    const size_t n3 = ((size_t)bytes / 40) & ~(size_t)2047;  // lanes x steps of the three-stream shape
+    // four access shapes, the best one is reported: one stream of 16-byte loads; three streams side by side (40 bytes per lane and step), two,
+    // four or eight steps of a lane in flight
+    const size_t n3 = ((size_t)bytes / 40) & ~(size_t)((size_t)256 * 1024 * 8 - 1);  // lanes x steps of the three-stream shapes (whole rounds at every depth)
     const char* base = (const char*)buf;
     double best_gbps = 0.0;
-    for (int shape = 0; shape < 2 && e == hipSuccess; ++shape) {
+    for (int shape = 0; shape < 4 && e == hipSuccess; ++shape) {
+        if (shape > 0 && n3 == 0) break;
         float best = 1e30f;
         const double moved = shape == 0 ? (double)bytes : (double)n3 * 40.0;
         for (int r = 0; r <= reps && e == hipSuccess; ++r) {  // (first pass untimed)
             e = hipEventRecord(e0, st);
             if (shape == 0)
                 hipLaunchKernelGGL(read_stream_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)buf, (size_t)bytes / 16, sink);
-            else
+            else if (shape == 1)
                 hipLaunchKernelGGL(read_stream3_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
+                                   (const read_vec2*)(base + n3 * 32), n3, sink);
+            else if (shape == 2)
+                hipLaunchKernelGGL(read_stream3_deep_kernel<4>, dim3(512), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
+                                   (const read_vec2*)(base + n3 * 32), n3, sink);
+            else
+                hipLaunchKernelGGL(read_stream3_deep_kernel<8>, dim3(256), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
                                    (const read_vec2*)(base + n3 * 32), n3, sink);
             if (e == hipSuccess) e = hipEventRecord(e1, st);
             if (e == hipSuccess) e = hipEventSynchronize(e1);

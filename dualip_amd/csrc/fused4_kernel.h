@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     // 2.434 -> 2.346).  Round 2 had restricted it to the both-in-LDS plan after one build of the no-LDS plan returned wrong sums with
     // it: that was a code-generation defect -- a VGPR spill placed ahead of an exec restore, DESIGN.md section 8 -- which the build now
     // screens every object for (dualip_amd/_build.py: _spill_defects).
-    const bool sell_first = !(g.ablate & 128) && ((wave >> 2) & 1);
+    const bool sell_first = !DL_ABLATE(g.ablate, 128) && ((wave >> 2) & 1);
     Deal dealw;
     uint32_t kw = 0;                            // round
     uint32_t ti = n_tiles, ti_next = n_tiles;   // schedule slots of the current / next tile (n_tiles: none)
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
     const WgCtx<T> w = fused_prologue<T, LAM_LDS, GRAD_LDS>(g, smem, tid, lane, wave, wg);
     // (developer aid, second binary only: DUALIP_HIP_ABLATE = 4096 / 8192 / 12288 moves stamp 1 behind the workgroup-walked columns /
     //  the single-column tiles / the K-lane slices -- with a workgroup barrier, so it is the slowest wavefront's time)
-    const int stamp_at = LANES ? ((g.ablate >> 12) & 3) : 0;
+    const int stamp_at = LANES ? (DL_ABLATE(g.ablate, 3 << 12) >> 12) : 0;
     if (stamp_at == 0) stamp(g, wg, tid, 1);
     unsigned long long* bst = kernarg_args(g).bal_stamps;
     if (bst && tid == 0) bst[4 * (size_t)wg] = wall_clock64();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             // flight at once, the values kept in registers, straight-line passes, reductions on the DPP unit
             // (up to 1024 non-zeros the values stay in registers across the passes; 1025 .. 2048: the RELOAD variants -- only the clamped
             //  values stay, a / c / rows are re-read for the scatter -- still one wavefront, every reduction on the DPP unit, no barrier)
-            if (is_simplex_kind(pl.kind) && len <= 2048 && !(gk.ablate & 1024)) {
+            if (is_simplex_kind(pl.kind) && len <= 2048 && !DL_ABLATE(gk.ablate, 1024)) {
                 const int L = (int)len, H = (L + 63) >> 6, Hmin = L >> 6;
                 const uint64_t kx = (((uint64_t)rl(dvl, 5) << 32) | rl(dvl, 4)) & ((1ull << 40) - 1);  // the column's place in the caller's order (primal)
                 const int len_lane = (L - lane + 63) >> 6;

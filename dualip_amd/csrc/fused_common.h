@@ -31,6 +31,11 @@ struct FusedArgs {
     int64_t m;
     int64_t mpad;
     int64_t nnz;
+    int slab32;                          // 1: the gradient slabs are int32 low words [n_wg][mpad] (+ high words on overflow): common.h
+    double slab_abound;                  //    sum of |a| a workgroup's share of one row is expected to stay below (times the bound of x: the grid's 2^30)
+    int32_t* slab_hi;                    //    [n_wg][mpad] high words
+    unsigned long long* slab_ovf;        //    [n_wg + 1] epochs (common.h)
+    unsigned long long slab_epoch;       //    this launch's
     int32_t n_proj;
     uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
     uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
@@ -311,7 +316,7 @@ __device__ __forceinline__ void process_long_tile(const FusedArgs<T>& g, const P
     //  arrays in every pass; the benchmark's binary stays at 8: with 16 its hot loop lost its last registers, 20 bytes of scratch, and the
     //  build refuses that)
     constexpr int kRB = WG ? KRB_WG : 16;
-    const bool cached = len <= (uint64_t)kStride * kRB && !(g.ablate & 8);
+    const bool cached = len <= (uint64_t)kStride * kRB && !DL_ABLATE(g.ablate, 8);
     T vr[kRB];
     if (is_simplex) {
         T S = (T)0, v1 = (T)(-INFINITY);
@@ -602,11 +607,15 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
             const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
             xmax = ub > xmax ? ub : xmax;
         }
-        const double bound = g.amax * xmax * g.row_count_max;
+        // 32-bit slabs: the grid is taken from what ONE WORKGROUP's share of a row is expected to stay below (slab_abound: a share of the largest
+        // row L1 norm of A, times the bound of x), so that
+        // the low word of its 64-bit LDS accumulator normally IS the value; a share that does not fit sends its high word too (epilogue)
+        const bool s32 = sizeof(T) == 4 && g.slab32;
+        const double bound = s32 ? xmax * g.slab_abound : g.amax * xmax * g.row_count_max;
         int e = 0;
         if (bound > 0.0 && bound < 1.7e308) (void)frexp(bound, &e);
         else if (bound > 0.0) e = 1100;  // (an overflowing bound: the coarsest grid, not exponent 0)
-        shift = FixedBits<T>::value - e;
+        shift = (s32 ? 30 : FixedBits<T>::value) - e;
         shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
         shift2 = scalar_shift((double)g.nnz, g.cmax, xmax);
     }
@@ -637,6 +646,8 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
     const long long ssq = wave_allreduce(acc.ssq, OpAdd());
     if constexpr (FAIR) fair = wave_allreduce(fair, OpAdd());
     long long* red_i = reinterpret_cast<long long*>(w.red_s);
+    uint32_t* slab_oflag = reinterpret_cast<uint32_t*>(w.red_s + 48);  // (a free word of the 512-byte scratch: [0, 48) the sums below, [56] the second binary's claim counters)
+    if (tid == 0) *slab_oflag = 0u;
     if (lane == 0) {
         red_i[2 * wave] = obj;
         red_i[2 * wave + 1] = ssq;
@@ -667,10 +678,50 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
         //  faulted; found with rocgdb's precise memory mode, tools/gdb_fault.sh)
         //  Only the second binary does (REREAD): the benchmark's kernel keeps the values it has in registers -- the dependent scalar load
         //  at the end of every launch measured +0.7 ... 1.5 % at 10M entities, all-box.
-        const FusedArgs<T>& gk = REREAD ? kernarg_args(g) : g;
-        long long* slab = gk.partial + (int64_t)wg * gk.mpad;
-        const int64_t m_lds = gk.m_hot > 0 ? gk.m_hot : gk.m;
-        for (int64_t i = tid; i < m_lds; i += kFusedThreads) slab[i] = w.grad_s[i];
+        // 32-bit slabs (fp32 handles; the branch does not exist in the fp64 kernels): the low words of the accumulators -- half the bytes out,
+        // and half of them back in for the slab sums -- and, only when some share of this workgroup does not fit them, the high words too,
+        // stamped with this launch's epoch (common.h: slab32).  Every 64-bit argument is (re-)read in the scope that uses it.
+        bool flushed = false;
+        if constexpr (sizeof(T) == 4) {
+            if ((REREAD ? kernarg_args(g).slab32 : g.slab32) != 0) {  // (wave-uniform)
+                flushed = true;
+                int ovf = 0;
+                {
+                    const FusedArgs<T>& ga = REREAD ? kernarg_args(g) : g;
+                    const int64_t m_lds = ga.m_hot > 0 ? ga.m_hot : ga.m;
+                    int32_t* slab = reinterpret_cast<int32_t*>(ga.partial) + (int64_t)wg * ga.mpad;
+                    for (int64_t i = tid; i < m_lds; i += kFusedThreads) {
+                        const long long v = w.grad_s[i];
+                        const int32_t lo = (int32_t)v;
+                        slab[i] = lo;
+                        ovf |= (long long)lo != v;
+                    }
+                }
+                // (workgroup-wide OR through the scratch word zeroed above -- __syncthreads_or brings 256 bytes of static LDS of its own, which the
+                //  160 KB plan has no room for)
+                if (__any(ovf) && lane == 0) *slab_oflag = 1u;
+                __syncthreads();
+                if (*slab_oflag) {  // rare
+                    const FusedArgs<T>& gb = kernarg_args(g);
+                    const int64_t m_lds = gb.m_hot > 0 ? gb.m_hot : gb.m;
+                    int32_t* hi = gb.slab_hi + (int64_t)wg * gb.mpad;
+                    for (int64_t i = tid; i < m_lds; i += kFusedThreads) {
+                        const long long v = w.grad_s[i];
+                        hi[i] = (int32_t)((v - (long long)(int32_t)v) / 4294967296ll);  // (exact: the difference is a multiple of 2^32)
+                    }
+                    if (tid == 0) {
+                        gb.slab_ovf[wg] = gb.slab_epoch;
+                        gb.slab_ovf[gridDim.x] = gb.slab_epoch;
+                    }
+                }
+            }
+        }
+        if (!flushed) {
+            const FusedArgs<T>& gk = REREAD ? kernarg_args(g) : g;
+            const int64_t m_lds = gk.m_hot > 0 ? gk.m_hot : gk.m;
+            long long* slab = gk.partial + (int64_t)wg * gk.mpad;
+            for (int64_t i = tid; i < m_lds; i += kFusedThreads) slab[i] = w.grad_s[i];
+        }
     }
 }
 

@@ -190,18 +190,18 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs
             eq_row[q] = (kind == DL_PROJ_SIMPLEX_EQ && g.eq_heights) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
             any_simplex = any_simplex || smp[q];
             T lam = (T)1;
-            if (!(g.ablate & 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
+            if (!DL_ABLATE(g.ablate, 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
             const T t1 = (T)(cur.a[q] * lam);          // sparse_utils.py:79
             v[q] = (T)(t1 + (T)(s * cur.c[q]));        // matching.py:66,142
-            x[q] = (g.ablate & 4) ? v[q] : project_pointwise(v[q], pj[q]);
+            x[q] = DL_ABLATE(g.ablate, 4) ? v[q] : project_pointwise(v[q], pj[q]);
         }
-        if (any_simplex && !(g.ablate & 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x, eq_row);
+        if (any_simplex && !DL_ABLATE(g.ablate, 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x, eq_row);
         T o32 = (T)0, q32 = (T)0;
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             const T xq = valid[q] ? x[q] : (T)0;
             const T ax = (T)(cur.a[q] * xq);
-            if (ax != (T)0 && !(g.ablate & 1)) scatter_fixed(gacc, cur.r[q], ax, scale);
+            if (ax != (T)0 && !DL_ABLATE(g.ablate, 1)) scatter_fixed(gacc, cur.r[q], ax, scale);
             o32 = (T)(o32 + (T)(cur.c[q] * xq));
             q32 = (T)(q32 + (T)(xq * xq));
             x[q] = xq;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
                                                                       const int* __restrict__ shift_in, int n_slabs, int n_scal, int64_t m, int64_t mpad,
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
                                                                       const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
-                                                                      int accumulate) {
+                                                                      int accumulate, int slab32, const int32_t* __restrict__ slab_hi,
+                                                                      const unsigned long long* __restrict__ slab_ovf, unsigned long long slab_epoch) {
     unsigned long long pushed_h = 0ull;  // hashes of what this thread pushed (comm.h: the payload checksum the flag will carry)
     auto emit = [&](int64_t i, double v) {
         if constexpr (MODE == 0) packed[i] = v;
@@ -306,15 +307,26 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         }
         // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
         constexpr int kU = 8, kStride = kRedThreads / kRedRows;
-        for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
-            long long v[kU];
+        auto sum_slabs = [&](auto* slabs) {  // (int32 slabs of handles with slab32, common.h; else int64)
+            for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
+                long long v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int w = w0 + kStride * u;
-                v[u] = partial[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+                for (int u = 0; u < kU; ++u) {
+                    const int w = w0 + kStride * u;
+                    v[u] = (long long)slabs[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
             }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
+        };
+        if (slab32) {
+            sum_slabs(reinterpret_cast<const int32_t*>(partial));
+            if (in_slabs && slab_ovf[n_slabs] == slab_epoch) {  // (uniform, rare) some workgroup's shares left 32 bits in this launch: their high words
+                for (int w0 = ws; w0 < n_slabs; w0 += kStride)
+                    if (slab_ovf[w0] == slab_epoch) acc += (long long)slab_hi[(int64_t)w0 * mpad + rc] * 4294967296ll;
+            }
+        } else {
+            sum_slabs(partial);
         }
         shi[tid] = acc;
         __syncthreads();
@@ -376,6 +388,51 @@ int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* o
     if (val_dtype == DL_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(threads), 0, st, n, (const float*)v, out_bits);
     else hipLaunchKernelGGL(absmax_kernel<double>, dim3(blocks), dim3(threads), 0, st, n, (const double*)v, out_bits);
     DL_HIP(hipGetLastError());
+    return 0;
+}
+
+// max_i sum_{k in row i} |a_k| (one-off, for handles with 32-bit slabs: the fixed-point grid is taken from it -- common.h: slab32).  A bound's
+// estimate, so float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused
+// kernel's LDS), flushed with float atomics, reduced to one maximum (floats >= 0 order like their bit patterns) by the last block.
+constexpr int kRowL1Max = 16384;
+template <class RowT>
+__global__ __launch_bounds__(1024) void row_l1_kernel(int64_t nnz, const RowT* __restrict__ rows, const float* __restrict__ a, int m, float* __restrict__ sums) {
+    __shared__ float acc[kRowL1Max];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) atomicAdd(&acc[(uint32_t)rows[k]], fabsf(a[k]));
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += blockDim.x)
+        if (acc[i] != 0.f) atomicAdd(&sums[i], acc[i]);
+}
+__global__ void row_l1_max_kernel(int m, const float* __restrict__ sums, unsigned int* __restrict__ out_bits) {
+    float mx = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) mx = fmaxf(mx, sums[i]);
+    mx = wave_allreduce(mx, OpMax());
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(mx));
+}
+// *out_host = the largest row L1 norm of the fp32 values `a` (rows: the handle's re-encoded indices); -1 when the rows do not fit the LDS table
+int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, hipStream_t st) {
+    *out_host = -1.0;
+    if (m <= 0 || m > kRowL1Max || nnz <= 0) return 0;
+    float* sums = nullptr;
+    DL_HIP(hipMalloc((void**)&sums, sizeof(float) * ((size_t)m + 1)));
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * ((size_t)m + 1), st);
+    if (e == hipSuccess) {
+        const int64_t b64 = (nnz + 1023) / 1024;
+        const int blocks = (int)(b64 > 256 ? 256 : b64);
+        if (row_bytes == 2) hipLaunchKernelGGL(row_l1_kernel<uint16_t>, dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, sums);
+        else hipLaunchKernelGGL(row_l1_kernel<uint32_t>, dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, sums);
+        hipLaunchKernelGGL(row_l1_max_kernel, dim3(16), dim3(256), 0, st, (int)m, sums, reinterpret_cast<unsigned int*>(sums + m));
+        e = hipGetLastError();
+    }
+    float mx = 0.f;
+    if (e == hipSuccess) e = hipMemcpyAsync(&mx, sums + m, sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(sums);
+    if (e != hipSuccess) return hip_fail(e, "row L1 norms");
+    *out_host = (double)mx;
     return 0;
 }
 
@@ -673,7 +730,7 @@ bool matching_can_fuse_apply(const dl_matching* h) {
     // dependent memory latency at its head: measured -4.5 % per iteration at 1M entities (10 tiles per wavefront; 44.8 -> 42.8 us,
     // four pairs on one box), +-1 % at 10M (95), neutral at 12.5M (fused_common.h: fused_prologue).
     constexpr int64_t kFuseApplyRounds = 32;
-    const char* e = getenv("DUALIP_HIP_FUSE_APPLY");
+    const char* e = plan_env("DUALIP_HIP_FUSE_APPLY");
     bool on = h->n_wg > 0 && (h->n_tiles + h->n_sell) < kFuseApplyRounds * (int64_t)h->n_wg * kFusedWaves;
     if (e && e[0] == '1') on = true;
     if (e && e[0] == '0') on = false;
@@ -704,6 +761,11 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.m = h->m;
     args.mpad = h->mpad;
     args.nnz = h->nnz;
+    args.slab32 = h->slab32 ? 1 : 0;
+    args.slab_abound = h->slab_abound;
+    args.slab_hi = h->slab_hi;
+    args.slab_ovf = h->slab_ovf;
+    args.slab_epoch = ++h->slab_epoch;
     args.n_proj = h->n_proj;
     args.n_tiles = (uint32_t)(h->layout == 4 ? h->n_short : h->n_tiles);
     args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short - h->n_xlong : 0);
@@ -823,7 +885,7 @@ int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* pu
     auto kern = mode == 0 ? reduce_partials_kernel<0> : (mode == 1 ? reduce_partials_kernel<1> : reduce_partials_kernel<2>);
     hipLaunchKernelGGL(kern, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial), h->partial_scal, h->shift_dev, n_slabs,
                        h->n_wg, h->m, h->mpad, packed, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad, h->fair ? h->dense_ax : nullptr, pa,
-                       push_accumulate);
+                       push_accumulate, h->slab32 ? 1 : 0, h->slab_hi, h->slab_ovf, h->slab_epoch);
     DL_HIP(hipGetLastError());
     return 0;
 }

@@ -141,7 +141,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     uint32_t r[KEEP];
     // (developer-only timing ablations, K-lane / in-place slices of the second binary only -- results are wrong on purpose:
     //  DUALIP_HIP_ABLATE bit 14 = no cold-row scatter, 15 = no scatter at all, 16 = no Newton passes, 17 = no cold-row gather)
-    constexpr bool DEVAB = KLOG > 0;
+    constexpr bool DEVAB = DL_ABLATE(1, 1) && KLOG > 0;  // (false in the shipped library: the branches below are compiled out)
     const int ab = DEVAB ? kernarg_args(g).ablate : 0;
     // Hot-rows plan: a row >= m_hot has its dual entry in global memory (L2).  Round 3 read it under a per-element branch
     // (`row < m_hot ? lam_s[row] : s * lambda[row]`): every step of a slice then waits for its own L2 round trip at the branch's join
@@ -257,7 +257,7 @@ __device__ __forceinline__ void sell_slice(const FusedArgs<T>& g, const WgCtx<T>
     // threshold), so the vertex test is unchanged.
     const T th0 = (T)(mx - pj.z);
     T theta0 = th0;
-    if (!(g.ablate & 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
+    if (!DL_ABLATE(g.ablate, 32)) theta0 = tmax(th0, div_exactish((T)(sall - pj.z), (T)(len > 0 ? len : 1)));
     // (supports are counted in integers: the compiler folds two members' worth of compare masks into one add-with-carry, so a
     //  step of a pass costs four vector instructions -- compare, select, add, count -- instead of five with a float counter)
     typedef uint32_t CntT;

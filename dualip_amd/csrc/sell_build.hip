@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(uint32_t n_slices, const
 // the cheapest slices) was measured on one box, three repetitions each (tools/ab.sh bench): 100M mixed 1.677-1.685 ms against
 // 1.654-1.660 ms ascending, 12.5M 0.224-0.230 against 0.221-0.224 -- slower.  DUALIP_HIP_SELL_ORDER=desc keeps it reachable.
 static bool sell_descending() {
-    const char* e = getenv("DUALIP_HIP_SELL_ORDER");
+    const char* e = dev_env("DUALIP_HIP_SELL_ORDER");
     return e && e[0] == 'd';
 }
 
@@ -152,7 +152,7 @@ static void sell_plan(const unsigned long long* hist, const unsigned long long* 
         // table is dealt by cost and claimed dynamically.  (Heights below 9 run the 9-step variant: a few slices' worth of padding.)
         uint64_t n_short = 0;
         for (int l = 1; l <= kSellMaxH; ++l) n_short += hp[l];
-        const char* me = getenv("DUALIP_HIP_SELL_MERGE_SHORT");  // 0: never (testing: both kinds of slices in one small handle)
+        const char* me = plan_env("DUALIP_HIP_SELL_MERGE_SHORT");  // 0: never (testing: both kinds of slices in one small handle)
         const bool merge_short = lanes_entry && n_short <= 64ull * 4096ull && !(me && me[0] == '0');
         for (int kc = 0; kc < n_classes; ++kc) {
             const int k = down ? n_classes - 1 - kc : kc;
@@ -228,10 +228,10 @@ static int sell_prepare_typed(dl_matching* h, const IdxT* colptr, const int32_t*
     uint64_t n_cols = 0, n_elems = 0, n_nnz = 0, n_lane_cols = 0;
     // K lanes per column for the columns of 25 .. 512 non-zeros (sell.h) unless DUALIP_HIP_SELL_LANES=0, for the entries in which they
     // hold at least DUALIP_HIP_SELL_LANES_MIN_SHARE (default 1 %) of the non-zeros (sell_plan).
-    const char* le = getenv("DUALIP_HIP_SELL_LANES");
+    const char* le = plan_env("DUALIP_HIP_SELL_LANES");
     const bool lanes_on = !(le && le[0] == '0');
     double lane_share = 0.01;
-    if (const char* ls = getenv("DUALIP_HIP_SELL_LANES_MIN_SHARE")) lane_share = atof(ls);
+    if (const char* ls = plan_env("DUALIP_HIP_SELL_LANES_MIN_SHARE")) lane_share = atof(ls);
     sell_plan(stats_h.data(), stats_h.data() + (size_t)kSellPidSlots * kSellBins, projs, n_proj, col_proj == nullptr, min_share, lanes_on, lane_share, pid_sell_out, desc, &n_cols,
               &n_elems, &n_nnz, &n_lane_cols);
     if (n_cols == 0 || n_cols >= (1ull << 32) || desc.size() / kSellDescWords >= (1ull << 31)) {
@@ -311,7 +311,7 @@ static int sell_finish_typed(dl_matching* h, const IdxT* colptr, const int32_t* 
     std::vector<uint32_t> rotated;
     const uint32_t* desc_up = desc.data();
     {
-        const char* te = getenv("DUALIP_HIP_SELL_TAIL");
+        const char* te = dev_env("DUALIP_HIP_SELL_TAIL");
         const uint64_t S = (uint64_t)(h->n_wg > 0 ? h->n_wg : 1) * (uint64_t)kFusedWaves;
         std::vector<uint32_t> lanes, plain;
         for (size_t t = 0; t + kSellDescWords <= desc.size(); t += kSellDescWords) {

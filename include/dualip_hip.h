@@ -130,8 +130,18 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
  * 2003 rows whose DUAL entry the hot-rows plan stages in LDS (>= what 9 reports; = m when the whole dual vector fits: no tile gathers
  *      from L2), 2004 launches take the fused kernel's second binary (K-lane / in-place slices, dynamic deal inside a workgroup),
  * 2005 share (ppm) of the one-lane slices that only the early-finishing half of the workgroups walks (two-phase deal of handles whose
- *      window tiles do not adapt, e.g. all-simplex maps; -1: even deal; synchronous device read), 2006 updates of that share so far. */
+ *      window tiles do not adapt, e.g. all-simplex maps; -1: even deal; synchronous device read), 2006 updates of that share so far,
+ * 2007 bytes per element of the per-workgroup gradient slabs (8; 4 for fp32 handles with the whole gradient in LDS whose projections all bound
+ *      x: a workgroup flushes the low words of its 64-bit accumulators and, only when a share does not fit 32 bits, the high words too --
+ *      the slab flush and the slab sums normally move half the bytes; the same exact integer sums), 2008 workgroups that sent high words
+ *      in the last fused launch (synchronous device read),
+ * 2100 mask of the PLAN switches (environment variables that force one of the handle's kernel plans -- every plan computes the same
+ *      function) that were set when the handle was created: bit i = dl_switch_name(i),
+ * 2101 1 for a developer build of the library (-DDL_DEVTOOLS: ablation switches that skip work are live), 0 for the shipped one. */
 int64_t dl_matching_info(const dl_matching* h, int what);
+/* Name of plan switch `bit` (0 .. count-1), NULL beyond the last: the only environment variables the kernels' side of the shipped
+ * library reads, besides DUALIP_COMM_TIMEOUT_MS. */
+const char* dl_switch_name(int bit);
 
 /* The local part of calculate() -- K1..K5 of the reference in ONE pass over the CSC arrays
  * (matching.py:116-161 with b_vec=None; sparse_utils.py:54-85 left_multiply_sparse, :26-51 elementwise_csc,

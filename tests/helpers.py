@@ -300,3 +300,25 @@ def verify_at_size(dtype_name, gamma, inp, pm_local, f, local, lam, rank=0, worl
         note("duals identical on all ranks (byte checksum spread)", float(hi_ - lo_), 0.0)
     torch.cuda.synchronize()
     return out
+
+
+def gather_results(procs, q, timeout=420):
+    """One result per worker process from a multiprocessing SimpleQueue -- WITHOUT blocking forever when a worker dies before it reports
+    (a bare ``q.get()`` does: the first world-8 run of this suite sat in one until the box's time limit).  Raises as soon as a worker has
+    exited with a non-zero code, or after ``timeout`` seconds, and ends the surviving workers (they would otherwise wait for the dead one
+    inside a collective)."""
+    import time
+
+    out, t0 = [], time.time()
+    while len(out) < len(procs):
+        if not q.empty():
+            out.append(q.get())
+            continue
+        failed = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        if failed or time.time() - t0 > timeout:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f"{len(out)} of {len(procs)} workers reported; exit codes {[p.exitcode for p in procs]}" + ("" if failed else f" (no report within {timeout} s)"))
+        time.sleep(0.05)
+    return out

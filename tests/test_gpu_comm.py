@@ -17,6 +17,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests.helpers import gather_results
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -79,7 +81,7 @@ def test_p2p_allreduce_is_exact_under_uneven_load(world, backend, expect, fail):
     procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, q, backend, expect, fail)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get() for _ in procs]
+    got = gather_results(procs, q)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -164,8 +166,7 @@ def test_sharded_c_loop_matches_reference_goldens(kind, world):
     for p in procs:
         p.start()
     out = {}
-    for _ in procs:
-        rank, log, dual, backend, exchanges = q.get()
+    for rank, log, dual, backend, exchanges in gather_results(procs, q):
         out[rank] = (log, dual, backend, exchanges)
     for p in procs:
         p.join(timeout=180)
@@ -347,7 +348,7 @@ def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops(world, flipp
     procs = [ctx.Process(target=_fault_allreduce_worker, args=(r, world, port, q, flipper, flip_victim, staler, stale_victim)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict((r, (ev, c)) for r, ev, c in [q.get() for _ in procs])
+    got = dict((r, (ev, c)) for r, ev, c in gather_results(procs, q))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -433,7 +434,7 @@ def test_damaged_exchange_inside_the_c_loop_degrades_or_raises_on_every_rank(fus
     procs = [ctx.Process(target=_fault_loop_worker, args=(r, 2, port, fuse, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get() for _ in procs)
+    got = dict(gather_results(procs, q))
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0

@@ -86,8 +86,8 @@ def test_objective_and_maximizer_on_cpu_tensors_scala_known_answers():
     _all_cpu(one)
     on_device = f.calculate(lam.to(f.device), gamma=1e-3, save_primal=True)
     assert on_device.dual_gradient.is_cuda and torch.equal(on_device.dual_gradient.cpu(), one.dual_gradient)  # same launch, same bits
-    solver = AcceleratedGradientDescent(max_iter=30, gamma=1e-3, initial_step_size=1e-5, max_step_size=0.1, iteration_callback=False)
-    res = solver.maximize(f, lam)
+    solver = AcceleratedGradientDescent(max_iter=30, gamma=1e-3, iteration_callback=False)
+    res = solver.maximize(f, 0.1 * torch.ones(p["m"], dtype=torch.float32))  # (the reference test's start and default step sizes)
     _all_cpu(res)
     for it, want in SCALA_GOLDEN:
         assert abs(res.dual_objective_log[it - 1] - want) < 2e-4 * abs(want), (it, res.dual_objective_log[it - 1], want)

@@ -265,6 +265,71 @@ def test_results_are_bit_reproducible():
         assert torch.equal(g, outs[0][0]) and torch.equal(x, outs[0][1]) and o == outs[0][2]
 
 
+def test_32_bit_gradient_slabs_are_the_same_exact_sums(monkeypatch):
+    """fp32 handles with the whole gradient in LDS whose projections all bound x flush their per-workgroup gradient slabs as int32 LOW words
+    of the 64-bit LDS accumulators (dl_matching_info 2007) -- and, only for a workgroup one of whose shares does not fit 32 bits, the high
+    words too, stamped with the launch's epoch.  The fixed-point grid is taken from what a workgroup's share of a row is expected to stay
+    below; nothing but the speed depends on that estimate.  Checked: bit-identical run to run and for ANY deal of the tiles (even / adapted);
+    within fp32 rounding of the 64-bit-slab result and of the oracle; the overflow path (DUALIP_HIP_SLAB32=tiny: every workgroup overflows)
+    gives the same sums on its finer grid; fp64 handles and one-sided projections keep 64-bit slabs; the honoured switches are reported."""
+    import os
+
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SLAB32") is not None or os.environ.get("DUALIP_HIP_LDS_MODE") in ("grad", "none"):
+        pytest.skip("states the default plan of the 256-wide layout")
+    m, n = 500, 120_000  # (enough tiles for >= 128 workgroups: smaller handles keep 64-bit slabs -- a workgroup's share would be most of a row)
+    p = _random_problem(m, n, 10, seed=77, long_cols=[(11, 300), (39_000, 90)])
+    pm = {"box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=range(0, n // 2)), "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=range(n // 2, n))}
+    entries, col_proj = [("box", {"lower": 0.0, "upper": 1.0}), ("simplex", {"z": 1.0})], np.repeat(np.array([0, 1], dtype=np.int32), n // 2)
+    lam_np = np.random.default_rng(3).uniform(0, 0.02, m)
+    lam = torch.from_numpy(lam_np).float().to(DEV)
+    kw = dict(max_iter=40, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.02)
+        for k in env:
+            monkeypatch.delenv(k)
+        r = f.calculate(lam, save_primal=True)
+        out = (r.dual_gradient.clone(), r.primal_var.clone(), float(r.dual_objective), f.info())
+        res = AcceleratedGradientDescent(**kw).maximize(f, torch.zeros(m, dtype=torch.float32, device=DEV))
+        return out + (list(res.dual_objective_log), res.dual_val.clone(), f.info()["slab_overflows"])
+
+    g32, x32, o32, info32, log32, d32, _ = run({})
+    assert info32["slab_bytes"] == 4 and info32["workgroups"] >= 128 and info32["switches"] == [] and info32["developer_build"] == 0 and info32["slab_overflows"] == 0, info32
+    g32b, x32b, o32b, info_b, log32b, d32b, _ = run({"DUALIP_HIP_XCD_BALANCE": "0", "DUALIP_HIP_SELL_BALANCE": "0"})  # another deal, the same integers
+    assert sorted(info_b["switches"]) == ["DUALIP_HIP_SELL_BALANCE", "DUALIP_HIP_XCD_BALANCE"]
+    assert torch.equal(g32, g32b) and torch.equal(x32, x32b) and o32 == o32b and log32 == log32b and torch.equal(d32, d32b)
+    g64, x64, o64, info64, log64, d64, _ = run({"DUALIP_HIP_SLAB32": "0"})
+    assert info64["slab_bytes"] == 8 and info64["switches"] == ["DUALIP_HIP_SLAB32"]
+    assert torch.equal(x32, x64)  # (the primal does not pass through the slabs)
+    assert relerr(g32.cpu().numpy(), g64.cpu().numpy()) < 2e-7 and abs(o32 - o64) <= 1e-6 * abs(o64)
+    assert relerr(log32, log64) < 1e-6 and relerr(d32.cpu().numpy(), d64.cpu().numpy()) < 1e-5
+    # every workgroup on the overflow path: low AND high words travel, the sums are those of a (finer) grid
+    gt, xt, ot, info_t, logt, dt, ovf_t = run({"DUALIP_HIP_SLAB32": "tiny"})
+    assert info_t["slab_bytes"] == 4 and info_t["slab_overflows"] > info_t["workgroups"] // 2 and ovf_t > info_t["workgroups"] // 2, info_t
+    assert torch.equal(xt, x64) and relerr(gt.cpu().numpy(), g64.cpu().numpy()) < 2e-7 and relerr(logt, log64) < 1e-6
+    ax, obj0, ssq, x = oracle.matching_calculate(m, n, p["colptr"], p["rowidx"], p["a"], p["c"], lam_np, 0.02, entries, col_proj=col_proj, dtype=np.float32)
+    grad, obj, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam_np, p["b"], 0.02, np.float32)
+    assert relerr(g32.cpu().numpy(), grad) < RTOL["f32"] and relerr([o32], [obj]) < RTOL["f32"] * 10
+    # the developer switches do not exist in the shipped library: an ablation request changes nothing
+    monkeypatch.setenv("DUALIP_HIP_ABLATE", "7")
+    ga, xa, oa, info_a, *_ = run({})
+    monkeypatch.delenv("DUALIP_HIP_ABLATE")
+    assert torch.equal(ga, g32) and torch.equal(xa, x32) and info_a["switches"] == []
+    # who keeps 64-bit slabs: fp64 handles, maps with a one-sided operator
+    assert MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, DEV), gamma=0.02).info()["slab_bytes"] == 8
+    assert MatchingSolverDualObjectiveFunction(torch_args(p, "f32", create_projection_map("cone", {"lower": 0.0}, n), DEV), gamma=0.02).info()["slab_bytes"] == 8
+    q = _random_problem(300, 20_000, 8, seed=5)  # a handle that does not fill the chip
+    small = MatchingSolverDualObjectiveFunction(torch_args(q, "f32", create_projection_map("box", {"lower": 0.0, "upper": 1.0}, q["n"]), DEV), gamma=0.02).info()
+    assert small["workgroups"] < 128 and small["slab_bytes"] == 8, small
+
+
 def _skewed_problem(m, n, mean_deg, seed):
     """Rows drawn from a heavy-tailed popularity law (a few destinations get most of the edges)."""
     rng = np.random.default_rng(seed)

@@ -15,6 +15,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests.helpers import gather_results
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -132,8 +134,7 @@ def test_two_ranks_share_one_gpu(kind):
     for pr in procs:
         pr.start()
     out = {}
-    for _ in procs:
-        rank, log, dual, layout = q.get()
+    for rank, log, dual, layout in gather_results(procs, q):
         out[rank] = (log, dual, layout)
     for pr in procs:
         pr.join(timeout=120)
@@ -199,8 +200,7 @@ def test_generic_lp_sharded_by_variables():
     for pr in procs:
         pr.start()
     out = {}
-    for _ in procs:
-        rank, log, dual = q.get()
+    for rank, log, dual in gather_results(procs, q):
         out[rank] = (log, dual)
     for pr in procs:
         pr.join(timeout=120)

@@ -441,6 +441,11 @@ def test_build_manifest_records_what_the_screens_saw():
     assert man["benchmark_kernel"] == _build.BENCHMARK_KERNEL and "matching_fused_kernel4IftLb1ELb1ELb0ELb0ELb0" in man["benchmark_kernel"]
     assert bench["vgpr_spill_count"] == 0 and bench["scratch_bytes"] == 0 and bench["vgpr_count"] <= 128, bench
     assert len(kernels) > 60 and all(v["vgpr_count"] is not None for v in kernels.values())
+    # the fused kernels ask for all 160 KB of LDS dynamically (hipFuncAttributeMaxDynamicSharedMemorySize = kLdsBudget): a single byte of STATIC
+    # LDS -- a __shared__ array, or a builtin that brings its own (__syncthreads_or: 256 bytes) -- makes that request invalid and every handle
+    # creation fail at run time (round 5 found out on the GPU box)
+    fused = {k: v for k, v in kernels.items() if "matching_fused_kernel" in k}
+    assert len(fused) >= 20 and all(v["lds_bytes"] == 0 for v in fused.values()), {k: v["lds_bytes"] for k, v in fused.items() if v["lds_bytes"]}
 
 
 def test_build_lists_cover_every_source_and_header():

@@ -13,7 +13,7 @@ for l in sys.stdin:
     if not l.startswith('{'): continue
     d = json.loads(l); r = d['roofline']; a = d.get('aux', {}); la = a.get('late') or {}; w = a.get('whole_solve') or {}
     print('$1', 'ms/step %.4f kernel %.4f frac %.3f | late ms/step %.4f kernel %.4f | whole %.4fs %.1f it/s | read ceiling %s' % (
-        d['ms_per_step'], r['kernel_avg_ms'], r.get('frac', 0), la.get('ms_per_step', 0), la.get('kernel_avg_ms', 0), w.get('seconds', 0), w.get('iterations_per_s', 0), a.get('read_ceiling_GBps')))
+        d['ms_per_step'], r['kernel_avg_ms'], r.get('frac', 0), la.get('ms_per_step', 0), la.get('kernel_avg_ms', 0), w.get('seconds', 0), w.get('iterations_per_s', 0), a.get('read_probe_GBps')))
 "; }
 mode=$1; shift
 case $mode in
@@ -22,10 +22,10 @@ snapshot)
   (cd "$ROOT" && git archive "$rev" dualip_amd benchmark bench.py include oracle tests/helpers.py tests/__init__.py | tar -x -C "_ab/$name") && (cd "$ROOT/_ab/$name" && python -m dualip_amd._build) ;;
 bench)
   A=$1; B=$2; R=$3; shift 3; [ "$1" == "--" ] && shift
-  for i in $(seq $R); do for d in $A $B; do (cd $d && timeout 900 python bench.py "$@" --no-cpu-baseline 2>/dev/null | line "$d rep$i"); done; done ;;
+  for i in $(seq $R); do for d in $A $B; do (cd $d && timeout 900 python bench.py "$@" --no-cpu-baseline --no-traffic-fallback 2>/dev/null | line "$d rep$i"); done; done ;;
 env)
   V=$1; A=$2; B=$3; R=$4; shift 4; [ "$1" == "--" ] && shift
-  for i in $(seq $R); do for v in $A $B; do (cd $ROOT && env $V=$v timeout 900 python bench.py "$@" --no-cpu-baseline 2>/dev/null | line "$V=$v rep$i"); done; done ;;
+  for i in $(seq $R); do for v in $A $B; do (cd $ROOT && env $V=$v timeout 900 python bench.py "$@" --no-cpu-baseline --no-traffic-fallback 2>/dev/null | line "$V=$v rep$i"); done; done ;;
 movielens)
   A=$1; B=$2; R=$3
   run() { rm -rf /tmp/pm; (cd $1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -o t -- python benchmark/movielens_like.py --max-iter 300 --no-verify > /tmp/pm.log 2>&1); f=$(find /tmp/pm -name "*kernel_stats.csv" | head -1); python3 -c "

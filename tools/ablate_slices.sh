@@ -6,6 +6,7 @@
 # after the two group reductions `if (ab & (1 << 20)) { fx_add(acc, sall, mx, w.scale2); return; }`; rebuild it) -- what profiles/r04j_*, r04l_* ran.
 #   bits: 15 no scatter, 16 no Newton passes, 18 no projection, 19 no lambda gather, 20 nothing after pass 1.   ABLATES="0 65536 ..." overrides the list.
 export TMPDIR=/tmp
+export DUALIP_DEV_LIBRARY=1  # the developer build of the scratch tree (the shipped library never reads DUALIP_HIP_ABLATE)
 cd _ab/abl
 line() { python -c "
 import sys, json
@@ -16,7 +17,7 @@ for l in sys.stdin:
 "; }
 for rep in 1 2; do
 for ab in ${ABLATES:-0 65536 32768 98304 262144 294912}; do
-  DUALIP_HIP_ABLATE=$ab timeout 600 python bench.py --proj simplex --steps 30 --warmup 5 --no-verify --no-late --no-cpu-baseline 2>/dev/null | line "100M simplex ablate=$ab"
+  DUALIP_HIP_ABLATE=$ab timeout 600 python bench.py --proj simplex --steps 30 --warmup 5 --no-verify --no-late --no-cpu-baseline --no-traffic-fallback 2>/dev/null | line "100M simplex ablate=$ab"
 done
-DUALIP_HIP_ABLATE=0 timeout 600 python bench.py --proj box --steps 30 --warmup 5 --no-verify --no-late --no-cpu-baseline 2>/dev/null | line "100M box"
+DUALIP_HIP_ABLATE=0 timeout 600 python bench.py --proj box --steps 30 --warmup 5 --no-verify --no-late --no-cpu-baseline --no-traffic-fallback 2>/dev/null | line "100M box"
 done

@@ -1,5 +1,6 @@
 #!/bin/bash
 # developer aid: MovieLens-shaped problem (config 1's shape), fused-kernel time per launch under rocprofv3 for a list of settings of ONE
+# (developer switches such as DUALIP_HIP_XLONG_COST10 exist only in the developer build: export DUALIP_DEV_LIBRARY=1 for those)
 # environment switch:   bash tools/ml_sweep.sh <tree> VAR v1 v2 ...     (e.g. . DUALIP_HIP_XLONG_COST10 160 100 60)
 export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
