@@ -103,6 +103,13 @@ __device__ __forceinline__ T group_max_nonneg(T x) {
 //  pairs allocated without a single extra move: 4.3 % fewer vector instructions in the slice loop, NO difference in time on any shape,
 //  three alternations, profiles/r04i_ab_packed_slice_arithmetic_neutral.txt.  After the scalar clean-up above the slices are no longer
 //  bound by their vector instruction count.)
+// (Round 5 built the second slice in flight that DESIGN.md section 8 item 00 asked for -- for runs of full slices of one height 5 .. 9 the 3 H loads of
+//  slice k + 1 issued into a second register set BEFORE slice k is projected, descriptors two slices ahead, the loop body written twice; the device
+//  assembly waits with vmcnt(27) where it waited with vmcnt(0), no scratch, 126 VGPRs -- and measured it against the same binary with the runs
+//  switched off, same box, three alternations: 100M all-simplex 1.710 ms against 1.678 (+1.9 %), 100M mixed 1.577 against 1.560 (+1.1 %), config 3
+//  (10M simplex, gamma decay) 0.199 against 0.184 (+8 %: a wavefront's runs are three slices long there and each ends in one redundant slice load).
+//  More bytes in flight per wavefront do not raise the rate the slices stream at; removed.  profiles/r05l_ab_second_slice_in_flight_same_box.txt,
+//  the patch: profiles/r05l_second_slice_in_flight.patch.)
 // One slice.  HM = 4 * chunks >= H.  RELOAD: the value / row registers are not kept across the Newton passes; the slice is
 // read a second time (L2 / HBM) for the scatter -- tall slices, whose columns would not fit the register file otherwise.
 // KLOG: log2 of the lanes per column; `len` is the COLUMN's length, `len_lane` the number of its elements this lane holds

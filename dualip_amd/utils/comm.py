@@ -76,6 +76,7 @@ class Communicator:
                  os.environ.get("CUDA_VISIBLE_DEVICES", ""), self.device.index)
         idents = _gather(ident, group, self.world)
         shared_device = len(set(idents)) < len(idents)
+        self.shared_device = shared_device
         one_node = len({i[0] for i in idents}) == 1
         self.fallback_reason = None
         self.selftest = None  # what the creation-time soak test saw, per level tried
@@ -142,8 +143,12 @@ class Communicator:
         mailbox parities, every rank delayed by its own pseudo-random time before each push (ranks arrive in every order; a
         third of the rounds run back to back); every element must come back exact and no wait may time out."""
         # a mapping that does not carry remote stores into a running kernel shows as a timed-out wait: keep that short here
+        # (ranks that SHARE a device -- the one-GPU test harness -- are time-sliced against each other by the driver: a rank's in-kernel wait then
+        #  spans the other processes' turns; eight of them beside a test runner holding its own context overran the two seconds, and the ranks
+        #  that gave up raced ahead of the others' readers.  There the regular bound applies: the mapping is to the device's own memory.)
         user_ms = int(os.environ.get("DUALIP_COMM_TIMEOUT_MS", "0") or 0)
-        self.lib.dl_comm_set_timeout_ms(self.handle, min(user_ms, 2000) if user_ms > 0 else 2000)
+        soak_ms = (user_ms if user_ms > 0 else 20000) if getattr(self, "shared_device", False) else (min(user_ms, 2000) if user_ms > 0 else 2000)
+        self.lib.dl_comm_set_timeout_ms(self.handle, soak_ms)
         bad = ctypes.c_int64(-1)
         variant = "p2p-fenced" if int(self.lib.dl_comm_info(self.handle, 5)) == 1 else "p2p"
         try:
