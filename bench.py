@@ -318,10 +318,9 @@ def current_commit():
 
 
 def stored_traffic(args, world, lay, phys_bytes):
-    """(bytes, source) from profiles/traffic.json, or (None, why not).  A record carries the kernel layout (dl_matching_info) it was
-    measured on and the commit; it is REFUSED when today's handle is laid out differently -- a layout change that keeps the bytes
-    within 10 % must not inherit yesterday's counters.  (Records of rounds 1-3 are bare numbers: accepted within 10 % of the
-    layout's bytes and labelled as unverifiable.)"""
+    """(bytes, source) from profiles/traffic.json, or (None, why not).  A record carries the SOURCE HASH of the kernels it was measured on
+    (any kernel edit retires it, whether or not the layout moves) and the kernel layout (dl_matching_info); it is REFUSED when either differs
+    from this run's.  Bare numbers of rounds 1-3 are refused too."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         rec = json.load(open(tpath)).get(traffic_key(args, world))
@@ -339,9 +338,7 @@ def stored_traffic(args, world, lay, phys_bytes):
             return None, f"the record of commit {rec.get('commit')} was taken on another kernel layout ({diff}): refused"
         return float(rec["bytes"]), (f"profiles/traffic.json: rocprofv3 --pmc passes of this command at commit {rec.get('commit')} ({rec.get('file', 'bench.py --measure-traffic --record-traffic')}), "
                                      f"2 x FETCH_SIZE + WRITE_SIZE (gfx950 corrections), same kernel sources (hash {have[:12]}) and layout as this run")
-    if abs(float(rec) - phys_bytes) > 0.1 * phys_bytes:
-        return None, "the (round 1-3, layout-less) record is more than 10 % from this launch's bytes by construction: refused"
-    return float(rec), "profiles/traffic.json: rocprofv3 --pmc passes of this command in an earlier round (record without layout / commit: only checked to be within 10 % of the layout's bytes)"
+    return None, "the record is a bare number of rounds 1-3 (no kernel source hash, no layout): refused"
 
 
 def measure_traffic_now(child=None, extra_counters=()):

@@ -970,7 +970,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         const char* se = plan_env("DUALIP_HIP_SLAB32");
         // Every projection must bound x itself (box, simplex): with a one-sided operator the bound is |v|'s -- (amax lmax + cmax) / gamma -- which
         // typical elements sit orders of magnitude below, and a grid taken from it would round them away.
-        const bool can = val_dtype == DL_F32 && h->layout == 4 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg;
+        const bool can = val_dtype == DL_F32 && h->layout == 4 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg && h->row_count_max <= kSlabMaxRow;
         h->slab32 = can && !(se && se[0] == '0');
         if (h->slab32) {
             int rc_l1 = slab_refresh_bound(h, st);

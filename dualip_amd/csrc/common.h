@@ -79,6 +79,8 @@ struct ProjDev {
 
 constexpr int kFusedThreads = 1024;            // one workgroup per CU, 16 wavefronts
 constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int64_t kSlabMaxRow = 65536;  // 32-bit slabs: most non-zeros of a row.  Beyond, the slabs are < 0.4 % of what a launch moves (nothing to win), and a
+                                      // workgroup's share of such a row overflows 32 bits on the row-L1 grid in most launches (250M entities: all 256 did)
 constexpr int kSlabMinWg = 128;      // 32-bit slabs: fewest workgroups of a handle that gets them
 constexpr double kSlabHeadroom = 4.0; // ... and how many mean shares of the fullest row a workgroup's share may reach before its high words travel
 constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
