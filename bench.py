@@ -221,7 +221,8 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
 
     npdt = np.float32 if args.dtype == "f32" else np.float64
     threads = oracle.max_threads()
-    out = {"unit": "iterations/s", "cores": threads, "kind": "port", "extrapolated": True}
+    host_cores = os.cpu_count() or 0  # (hardware threads of the host; `cores` below = the threads each leg actually used)
+    out = {"unit": "iterations/s", "cores": threads, "host_cores": host_cores, "kind": "port", "extrapolated": True}
     # ---- C port -------------------------------------------------------------------------------------------------
     smp = _cpu_sample(args, inp, pm_local, args.cpu_sample_cols)
     m = smp["m"]
@@ -704,10 +705,24 @@ def main():
     compared = None
     if sharded and (world > 1 or emu) and not args.no_partition_compare:
         other = "reference" if args.partition != "reference" else "balanced"
-        try:  # (every rank takes the same path through here; a failure must show in the line, not cost the headline number)
+        # Rank-LOCAL work first (cutting this rank's shard can fail on one rank only: memory, an empty block), then the ranks AGREE that all of
+        # them got through it before anyone enters the collective part -- a rank that skipped the window alone would leave the others inside
+        # the communicator's first collective for ever.  A failure must show in the line, not cost the headline number.
+        local_err = None
+        try:
             bi2, nnz2, b2, ranges2 = make_shard(other)
             for bi in bi2:
                 bi.b_vec = None
+        except Exception as exc:
+            local_err = f"{type(exc).__name__}: {exc}"
+        if world > 1:
+            okt = torch.tensor([0.0 if local_err else 1.0], dtype=torch.float64, device=device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if float(okt.item()) < 1.0 and local_err is None:
+                local_err = "another rank could not cut its shard of this split"
+        try:
+            if local_err:
+                raise RuntimeError(local_err)
             f2 = MatchingSolverDualObjectiveFunctionDistributed(bi2 if nb > 1 else bi2[0], b2, args.gamma, host_device=device, comm_backend=args.comm)
             comm2 = f2.communicator()
             if emu and comm2 is not None:

@@ -54,6 +54,7 @@ size_t agd_partial_stats_bytes(int64_t m);
 int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, void* out, const dl_proj_desc* p, hipStream_t st);
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
+int cold_xcd_selftest(hipStream_t st);
 int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
 size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype);
@@ -819,7 +820,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         CK(owned_malloc(h, (void**)&h->row_perm, sizeof(int32_t) * (size_t)m));
         CK(owned_malloc(h, &h->lam_perm, (size_t)m * (val_dtype == DL_F32 ? 4 : 8)));
         CK(owned_malloc(h, (void**)&h->cold_grad, sizeof(long long) * (size_t)h->mpad * (size_t)kColdCopies));
-        h->cold_per_xcd = !(plan_env("DUALIP_HIP_COLD_XCD") && plan_env("DUALIP_HIP_COLD_XCD")[0] == '0');
+        // (one array of cold-row accumulators per XCD with L2-local atomics -- only on a device that passes the self-check of that assumption,
+        //  matching_kernels.hip: cold_xcd_selftest; DUALIP_HIP_COLD_XCD=0: the shared array with device-scope atomics)
+        h->cold_per_xcd = !(plan_env("DUALIP_HIP_COLD_XCD") && plan_env("DUALIP_HIP_COLD_XCD")[0] == '0') && cold_xcd_selftest(st) == 1;
     }
     if (plan_env("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
     int* bad_dev = nullptr;
@@ -1071,6 +1074,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
             return k;
         }
         case 2100: return (int64_t)h->switches;
+        case 2009: return h->cold_per_xcd ? 1 : 0;  // hot-rows plan: one cold-row accumulator array per XCD (self-checked at creation) / 0: one shared array
         case 2101:
 #ifdef DL_DEVTOOLS
             return 1;  // a developer build: ablation switches are live (results may be wrong on purpose)

@@ -391,6 +391,51 @@ int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* o
     return 0;
 }
 
+// ---- self-check of the per-XCD cold-row accumulators (hot-rows plan, fused_common.h) ----
+// They rest on behaviour outside the HIP / LLVM memory model: WORKGROUP-scope atomics of DIFFERENT workgroups on one address are atomic when
+// all of them run on the XCD whose L2 executes them, and HW_REG_XCC_ID & 7 names that XCD.  True of this part in SPX mode; a partition mode
+// with another XCD numbering, tgsplit, or a future part could break it silently.  So, once per device and process, before the first
+// handle relies on it: 2048 workgroups hammer 64 words of "their" XCD's copy with workgroup-scope increments, the eight copies are added
+// up, and every word must hold exactly the number of increments issued.  A lost update anywhere -> the plan falls back to ONE shared
+// array with device-scope atomics (what DUALIP_HIP_COLD_XCD=0 selects).  ~60 us, exact integers.
+constexpr int kXcdTestBlocks = 2048, kXcdTestThreads = 256, kXcdTestReps = 32, kXcdTestWords = 64;
+__global__ void cold_xcd_selftest_kernel(unsigned long long* __restrict__ copies) {
+    const unsigned int xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11)) & (unsigned int)(kColdCopies - 1);
+    typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+    glb_u64* p = (glb_u64*)(copies + (size_t)xcc * kXcdTestWords + (threadIdx.x & (kXcdTestWords - 1)));
+    for (int r = 0; r < kXcdTestReps; ++r) (void)__hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// 1: the per-XCD accumulators are safe on the current device; 0: they lost updates (or the check could not run)
+int cold_xcd_selftest(hipStream_t st) {
+    static std::atomic<int> verdict[64];  // per device ordinal: 0 unknown, 1 safe, 2 unsafe
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int slot = dev & 63;
+    const int known = verdict[slot].load(std::memory_order_relaxed);
+    if (known) return known == 1;
+    unsigned long long* copies = nullptr;
+    const size_t words = (size_t)kColdCopies * kXcdTestWords;
+    if (hipMalloc((void**)&copies, sizeof(unsigned long long) * words) != hipSuccess) return 0;
+    std::vector<unsigned long long> host(words, 0ull);
+    hipError_t e = hipMemsetAsync(copies, 0, sizeof(unsigned long long) * words, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cold_xcd_selftest_kernel, dim3(kXcdTestBlocks), dim3(kXcdTestThreads), 0, st, copies);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), copies, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(copies);
+    bool ok = e == hipSuccess;
+    const unsigned long long want = (unsigned long long)kXcdTestBlocks * (kXcdTestThreads / kXcdTestWords) * kXcdTestReps;
+    for (int w = 0; ok && w < kXcdTestWords; ++w) {
+        unsigned long long sum = 0ull;
+        for (int k = 0; k < kColdCopies; ++k) sum += host[(size_t)k * kXcdTestWords + w];
+        ok = sum == want;
+    }
+    verdict[slot].store(ok ? 1 : 2, std::memory_order_relaxed);
+    return ok ? 1 : 0;
+}
+
 // max_i sum_{k in row i} |a_k| (one-off, for handles with 32-bit slabs: the fixed-point grid is taken from it -- common.h: slab32).  A bound's
 // estimate, so float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused
 // kernel's LDS), flushed with float atomics, reduced to one maximum (floats >= 0 order like their bit patterns) by the last block.

@@ -281,6 +281,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         info["slice_balance_ppm"] = int(self._lib.dl_matching_info(self._handle, 2005))  # share of the one-lane slices dealt only to the early-finishing half of the workgroups (-1: even deal)
         info["slice_balance_updates"] = int(self._lib.dl_matching_info(self._handle, 2006))
         info["slab_bytes"] = int(self._lib.dl_matching_info(self._handle, 2007))  # per element of the per-workgroup gradient slabs (4: 32-bit fixed point)
+        info["cold_per_xcd"] = int(self._lib.dl_matching_info(self._handle, 2009))  # hot-rows plan: per-XCD cold-row accumulators (self-checked) in use
         info["slab_overflows"] = int(self._lib.dl_matching_info(self._handle, 2008))  # workgroups that sent high words too in the last launch
         mask = int(self._lib.dl_matching_info(self._handle, 2100))  # plan switches honoured at creation (DUALIP_HIP_*)
         info["switches"] = [self._lib.dl_switch_name(i).decode() for i in range(32) if (mask >> i) & 1 and self._lib.dl_switch_name(i)]

@@ -99,6 +99,7 @@ class AcceleratedGradientDescent:
         self._user_callback = iteration_callback
         self.iteration_callback = self._default_iteration_callback if iteration_callback in (None, False) else iteration_callback
         self.log_chunk = 100  # native routes: iterations between host reads of the device log
+        self.attempt = 1  # 2 while a sharded solve is being repeated after a degraded exchange (_maximize_native)
 
     # ---- small pieces shared by all routes --------------------------------------------------------------
     def _compute_beta_seq(self, max_iter: int) -> torch.Tensor:
@@ -181,10 +182,14 @@ class AcceleratedGradientDescent:
         """The device-resident loop.  A sharded run whose exchange was chosen by ``DUALIP_COMM=auto`` gets ONE more attempt when a
         payload checksum did not match under the unfenced P2P ordering: every rank moves to the fenced ordering together
         (``Communicator.degrade``) and the solve is repeated from ``initial_value`` -- it is deterministic, so nothing of the failed
-        attempt survives.  Any other failure (a timed-out wait, an explicitly chosen back-end) is raised on every rank."""
+        attempt survives.  Any other failure (a timed-out wait, an explicitly chosen back-end) is raised on every rank.
+        ``self.attempt`` is 1 during the first pass and 2 during the repeat: iteration callbacks, printed summaries and tracked metrics of
+        the failed pass are issued AGAIN from iteration 1 by the repeat (the warning says so); a callback that must not see an iteration
+        twice checks ``solver.attempt``."""
         from dualip_amd.utils.comm import CHECKSUM, ExchangeError
 
         state = (self.gamma, self.max_step_size)
+        self.attempt = 1
         try:
             return self._maximize_native_once(f, initial_value, rank)
         except ExchangeError as exc:
@@ -193,8 +198,9 @@ class AcceleratedGradientDescent:
                 raise
             import warnings
 
-            warnings.warn(f"dualip_amd: {exc}; repeating the solve with the fenced exchange")
+            warnings.warn(f"dualip_amd: {exc}; repeating the solve with the fenced exchange (iteration callbacks and logged metrics start again at iteration 1: solver.attempt == 2)")
             self.gamma, self.max_step_size = state
+            self.attempt = 2
             return self._maximize_native_once(f, initial_value, rank)
 
     def _maximize_native_once(self, f, initial_value, rank):

@@ -135,6 +135,8 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
  *      x: a workgroup flushes the low words of its 64-bit accumulators and, only when a share does not fit 32 bits, the high words too --
  *      the slab flush and the slab sums normally move half the bytes; the same exact integer sums), 2008 workgroups that sent high words
  *      in the last fused launch (synchronous device read),
+ * 2009 hot-rows plan: 1 = the cold rows add into one accumulator array PER XCD with L2-local (workgroup-scope) atomics -- taken only on a device
+ *      that passed the creation-time self-check of that assumption (exact counts under 2048 contending workgroups) --, 0 = one shared array,
  * 2100 mask of the PLAN switches (environment variables that force one of the handle's kernel plans -- every plan computes the same
  *      function) that were set when the handle was created: bit i = dl_switch_name(i),
  * 2101 1 for a developer build of the library (-DDL_DEVTOOLS: ablation switches that skip work are live), 0 for the shipped one. */

@@ -391,6 +391,9 @@ def test_hot_rows_plan(forced, monkeypatch):
             continue
         assert info["hot_rows"] == (128 if forced else info["hot_rows"]) and 0 < info["hot_rows"] < m, info
         assert info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1
+        # the per-XCD cold-row accumulators are taken only after the device passed their self-check (2048 contending workgroups, exact
+        # counts): on this part it does; DUALIP_HIP_COLD_XCD=0 (or a failed check) selects the shared array
+        assert info["cold_per_xcd"] == (0 if os.environ.get("DUALIP_HIP_COLD_XCD") == "0" else 1), info
         if whole and dn == "f32" and not forced_off:
             assert info["lambda_rows_in_lds"] == m and 1024 <= info["hot_rows"] < 12_000, info
         else:

@@ -12,7 +12,7 @@ d=json.loads([l for l in open('gpurun_out/r05p_record_$i.json') if l.startswith(
 print(r['traffic'], r['physical_bytes_per_launch'], r['kernel_avg_ms'], round(r['frac'],3), r['traffic_source'][:120])"
 done
 cp profiles/traffic.json gpurun_out/r05p_traffic.json
-for n in 250000000 200000000; do
+for n in ${BIG:-250000000 200000000}; do
   timeout 900 python bench.py --entities $n --steps 10 --warmup 3 --no-cpu-baseline --no-late --no-traffic-fallback > gpurun_out/r05p_${n}_line.json 2> gpurun_out/r05p_${n}.err
   echo "$n: rc=$?"; python -c "
 import json
