@@ -166,6 +166,8 @@ static void matching_free(dl_matching* h) {
     if (h->rowidx) (void)hipFree(h->rowidx);
     if (h->own_a) (void)hipFree(h->own_a);
     if (h->own_c) (void)hipFree(h->own_c);
+    if (h->stage_a) (void)hipFree(h->stage_a);
+    if (h->stage_c) (void)hipFree(h->stage_c);
     if (h->tiles) (void)hipFree(h->tiles);
     if (h->wg_tile_begin) (void)hipFree(h->wg_tile_begin);
     if (h->projs) (void)hipFree(h->projs);
@@ -495,7 +497,28 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     const char* lay_env = plan_env("DUALIP_HIP_LAYOUT");
     const bool want4 = !(lay_env && lay_env[0] == '1');
     const bool aligned = (((uintptr_t)a | (uintptr_t)c) & 15u) == 0;
-    h->layout = (want4 && aligned && nnz >= 1024) ? 4 : 1;
+    h->nnz_arr = nnz;
+    if (want4 && (!aligned || nnz < 1024)) {
+        // unaligned or tiny value arrays: aligned, zero-padded copies owned by the handle (common.h: stage_a) -- one layout, one kernel
+        const size_t vs_st = val_dtype == DL_F32 ? 4 : 8;
+        const int64_t npad = std::max<int64_t>(1024, (nnz + 3) & ~(int64_t)3);
+        CK(owned_malloc(h, &h->stage_a, (size_t)npad * vs_st));
+        CK(owned_malloc(h, &h->stage_c, (size_t)npad * vs_st));
+        CKH(hipMemsetAsync(h->stage_a, 0, (size_t)npad * vs_st, st));
+        CKH(hipMemsetAsync(h->stage_c, 0, (size_t)npad * vs_st, st));
+        if (nnz > 0) {
+            CKH(hipMemcpyAsync(h->stage_a, a, (size_t)nnz * vs_st, hipMemcpyDeviceToDevice, st));
+            CKH(hipMemcpyAsync(h->stage_c, c, (size_t)nnz * vs_st, hipMemcpyDeviceToDevice, st));
+        }
+        h->a_src = a;
+        h->c_src = c;
+        a = h->stage_a;
+        c = h->stage_c;
+        h->a = a;
+        h->c = c;
+        h->nnz_arr = npad;
+    }
+    h->layout = want4 ? 4 : 1;
     // column-per-lane slices for the short columns of simplex entries (sell.h): decided before the windows are packed.
     // DUALIP_HIP_SELL=0 switches them off; DUALIP_HIP_SELL_MIN_SHARE = least share of an entry's non-zeros in short columns.
     std::vector<uint8_t> pid_sell;
@@ -592,14 +615,14 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         for (int32_t q = 0; q < n_proj && compact; ++q)
             if (!pid_flat[(size_t)q] && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q])) compact = false;
         h->desc_words = compact ? 2 : 12;
-        CK(pack_device(n, nnz, colptr, idx_dtype, col_proj, n_proj, pid_sell, pid_flat, compact ? 1 : 0, &win_dev, &n_win_dev, long_list, used_dev, st));
+        CK(pack_device(n, h->nnz_arr, colptr, idx_dtype, col_proj, n_proj, pid_sell, pid_flat, compact ? 1 : 0, &win_dev, &n_win_dev, long_list, used_dev, st));
         words4 = long_list;  // single-column tiles only; split / ordered below
         for (size_t t = 0; t < long_list.size() / 12; ++t) tile_pid4.push_back(long_list[t * 12 + 10] == 0xFFFFFFFFu ? kNoProj : long_list[t * 12 + 10]);
         h->n_long = (int64_t)(long_list.size() / 12);
         h->n_tiles = n_win_dev + h->n_long;
         prefix.assign(1, 0);
     } else if (h->layout == 4) {
-        CK(pack_tiles4(n, nnz, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell, pid_flat));
+        CK(pack_tiles4(n, h->nnz_arr, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell, pid_flat));
         h->n_tiles = (int64_t)(words4.size() / 12);
     } else {
         CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
@@ -803,7 +826,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     h->row_bytes = m <= 65536 ? 2 : 4;
     const char* row_env = plan_env("DUALIP_HIP_ROW32");
     if (row_env && row_env[0] == '1') h->row_bytes = 4;
-    CK(owned_malloc(h, &h->rowidx, (size_t)nnz * (size_t)h->row_bytes));
+    CK(owned_malloc(h, &h->rowidx, (size_t)h->nnz_arr * (size_t)h->row_bytes));
+    if (h->nnz_arr > nnz) CKH(hipMemsetAsync(h->rowidx, 0, (size_t)h->nnz_arr * (size_t)h->row_bytes, st));  // (staged: the padding's rows are row 0, its values 0)
     const size_t win_bytes = dev_pack ? sizeof(uint32_t) * (size_t)h->desc_words * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
     const size_t tile_bytes = win_bytes + (h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size());
     CK(owned_malloc(h, (void**)&h->tiles, tile_bytes));
@@ -1146,7 +1170,7 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
     if (h->m < 2) return fail(DL_E_ARG, "the fairness pair needs at least its own two rows");
     // (the mirror of dl_matching_own_inputs' refusal: after it the straggler tiles read at pool offsets while f stays in the caller's order)
     if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): the fairness stream is read at the caller's offsets, which its straggler tiles no longer use -- build a new handle");
-    if ((h->n_tiles > 0 || h->n_sell > 0) && (h->layout != 4 || !h->lam_lds || !h->grad_lds))
+    if ((h->n_tiles > 0 || h->n_sell > 0) && (h->layout != 4 || !h->lam_lds || !h->grad_lds || h->stage_a))  // (a staged handle's windows read past nnz inside ITS padded copies; f has no padding)
         return fail(DL_E_STATE, "the fairness pair needs the 256-wide tile layout with the dual vector and the gradient in LDS (16-byte aligned values, nnz >= 1024)");
     if ((reinterpret_cast<uintptr_t>(f_values) & 15u) != 0) return fail(DL_E_ARG, "fairness values must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -1280,6 +1304,7 @@ int dl_matching_update_costs(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
     if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): it no longer sees the caller's arrays -- build a new handle for new values");
     hipStream_t st = (hipStream_t)stream;
+    if (h->stage_c && h->nnz > 0) DL_HIP(hipMemcpyAsync(h->stage_c, h->c_src, (size_t)h->nnz * (h->val_dtype == DL_F32 ? 4 : 8), hipMemcpyDeviceToDevice, st));  // (staged handle: its copy follows the caller's array)
     if (h->nnz > 0) {  // max |c| scales the fixed-point sums c.x / sum x^2 (fused_common.h: scalar_shift) and bounds |v| for projections that do not bound x
         int rc = refresh_absmax(h, h->c, &h->cmax, st);
         if (rc) return rc;
@@ -1291,6 +1316,11 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
     if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): it no longer sees the caller's arrays -- build a new handle for new values");
     hipStream_t st = (hipStream_t)stream;
+    if (h->stage_a && h->nnz > 0) {  // (staged handle: its copies follow the caller's arrays)
+        const size_t vs_st = h->val_dtype == DL_F32 ? 4 : 8;
+        DL_HIP(hipMemcpyAsync(h->stage_a, h->a_src, (size_t)h->nnz * vs_st, hipMemcpyDeviceToDevice, st));
+        DL_HIP(hipMemcpyAsync(h->stage_c, h->c_src, (size_t)h->nnz * vs_st, hipMemcpyDeviceToDevice, st));
+    }
     if (h->nnz > 0) {  // max |a| scales the fixed-point gradient; max |c| as in dl_matching_update_costs
         int rc = refresh_absmax(h, h->a, &h->amax, st);
         if (!rc) rc = refresh_absmax(h, h->c, &h->cmax, st);

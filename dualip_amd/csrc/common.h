@@ -110,6 +110,15 @@ struct dl_matching {
     // column tiles and in-place slices read (everything the column-per-lane slices hold lives in the handle's transposed copies already)
     void* own_a = nullptr;    // owned, val[own_count] or null
     void* own_c = nullptr;
+    // Value arrays that are not 16-byte aligned, or shorter than 1024 elements (the 256-wide tiles read 16 bytes per lane and need one full
+    // round of quads): the handle reads its OWN aligned, zero-padded copies instead (round 5: such inputs used to take a second, 64-wide
+    // kernel).  `a` / `c` then point at the copies, `a_src` / `c_src` at the caller's arrays (dl_matching_update_values / _costs copy again),
+    // and `nnz_arr` -- the length of the arrays the tiles may read with vector loads -- is the padded length.
+    void* stage_a = nullptr;  // owned, val[nnz_arr] or null
+    void* stage_c = nullptr;
+    const void* a_src = nullptr;
+    const void* c_src = nullptr;
+    int64_t nnz_arr = 0;      // elements of a / c / rowidx that exist in memory (>= nnz; == nnz unless staged)
     int64_t own_count = 0;    // elements of the owned prefix
     int64_t unsliced_end = 0; // one past the last non-zero a tile reads in place from a / c / rowidx (0: every column is sliced)
     bool owns_inputs = false;

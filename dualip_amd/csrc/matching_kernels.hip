@@ -805,7 +805,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.has_unbounded = h->has_unbounded ? 1 : 0;
     args.m = h->m;
     args.mpad = h->mpad;
-    args.nnz = h->nnz;
+    args.nnz = h->nnz_arr > h->nnz ? h->nnz_arr : h->nnz;  // (the arrays' length: what the tiles may read with vector loads; padded when staged)
     args.slab32 = h->slab32 ? 1 : 0;
     args.slab_abound = h->slab_abound;
     args.slab_hi = h->slab_hi;
