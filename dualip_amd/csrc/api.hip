@@ -169,7 +169,6 @@ static void matching_free(dl_matching* h) {
     if (h->stage_a) (void)hipFree(h->stage_a);
     if (h->stage_c) (void)hipFree(h->stage_c);
     if (h->tiles) (void)hipFree(h->tiles);
-    if (h->wg_tile_begin) (void)hipFree(h->wg_tile_begin);
     if (h->projs) (void)hipFree(h->projs);
     if (h->partial) (void)hipFree(h->partial);
     if (h->slab_ovf) (void)hipFree(h->slab_ovf);
@@ -195,68 +194,6 @@ static void matching_free(dl_matching* h) {
     delete h;
 }
 
-// Greedy packing of whole columns into <= 64-lane tiles (host, one-off).  Tiles never straddle projection entries.
-// tile_nnz_prefix is a COST prefix: non-zeros weighted by the projection's relative cost per tile (the simplex tiles
-// run segmented scans and Newton passes; measured ~2.6x a clamp tile), so that contiguous equal-cost ranges finish together.
-static int pack_tiles(int64_t n, const int64_t* colptr, const int32_t* col_proj, int32_t n_proj, const dl_proj_desc* projs, std::vector<TileDesc>& tiles,
-                      std::vector<uint64_t>& tile_nnz_prefix, int64_t* n_long) {
-    auto weight = [&](uint32_t pj) -> uint64_t {
-        if (pj == kNoProj || (int32_t)pj >= n_proj) return 10;
-        const int k = projs[pj].kind;
-        return (k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) ? 26 : 10;
-    };
-    tiles.clear();
-    tile_nnz_prefix.clear();
-    tile_nnz_prefix.push_back(0);
-    uint64_t cur_start = 0, cur_mask = 0;
-    uint32_t cur_cnt = 0, cur_proj = kNoProj;
-    uint64_t running = 0;
-    *n_long = 0;
-    auto flush = [&]() {
-        if (cur_cnt == 0) return;
-        TileDesc d;
-        uint64_t mask = cur_mask;
-        if (cur_cnt < 64) mask |= 1ull << cur_cnt;  // sentinel: lanes >= count form their own dummy segment
-        d.w0 = cur_start | ((uint64_t)cur_cnt << 40) | ((uint64_t)cur_proj << 48);
-        d.w1 = mask;
-        tiles.push_back(d);
-        running += 64 * weight(cur_proj);  // cost is per tile (per wavefront pass), not per non-zero
-        tile_nnz_prefix.push_back(running);
-        cur_cnt = 0;
-        cur_mask = 0;
-    };
-    for (int64_t j = 0; j < n; ++j) {
-        const int64_t k0 = colptr[j], k1 = colptr[j + 1];
-        const int64_t len = k1 - k0;
-        if (len < 0) return fail(DL_E_LAYOUT, "ccol_indices is not monotone at column %lld", (long long)j);
-        if (len == 0) continue;
-        if ((uint64_t)k1 >= (1ull << 40)) return fail(DL_E_ARG, "nnz exceeds 2^40");
-        int32_t pid = col_proj ? col_proj[j] : (n_proj > 0 ? 0 : -1);
-        if (pid >= n_proj) return fail(DL_E_PROJ, "column %lld refers to projection %d but only %d were given", (long long)j, pid, n_proj);
-        const uint32_t pj = pid < 0 ? kNoProj : (uint32_t)pid;
-        // columns of entries that do not fit the kernel's LDS projection table take the single-column path as well
-        if (len > kTileLanes || (pj != kNoProj && pj >= (uint32_t)kProjLdsSlots - 1)) {
-            flush();
-            TileDesc d;
-            d.w0 = (uint64_t)k0 | kTileLongFlag | ((uint64_t)pj << 48);
-            d.w1 = (uint64_t)len;
-            tiles.push_back(d);
-            running += (uint64_t)len * weight(pj) * 3;  // every Newton pass re-reads the column
-            tile_nnz_prefix.push_back(running);
-            *n_long += 1;
-            continue;
-        }
-        if (cur_cnt > 0 && (cur_cnt + (uint32_t)len > (uint32_t)kTileLanes || pj != cur_proj)) flush();
-        if (cur_cnt == 0) {
-            cur_start = (uint64_t)k0;
-            cur_proj = pj;
-        }
-        cur_mask |= 1ull << cur_cnt;
-        cur_cnt += (uint32_t)len;
-    }
-    flush();
-    return 0;
-}
 
 
 // Layout 4 schedule.  The fused kernel deals descriptor q to wavefront q mod S (S = 16 * workgroups) as its (q / S)-th
@@ -459,8 +396,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     h->a = a;
     h->c = c;
     h->n_proj = n_proj;
-    const char* nodpp = plan_env("DUALIP_HIP_NO_DPP");
-    h->use_dpp = !(nodpp && nodpp[0] == '1');
     const char* abl = dev_env("DUALIP_HIP_ABLATE");  // (null in the shipped library)
     h->ablate = abl ? atoi(abl) : 0;
     (void)hipGetDevice(&h->device);
@@ -493,12 +428,10 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         fprintf(stderr, "[dl_matching_create] %-28s %.1f ms\n", name, (t - t_phase) * 1e3);
         t_phase = t;
     };
-    // layout 4 (16-byte loads) needs 16-byte aligned value arrays and at least one full quad; DUALIP_HIP_LAYOUT=1 forces layout 1
-    const char* lay_env = plan_env("DUALIP_HIP_LAYOUT");
-    const bool want4 = !(lay_env && lay_env[0] == '1');
+    // the 256-wide tiles (16-byte loads) need 16-byte aligned value arrays and at least one full round of quads
     const bool aligned = (((uintptr_t)a | (uintptr_t)c) & 15u) == 0;
     h->nnz_arr = nnz;
-    if (want4 && (!aligned || nnz < 1024)) {
+    if (!aligned || nnz < 1024) {
         // unaligned or tiny value arrays: aligned, zero-padded copies owned by the handle (common.h: stage_a) -- one layout, one kernel
         const size_t vs_st = val_dtype == DL_F32 ? 4 : 8;
         const int64_t npad = std::max<int64_t>(1024, (nnz + 3) & ~(int64_t)3);
@@ -518,12 +451,12 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         h->c = c;
         h->nnz_arr = npad;
     }
-    h->layout = want4 ? 4 : 1;
+    h->layout = 4;  // (the only one since round 5; dl_matching_info(h, 8) still reports it)
     // column-per-lane slices for the short columns of simplex entries (sell.h): decided before the windows are packed.
     // DUALIP_HIP_SELL=0 switches them off; DUALIP_HIP_SELL_MIN_SHARE = least share of an entry's non-zeros in short columns.
     std::vector<uint8_t> pid_sell;
     std::vector<uint32_t> sell_desc_h;
-    if (h->layout == 4) {
+    {
         const char* se = plan_env("DUALIP_HIP_SELL");
         double min_share = -1.0;  // default: 0.9, or none when columns of up to 255 non-zeros can be sliced (sell_build.hip)
         if (const char* ms = plan_env("DUALIP_HIP_SELL_MIN_SHARE")) min_share = atof(ms);
@@ -533,7 +466,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // whole-column windows.  Element n_proj: columns with no entry.
     std::vector<uint8_t> pid_flat;
     const char* flat_env = plan_env("DUALIP_HIP_FLAT");  // 0: whole-column windows everywhere; 1: cut every 256 from the run's start; default: at multiples of 256
-    if (h->layout == 4 && !(flat_env && flat_env[0] == '0')) {
+    if (!(flat_env && flat_env[0] == '0')) {
         const uint8_t mode = (flat_env && flat_env[0] == '1') ? 1 : 2;
         pid_flat.assign((size_t)n_proj + 1, 0);
         for (int32_t q = 0; q < n_proj; ++q) {
@@ -546,7 +479,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // Window tiles are packed on the device (pack_build.hip) unless the map has BOTH instruction-bound window tiles (a simplex
     // entry that is not sliced) and memory-bound ones -- those want the host's interleaved schedule (schedule_tiles4) -- or
     // DUALIP_HIP_HOST_PACK=1 asks for the host path (kept as the independent implementation for cross-checks).
-    bool dev_pack = h->layout == 4 && !plan_env("DUALIP_HIP_HOST_PACK") && n < (1ll << 31);
+    bool dev_pack = !plan_env("DUALIP_HIP_HOST_PACK") && n < (1ll << 31);
     for (int32_t q = 0; q < n_proj && dev_pack; ++q) {
         const int k = projs_host[q].kind;
         if ((k == DL_PROJ_SIMPLEX || k == DL_PROJ_SIMPLEX_EQ) && !((size_t)q < pid_sell.size() && pid_sell[(size_t)q]) && n_proj > 1) dev_pack = false;
@@ -595,7 +528,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
 
     phase("colptr / col_proj to host");
     // ---- tiles ----
-    std::vector<TileDesc> tiles;
     std::vector<uint32_t> words4, tile_pid4;
     std::vector<uint64_t> prefix;
     uint32_t* win_dev = nullptr;  // device path: window descriptors in memory order
@@ -621,12 +553,9 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         h->n_long = (int64_t)(long_list.size() / 12);
         h->n_tiles = n_win_dev + h->n_long;
         prefix.assign(1, 0);
-    } else if (h->layout == 4) {
+    } else {
         CK(pack_tiles4(n, h->nnz_arr, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, words4, prefix, tile_pid4, &h->n_long, pid_sell, pid_flat));
         h->n_tiles = (int64_t)(words4.size() / 12);
-    } else {
-        CK(pack_tiles(n, colptr_h.data(), col_proj ? col_proj_h.data() : nullptr, n_proj, projs_host, tiles, prefix, &h->n_long));
-        h->n_tiles = (int64_t)tiles.size();
     }
     if (h->n_tiles >= (1ll << 31)) {
         matching_free(h);
@@ -634,7 +563,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     }
 
     phase(dev_pack ? "window packing (device)" : "window packing (host)");
-    // ---- workgroups: one per CU.  Layout 1: contiguous tile ranges of equal cost (wg_tile_begin); layout 4: descriptors in
+    // ---- workgroups: one per CU; descriptors in
     //      schedule order, dealt cyclically to the wavefronts (schedule_tiles4) ----
     hipDeviceProp_t prop;
     CKH(hipGetDeviceProperties(&prop, h->device));
@@ -644,7 +573,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     int64_t want = (h->n_tiles + h->n_sell + kFusedWaves - 1) / kFusedWaves;  // at least one tile per wavefront
     h->n_wg = (int)(want < n_cu ? want : n_cu);
     if (h->n_wg < 1) h->n_wg = (h->n_tiles + h->n_sell) > 0 ? 1 : 0;
-    if (h->layout == 4) {
+    {
         // descriptor array = [window tiles in schedule order | one all-zero descriptor (what slots past the end read) |
         // single-column tiles]: the single-column walker runs in its own loop, outside the hot one
         // single-column tiles of more than xlong_min non-zeros are walked by a whole workgroup (listed last): one wavefront
@@ -740,18 +669,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         tile_pid4 = short_pid;
         tile_pid4.insert(tile_pid4.end(), long_pid.begin(), long_pid.end());
     }
-    std::vector<uint32_t> wg_begin((size_t)h->n_wg + 1, 0);
-    {
-        const uint64_t total = prefix.back();
-        size_t t = 0;
-        const size_t n_t = dev_pack ? 0 : (size_t)h->n_tiles;  // (the 256-wide layout deals tiles cyclically: the table is unused there)
-        for (int w = 0; w <= h->n_wg; ++w) {
-            const uint64_t target = h->n_wg ? (total * (uint64_t)w) / (uint64_t)h->n_wg : 0;
-            while (t < n_t && prefix[t] < target) ++t;
-            wg_begin[(size_t)w] = (uint32_t)t;
-        }
-        if (h->n_wg) wg_begin[(size_t)h->n_wg] = (uint32_t)n_t;
-    }
 
     phase("schedule (host)");
     // ---- LDS plan ----
@@ -776,7 +693,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     {
         const char* hot_env = plan_env("DUALIP_HIP_HOT_ROWS");
         int64_t forced = hot_env ? atoll(hot_env) : -1;
-        const bool allowed = h->layout == 4 && nnz > 0 && max_mode >= 2 && forced != 0;
+        const bool allowed = nnz > 0 && max_mode >= 2 && forced != 0;
         int64_t m_hot = 0;
         if (allowed && forced > 0 && forced < m && fused_lds_bytes(forced, val_dtype, true, true) <= kLdsBudget) {
             m_hot = forced;
@@ -829,9 +746,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     CK(owned_malloc(h, &h->rowidx, (size_t)h->nnz_arr * (size_t)h->row_bytes));
     if (h->nnz_arr > nnz) CKH(hipMemsetAsync(h->rowidx, 0, (size_t)h->nnz_arr * (size_t)h->row_bytes, st));  // (staged: the padding's rows are row 0, its values 0)
     const size_t win_bytes = dev_pack ? sizeof(uint32_t) * (size_t)h->desc_words * (size_t)n_win_dev : 0;  // device-packed windows precede the host-built part
-    const size_t tile_bytes = win_bytes + (h->layout == 4 ? sizeof(uint32_t) * words4.size() : sizeof(TileDesc) * tiles.size());
+    const size_t tile_bytes = win_bytes + sizeof(uint32_t) * words4.size();
     CK(owned_malloc(h, (void**)&h->tiles, tile_bytes));
-    CK(owned_malloc(h, (void**)&h->wg_tile_begin, sizeof(uint32_t) * wg_begin.size()));
     CK(owned_malloc(h, (void**)&h->projs, sizeof(ProjDev) * (size_t)(n_proj > 0 ? n_proj : 1)));
     const size_t vs = val_dtype == DL_F32 ? 4 : 8;
     (void)vs;
@@ -854,8 +770,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
     if (e == hipSuccess && win_bytes > 0) e = hipMemcpyAsync(h->tiles, win_dev, win_bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && tile_bytes > win_bytes)
-        e = hipMemcpyAsync((char*)h->tiles + win_bytes, h->layout == 4 ? (const void*)words4.data() : (const void*)tiles.data(), tile_bytes - win_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->wg_tile_begin, wg_begin.data(), sizeof(uint32_t) * wg_begin.size(), hipMemcpyHostToDevice, st);
+        e = hipMemcpyAsync((char*)h->tiles + win_bytes, (const void*)words4.data(), tile_bytes - win_bytes, hipMemcpyHostToDevice, st);
     std::vector<ProjDev> pd((size_t)(n_proj > 0 ? n_proj : 1));
     for (int32_t q = 0; q < n_proj; ++q) pd[(size_t)q] = ProjDev{projs_host[q].kind, 0, projs_host[q].p0, projs_host[q].p1};
     if (e == hipSuccess) e = hipMemcpyAsync(h->projs, pd.data(), sizeof(ProjDev) * pd.size(), hipMemcpyHostToDevice, st);
@@ -889,7 +804,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     uint8_t* sell_flags_dev = nullptr;
     if (e == hipSuccess) e = hipMalloc((void**)&mx_dev, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(mx_dev, 0, 3 * sizeof(unsigned long long), st);
-    if (e == hipSuccess && h->layout == 4 && n > 0) {  // where the in-place reads of the caller-ordered arrays end (dl_matching_own_inputs)
+    if (e == hipSuccess && n > 0) {  // where the in-place reads of the caller-ordered arrays end (dl_matching_own_inputs)
         if (!pid_sell.empty()) {
             e = hipMalloc((void**)&sell_flags_dev, pid_sell.size());
             if (e == hipSuccess) e = hipMemcpyAsync(sell_flags_dev, pid_sell.data(), pid_sell.size(), hipMemcpyHostToDevice, st);
@@ -918,7 +833,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         matching_free(h);
         return hip_fail(e, "create sync");
     }
-    h->unsliced_end = h->layout == 4 ? (int64_t)mx_host[2] : nnz;
+    h->unsliced_end = (int64_t)mx_host[2];
     memcpy(&h->amax, &mx_host[0], sizeof(double));
     memcpy(&h->cmax, &mx_host[1], sizeof(double));
     if (!std::isfinite(h->amax) || !std::isfinite(h->cmax)) {  // (absmax_kernel: any inf / NaN element surfaces here)
@@ -959,11 +874,6 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
     // |x| bounds per projection kind: box -> max(|lower|, |upper|); simplex -> z (+ slack); cone / identity -> via |v| per launch
     bool used_none = false;
     std::vector<char> used((size_t)(n_proj > 0 ? n_proj : 1), 0);
-    for (const TileDesc& d : tiles) {
-        const uint32_t pid = tile_proj(d.w0);
-        if (pid == kNoProj) used_none = true;
-        else used[pid] = 1;
-    }
     for (uint32_t pid : tile_pid4) {
         if (pid == kNoProj) used_none = true;
         else used[pid] = 1;
@@ -997,7 +907,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         const char* se = plan_env("DUALIP_HIP_SLAB32");
         // Every projection must bound x itself (box, simplex): with a one-sided operator the bound is |v|'s -- (amax lmax + cmax) / gamma -- which
         // typical elements sit orders of magnitude below, and a grid taken from it would round them away.
-        const bool can = val_dtype == DL_F32 && h->layout == 4 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg && h->row_count_max <= kSlabMaxRow;
+        const bool can = val_dtype == DL_F32 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg && h->row_count_max <= kSlabMaxRow;
         h->slab32 = can && !(se && se[0] == '0');
         if (h->slab32) {
             int rc_l1 = slab_refresh_bound(h, st);
@@ -1020,7 +930,7 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         if (const char* mr = plan_env("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
         if (const char* gn = dev_env("DUALIP_HIP_BALANCE_GAIN")) h->bal_gain = atof(gn) > 0.0 ? atof(gn) : h->bal_gain;
         const bool adapt = !(be && be[0] == '0') && h->n_wg >= 2 && h->n_wg <= 1024 && rw >= h->bal_min_rounds;
-        if (h->layout == 4) {  // (every layout-4 handle has a table; only those that adapt have stamps)
+        {   // (every handle has a table; only those that adapt have stamps)
             const size_t words = bal_table_words(h->n_wg > 0 ? h->n_wg : 1);
             CK(owned_malloc(h, (void**)&h->bal, sizeof(int32_t) * words));
             std::vector<int32_t> tab(words, 0);
@@ -1121,7 +1031,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
         case 13: return h->n_sell_cols;
         case 14: return h->n_sell_elems;
         case 15: return h->n_sell_nnz;
-        case 16: return h->layout == 4 ? h->desc_words : 4;
+        case 16: return h->desc_words;
         case 17: return h->n_sell_mixed_cols;
         case 2003: return h->m_hot > 0 ? h->m_lam : (h->lam_lds ? h->m : 0);  // rows of the dual vector staged in LDS
         case 2004: return (h->lanes_binary || h->n_sell_lane_slices > 0) ? 1 : 0;
@@ -1170,7 +1080,7 @@ int dl_matching_set_fairness(dl_matching* h, const void* f_values, dl_stream_t s
     if (h->m < 2) return fail(DL_E_ARG, "the fairness pair needs at least its own two rows");
     // (the mirror of dl_matching_own_inputs' refusal: after it the straggler tiles read at pool offsets while f stays in the caller's order)
     if (h->owns_inputs) return fail(DL_E_STATE, "the handle owns its inputs (dl_matching_own_inputs): the fairness stream is read at the caller's offsets, which its straggler tiles no longer use -- build a new handle");
-    if ((h->n_tiles > 0 || h->n_sell > 0) && (h->layout != 4 || !h->lam_lds || !h->grad_lds || h->stage_a))  // (a staged handle's windows read past nnz inside ITS padded copies; f has no padding)
+    if ((h->n_tiles > 0 || h->n_sell > 0) && (!h->lam_lds || !h->grad_lds || h->stage_a))  // (a staged handle's windows read past nnz inside ITS padded copies; f has no padding)
         return fail(DL_E_STATE, "the fairness pair needs the 256-wide tile layout with the dual vector and the gradient in LDS (16-byte aligned values, nnz >= 1024)");
     if ((reinterpret_cast<uintptr_t>(f_values) & 15u) != 0) return fail(DL_E_ARG, "fairness values must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -1223,7 +1133,6 @@ static int refresh_absmax(dl_matching* h, const void* values, double* out, hipSt
 int dl_matching_own_inputs(dl_matching* h, dl_stream_t stream) {
     if (!h) return fail(DL_E_ARG, "null handle");
     if (h->owns_inputs) return 0;
-    if (h->layout != 4) return fail(DL_E_STATE, "only handles of the 256-wide tile layout can own their inputs (unaligned or tiny inputs keep borrowing)");
     if (h->fair) return fail(DL_E_STATE, "a handle with the fairness stream borrows three arrays; release is not offered for it");
     hipStream_t st = (hipStream_t)stream;
     const size_t vs = h->val_dtype == DL_F32 ? 4 : 8;

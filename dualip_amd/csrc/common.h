@@ -33,9 +33,9 @@ int hip_fail(hipError_t e, const char* what);
 // measurements of profiles/ -- exist only in a library compiled with -DDL_DEVTOOLS (libdualip_hip_dev.so, built by
 // `python -m dualip_amd._build --dev` for tools/): the shipped library never reads them and compiles their branches out.
 constexpr const char* kPlanSwitches[] = {
-    "DUALIP_HIP_LAYOUT", "DUALIP_HIP_SELL", "DUALIP_HIP_SELL_MIN_SHARE", "DUALIP_HIP_SELL_LANES", "DUALIP_HIP_SELL_LANES_MIN_SHARE", "DUALIP_HIP_SELL_MERGE_SHORT",
+    "DUALIP_HIP_SELL", "DUALIP_HIP_SELL_MIN_SHARE", "DUALIP_HIP_SELL_LANES", "DUALIP_HIP_SELL_LANES_MIN_SHARE", "DUALIP_HIP_SELL_MERGE_SHORT",
     "DUALIP_HIP_LANES_BINARY", "DUALIP_HIP_FLAT", "DUALIP_HIP_COMPACT", "DUALIP_HIP_HOST_PACK", "DUALIP_HIP_LDS_MODE", "DUALIP_HIP_HOT_ROWS", "DUALIP_HIP_LAM_ALL",
-    "DUALIP_HIP_ROW32", "DUALIP_HIP_COLD_XCD", "DUALIP_HIP_XLONG_MIN", "DUALIP_HIP_NO_DPP", "DUALIP_HIP_XCD_BALANCE", "DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS",
+    "DUALIP_HIP_ROW32", "DUALIP_HIP_COLD_XCD", "DUALIP_HIP_XLONG_MIN", "DUALIP_HIP_XCD_BALANCE", "DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS",
     "DUALIP_HIP_SELL_BALANCE", "DUALIP_HIP_SELL_BALANCE_PPM", "DUALIP_HIP_FUSE_APPLY", "DUALIP_HIP_TIMING", "DUALIP_HIP_TIMELINE", "DUALIP_HIP_SLAB32",
 };
 constexpr int kNumPlanSwitches = (int)(sizeof(kPlanSwitches) / sizeof(kPlanSwitches[0]));
@@ -49,25 +49,12 @@ inline const char* dev_env(const char*) { return nullptr; }
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
-// wave tiles: the unit of work of one 64-lane wavefront
+// tiles
 // ---------------------------------------------------------------------------------------------------------
-// A SHORT tile is a run of whole, consecutive, non-empty columns with <= 64 non-zeros in total, all of the same
-// projection entry; lane k owns non-zero (nnz_start + k).  A LONG tile is one column with more than 64 non-zeros,
-// walked by the wavefront in 64-wide strides.
-//   w0: [ 0..39] nnz_start   [40..46] count (short tiles, 1..64)   [47] long flag   [48..63] projection id
-//   w1: short: bit k set <=> lane k starts a column (plus a sentinel bit at `count` when count < 64)
-//       long : the column length
-struct TileDesc {
-    uint64_t w0;
-    uint64_t w1;
-};
-constexpr int kTileLanes = 64;
-constexpr uint64_t kTileLongFlag = 1ull << 47;
+// A window tile is 256 non-zeros walked by one wavefront, four per lane (fused4_kernel.h: 12- or 2-dword descriptors); a single-column
+// tile is one column that fits no window.  (The 64-wide tiles of rounds 1-4 -- one non-zero per lane, 16-byte TileDesc records, a second
+// kernel for unaligned and tiny inputs -- are gone: such inputs are staged into aligned, padded copies, dl_matching::stage_a.)
 constexpr uint32_t kNoProj = 0xFFFFu;
-
-__host__ __device__ inline uint64_t tile_nnz_start(uint64_t w0) { return w0 & ((1ull << 40) - 1); }
-__host__ __device__ inline uint32_t tile_count(uint64_t w0) { return (uint32_t)((w0 >> 40) & 0x7F); }
-__host__ __device__ inline uint32_t tile_proj(uint64_t w0) { return (uint32_t)(w0 >> 48); }
 
 // device copy of dl_proj_desc in the working precision is built on the fly from this
 struct ProjDev {
@@ -123,9 +110,8 @@ struct dl_matching {
     int64_t unsliced_end = 0; // one past the last non-zero a tile reads in place from a / c / rowidx (0: every column is sliced)
     bool owns_inputs = false;
     int row_bytes = 4;
-    dl::TileDesc* tiles = nullptr;      // owned (layout 1: TileDesc[]; layout 4: 12 dwords per tile)
+    uint32_t* tiles = nullptr;          // owned: window descriptors (desc_words dwords each), one all-zero descriptor, single-column tiles (12 dwords each)
     int layout = 1;                     // 1 = one non-zero per lane (64-wide tiles), 4 = four per lane (256-wide tiles)
-    uint32_t* wg_tile_begin = nullptr;  // owned, [n_wg + 1]
     dl::ProjDev* projs = nullptr;       // owned
     int32_t n_proj = 0;
     int64_t n_tiles = 0, n_long = 0;
@@ -170,7 +156,6 @@ struct dl_matching {
     int64_t row_count_max = 0;          // most non-zeros in one row
     long long* partial_scal = nullptr;  // owned: [n_wg][2], c.x and sum x^2 per workgroup in fixed point (exponent shift_dev[1])
     size_t owned_bytes = 0;
-    bool use_dpp = true;
     int ablate = 0;  // developer-only timing ablations, see FusedArgs (always 0 in the shipped library)
     uint32_t switches = 0;  // plan switches set in the environment when the handle was created (bit i = kPlanSwitches[i])
     // "hot rows" plan (dual vector / gradient too large for the LDS): rows renumbered by frequency, the m_hot most frequent

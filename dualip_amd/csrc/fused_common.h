@@ -1,6 +1,5 @@
-// fused_common.h -- pieces shared by the two tile layouts of the fused pass (matching_kernels.hip: one non-zero per
-// lane, 64-wide tiles; matching_kernels4.hip: four per lane, 256-wide tiles): kernel arguments, the exact fixed-point
-// scatter, SGPR-base addressing and the single-column ("long tile") walker.
+// fused_common.h -- what the fused pass (fused4_kernel.h) and its slices (sell.h) share: kernel arguments, the exact fixed-point scatter,
+// SGPR-base addressing, the single-column ("long tile") walker, the prologue and the epilogue.
 #pragma once
 #include "agd_step.h"
 #include "common.h"
@@ -11,8 +10,7 @@ namespace dl {
 
 template <class T>
 struct FusedArgs {
-    const uint32_t* __restrict__ tiles32;  // TileDesc as 4 dwords each
-    const uint32_t* __restrict__ wg_tile_begin;
+    const uint32_t* __restrict__ tiles32;  // window descriptors (desc_words dwords each)
     const void* __restrict__ rowidx;
     const T* __restrict__ a;
     const T* __restrict__ c;
@@ -45,7 +43,7 @@ struct FusedArgs {
     const int32_t* balance;               // layout 4: the window tiles' weighted deal (Deal: rounds per workgroup + tables), or null (same for all)
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
     const int32_t* sell_bal;              // layout 4, first binary: two-phase deal of the one-lane slices (common.h), or null (one even deal)
-    int ablate;  // developer-only timing ablations of the 64-wide layout (DUALIP_HIP_ABLATE): 1 = skip scatter, 2 = skip gather, 4 = skip projection
+    int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE, libdualip_hip_dev.so only): bits 8, 32, 128, 1024, 12-13, 14-17 -- see their uses
     unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) have their GRADIENT accumulator in LDS; 0 = every row does
     int64_t m_lam;                 // hot-rows plan: rows < m_lam have their DUAL entry in LDS (m_hot <= m_lam <= m; m: no tile gathers from L2)

@@ -1,271 +1,14 @@
-// matching_kernels.hip -- the fused dual-gradient pass of the matching LP for gfx950.
-//
-// One launch streams the CSC arrays (a, c, row index) exactly once and performs, per non-zero / per column,
-// what the reference does in ~10^2 ATen launches (src/dualip/objectives/matching.py:136-161):
-//     gather  v = a * (-(1/g) lambda[row]) + (-(1/g) c)     left_multiply_sparse + elementwise_csc(add)
-//     project x = Proj_column(v)                              apply_F_to_columns (box / cone / simplex)
-//     scatter (A x)[row] += a x ;  c.x ;  sum x^2             row_sums_csc(A*x), dot, norm
-//
-// Mapping to the hardware (measured facts behind each choice are in DESIGN.md / profiles/)
-//   * one 1024-thread workgroup per CU (16 wavefronts).  lambda (pre-scaled by -1/gamma) is staged in LDS; the
-//     gradient is privatised in LDS as 64-bit FIXED-POINT integers and accumulated with ds_add_u64: the hardware
-//     float LDS atomic (ds_add_f32) retires ~1 lane per 3 cycles (185 cycles per wavefront instruction, measured),
-//     the integer one runs at gather speed, and integer sums are exact -> the gradient is bit-reproducible;
-//   * a wavefront owns "tiles": <= 64 non-zeros of whole consecutive columns, one non-zero per lane, described by a
-//     16-byte record (start, count, column-head bit mask, projection id) that replaces the column-pointer array.
-//     A wavefront works on a BATCH of kBatch tiles in lock-step (independent dependency chains for the scans) and
-//     keeps the next batch's CSC loads and the batch-after-next's descriptors in flight.  Descriptors travel
-//     through the vector-memory path (one coalesced 64-byte load + v_readlane), because scalar loads share the
-//     LDS wait counter and would put an HBM round trip in front of every LDS operation;
-//   * the simplex projection runs in registers: segmented DPP scans give per-column sum / max, a ballot gives the
-//     support size, and a monotone Newton (Michelot) iteration on the piecewise-linear f(theta) = sum max(u-theta,0)
-//     finds the exact threshold the reference obtains by sort + cumsum;
-//   * columns longer than 64 non-zeros are walked by a whole wavefront in 64-wide strides (re-reading L2-hot data
-//     per Newton pass);
-//   * every workgroup writes its private integer gradient to its own slab; a second small kernel sums the slabs
-//     (exactly) and converts to double.
+// matching_kernels.hip -- everything around the fused dual-gradient pass of the matching LP for gfx950 that is not the pass itself: the slab
+// reduction (reduce_partials_kernel: exact integer sums of the workgroups' gradient slabs; MODE 2 pushes them into the ranks' mailboxes), the
+// one-off measurements of handle creation (max |v|, row L1 norms, the self-check of the per-XCD accumulators), the balance kernels of the two
+// deals, and the launch glue (fused_typed).  The pass is matching_fused_kernel4 (fused4_kernel.h, four translation units); the 64-wide
+// kernel that used to live here served unaligned and tiny inputs until round 5 -- they are staged into the 256-wide layout now (api.hip).
 #include <atomic>
 
 #include "comm.h"
 #include "fused_common.h"
 
 namespace dl {
-
-// ---------------------------------------------------------------------------------------------------------
-// fused kernel
-// ---------------------------------------------------------------------------------------------------------
-template <class T, class RowT, bool LAM_LDS, bool GRAD_LDS, bool USE_DPP>
-__global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel(FusedArgs<T> g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: [gradient int64 m (GRAD_LDS)] [lambda T m (LAM_LDS)] [projection table] [scratch doubles]
-    long long* grad_s = reinterpret_cast<long long*>(smem);
-    size_t off = GRAD_LDS ? (size_t)g.m * 8 : 0;
-    T* lam_s = reinterpret_cast<T*>(smem + off);
-    off += LAM_LDS ? (size_t)g.m * sizeof(T) : 0;
-    off = (off + 15) / 16 * 16;
-    ProjT<T>* proj_s = reinterpret_cast<ProjT<T>*>(smem + off);
-    off += (size_t)kProjLds * sizeof(ProjT<T>);
-    double* red_s = reinterpret_cast<double*>(smem + off);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x;
-    const T s = (T)(-1.0 / g.gamma);  // matching.py:136: the scalar is formed in double, rounded once
-
-    // ---- prologue: stage -lambda/gamma, max |lambda|, zero the private gradient, cache the projection table ----
-    double lmax = 0.0;
-    for (int64_t i = tid; i < g.m; i += kFusedThreads) {
-        const T l = g.lambda[i];
-        if constexpr (LAM_LDS) lam_s[i] = (T)(s * l);
-        const double al = fabs((double)l);
-        lmax = al > lmax ? al : lmax;
-    }
-    if constexpr (GRAD_LDS) {
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) grad_s[i] = 0;
-    }
-    for (int id = tid; id < kProjLds; id += kFusedThreads) {  // slot kProjLds-1 stays the identity (columns in no entry)
-        proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
-    }
-    const LaneConst lc = make_lane_const(lane);
-    lmax = wave_allreduce(lmax, OpMax());
-    if (lane == 0) red_s[wave] = lmax;
-    __syncthreads();
-    lmax = red_s[0];
-    for (int w = 1; w < kFusedWaves; ++w) lmax = red_s[w] > lmax ? red_s[w] : lmax;
-    __syncthreads();  // red_s is reused by the epilogue
-    // fixed-point exponent: every row sum satisfies |sum a x| <= amax * xmax * row_count_max < 2^E -> scale = 2^(bits-E)
-    // (the same value in every workgroup; the slab reduction adds at most log2(#workgroups) <= 12 more bits)
-    int shift, shift2;
-    {
-        double xmax = g.xmax_bounded;
-        if (g.has_unbounded) {
-            const double vmax = fabs(-1.0 / g.gamma) * (g.amax * lmax + g.cmax);
-            const double ub = vmax > g.pmax_unbounded ? vmax : g.pmax_unbounded;
-            xmax = ub > xmax ? ub : xmax;
-        }
-        const double bound = g.amax * xmax * g.row_count_max;
-        int e = 0;
-        if (bound > 0.0 && bound < 1e300) (void)frexp(bound, &e);
-        shift = FixedBits<T>::value - e;
-        shift = shift > 1000 ? 1000 : (shift < -1000 ? -1000 : shift);
-        shift2 = scalar_shift((double)g.nnz, g.cmax, xmax);
-    }
-    const double scale = ldexp(1.0, shift);
-    const double scale2 = ldexp(1.0, shift2);  // the two scalar sums leave this kernel in fixed point, like the 256-wide kernel's
-    if (wg == 0 && tid == 0) {
-        g.shift_out[0] = shift;
-        g.shift_out[1] = shift2;
-    }
-
-    long long* gacc = GRAD_LDS ? grad_s : g.partial;
-    double obj = 0.0, ssq = 0.0;
-
-    const uint32_t t_begin = g.wg_tile_begin[wg];
-    const uint32_t t_end = g.wg_tile_begin[wg + 1];
-    // 32-bit byte offsets relative to the workgroup's first non-zero (SGPR base + VGPR offset addressing)
-    uint64_t k_base = 0;
-    if (t_begin < t_end) {
-        const uint32_t lo = g.tiles32[(size_t)t_begin * 4], hi = g.tiles32[(size_t)t_begin * 4 + 1];
-        k_base = tile_nnz_start(((uint64_t)hi << 32) | lo);
-    }
-    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)k_base);
-    k_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(k_base >> 32)) << 32) | kb_lo;
-    const T* __restrict__ a_wg = g.a + k_base;
-    const T* __restrict__ c_wg = g.c + k_base;
-    const RowT* __restrict__ r_wg = reinterpret_cast<const RowT*>(g.rowidx) + k_base;
-    T* __restrict__ x_wg = g.x_out ? g.x_out + k_base : nullptr;
-
-    // descriptor words of one batch through the vector path: lane l (< 4*kBatch) holds dword l of the 16-byte records.
-    // The load is UNCONDITIONAL (clamped index, result zeroed past the end): a load issued under a branch makes the
-    // compiler's wait-count insertion fall back to vmcnt(0) at the join and serialises the software pipeline.
-    const size_t last_word = (size_t)t_end * 4 - 1;
-    auto load_desc = [&](uint32_t tb) -> uint32_t {
-        const uint32_t l = (uint32_t)lane < 4u * kBatch ? (uint32_t)lane : 4u * kBatch - 1u;
-        size_t idx = (size_t)tb * 4 + l;
-        idx = idx < last_word ? idx : last_word;
-        const uint32_t v = g.tiles32[idx];
-        const bool ok = (uint32_t)lane < 4u * kBatch && tb < t_end && tb + (l >> 2) < t_end;
-        return v & (0u - (uint32_t)ok);  // an AND, not a select: a select lets the compiler sink the load under a branch
-    };
-    struct Batch {
-        uint32_t w0lo[kBatch], w0hi[kBatch];
-        uint64_t w1[kBatch];
-        uint32_t koff[kBatch];  // element offset of lane 0 relative to k_base (0 for padding / long tiles)
-        T a[kBatch], c[kBatch];
-        uint32_t r[kBatch];
-    };
-    // loads are unconditional: lanes past the tile's count re-read its first element and are masked at the end
-    auto unpack_and_issue = [&](uint32_t dv, Batch& b) {
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            b.w0lo[q] = __builtin_amdgcn_readlane(dv, 4 * q);
-            b.w0hi[q] = __builtin_amdgcn_readlane(dv, 4 * q + 1);
-            const uint32_t w1lo = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 2);  // readlane returns a signed int:
-            const uint32_t w1hi = (uint32_t)__builtin_amdgcn_readlane(dv, 4 * q + 3);  // never widen it directly
-            b.w1[q] = ((uint64_t)w1hi << 32) | w1lo;
-            const uint32_t cnt = (b.w0hi[q] >> 8) & 0x7F;
-            const bool is_long = (b.w0hi[q] & 0x8000u) != 0;
-            b.koff[q] = (cnt == 0 || is_long) ? 0u : b.w0lo[q] - kb_lo;  // exact: a workgroup spans < 2^32 non-zeros
-            const uint32_t k = b.koff[q] + ((uint32_t)lane < cnt ? (uint32_t)lane : 0u);
-            b.a[q] = *byte_offset(a_wg, k * (uint32_t)sizeof(T));
-            b.c[q] = *byte_offset(c_wg, k * (uint32_t)sizeof(T));
-            b.r[q] = (uint32_t)*byte_offset(r_wg, k * (uint32_t)sizeof(RowT));
-        }
-    };
-
-    // ---- main loop: batch k is processed while the CSC values of batch k+1 and the descriptors of batch k+2 fly ----
-    const uint32_t stride = kFusedWaves * kBatch;
-    uint32_t tb = t_begin + (uint32_t)wave * kBatch;
-    Batch cur;
-    uint32_t dv_next = 0;
-    if (tb < t_end) {
-        const uint32_t dv0 = load_desc(tb);
-        dv_next = load_desc(tb + stride);
-        unpack_and_issue(dv0, cur);
-    }
-    while (tb < t_end) {
-        Batch nxt;
-        const uint32_t tb_next = tb + stride;
-        unpack_and_issue(dv_next, nxt);  // past the end dv_next is 0: dummy loads of the workgroup's first element
-        dv_next = load_desc(tb_next + stride);
-
-        // ------------------------------ batch of short tiles: one non-zero per lane and tile ------------------------------
-        ProjT<T> pj[kBatch];
-        bool valid[kBatch], smp[kBatch];
-        const int32_t* eq_row[kBatch];
-        bool any_simplex = false, any_long = false;
-        T v[kBatch], x[kBatch];
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            const uint32_t cnt = (cur.w0hi[q] >> 8) & 0x7F;
-            const bool is_long = (cur.w0hi[q] & 0x8000u) != 0;
-            const uint32_t pid = cur.w0hi[q] >> 16;
-            any_long = any_long || is_long;
-            // entries beyond the LDS table only occur in single-column "long" tiles (see pack_tiles), never here
-            pj[q] = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
-            const int kind = __builtin_amdgcn_readfirstlane(pj[q].kind);
-            valid[q] = !is_long && (uint32_t)lane < cnt;
-            smp[q] = !is_long && cnt > 0 && is_simplex_kind(kind);
-            eq_row[q] = (kind == DL_PROJ_SIMPLEX_EQ && g.eq_heights) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
-            any_simplex = any_simplex || smp[q];
-            T lam = (T)1;
-            if (!DL_ABLATE(g.ablate, 2)) lam = LAM_LDS ? lam_s[cur.r[q]] : (T)(s * g.lambda[cur.r[q]]);
-            const T t1 = (T)(cur.a[q] * lam);          // sparse_utils.py:79
-            v[q] = (T)(t1 + (T)(s * cur.c[q]));        // matching.py:66,142
-            x[q] = DL_ABLATE(g.ablate, 4) ? v[q] : project_pointwise(v[q], pj[q]);
-        }
-        if (any_simplex && !DL_ABLATE(g.ablate, 4)) simplex_batch<USE_DPP>(v, valid, cur.w1, pj, smp, lc, x, eq_row);
-        T o32 = (T)0, q32 = (T)0;
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            const T xq = valid[q] ? x[q] : (T)0;
-            const T ax = (T)(cur.a[q] * xq);
-            if (ax != (T)0 && !DL_ABLATE(g.ablate, 1)) scatter_fixed(gacc, cur.r[q], ax, scale);
-            o32 = (T)(o32 + (T)(cur.c[q] * xq));
-            q32 = (T)(q32 + (T)(xq * xq));
-            x[q] = xq;
-        }
-        obj += (double)o32;
-        ssq += (double)q32;
-        if (x_wg) {
-#pragma unroll
-            for (int q = 0; q < kBatch; ++q)
-                if (valid[q]) x_wg[cur.koff[q] + (uint32_t)lane] = x[q];
-        }
-        if (any_long) {
-            // one shared code instance: the tile's words are selected by a run-time index
-#pragma unroll 1
-            for (int q = 0; q < kBatch; ++q) {
-                uint32_t w0lo = cur.w0lo[0], w0hi = cur.w0hi[0];
-                uint64_t w1 = cur.w1[0];
-#pragma unroll
-                for (int j = 1; j < kBatch; ++j) {
-                    if (q == j) {
-                        w0lo = cur.w0lo[j];
-                        w0hi = cur.w0hi[j];
-                        w1 = cur.w1[j];
-                    }
-                }
-                if (w0hi & 0x8000u) {
-                    const uint32_t pid = w0hi >> 16;
-                    ProjT<T> pl = proj_s[pid < (uint32_t)(kProjLds - 1) ? pid : (uint32_t)(kProjLds - 1)];
-                    if (pid >= (uint32_t)(kProjLds - 1) && pid != kNoProj) pl = make_proj<T>(g.projs[pid].kind, g.projs[pid].p0, g.projs[pid].p1);
-                    const uint64_t w0 = ((uint64_t)w0hi << 32) | w0lo;
-                    const int32_t* eq_long = (g.eq_heights && pid != kNoProj) ? g.eq_heights + (size_t)pid * kEqBuckets : nullptr;
-                    process_long_tile<T, RowT, LAM_LDS>(g, pl, tile_nnz_start(w0), w1, lam_s, gacc, s, scale, lane, obj, ssq, eq_long);
-                }
-            }
-        }
-
-        tb = tb_next;
-        cur = nxt;
-    }
-
-    // ---- epilogue: scalar partials, then the private gradient slab ----
-    obj = wave_allreduce(obj, OpAdd());
-    ssq = wave_allreduce(ssq, OpAdd());
-    if (lane == 0) {
-        red_s[2 * wave] = obj;
-        red_s[2 * wave + 1] = ssq;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double o = 0.0, q = 0.0;
-        for (int w = 0; w < kFusedWaves; ++w) {
-            o += red_s[2 * w];
-            q += red_s[2 * w + 1];
-        }
-        // (this layout's schedule is static -- contiguous tile ranges per workgroup -- so its double sums are the same run to run;
-        //  they are rounded to the fixed-point grid once per workgroup)
-        g.partial_scal[2 * (int64_t)wg] = __double2ll_rn(o * scale2);
-        g.partial_scal[2 * (int64_t)wg + 1] = __double2ll_rn(q * scale2);
-    }
-    if constexpr (GRAD_LDS) {
-        long long* slab = g.partial + (int64_t)wg * g.mpad;
-        for (int64_t i = tid; i < g.m; i += kFusedThreads) slab[i] = grad_s[i];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // slab reduction: packed[0..m) = 2^-shift * sum_w partial[w][i] (exact integer sum), packed[m], packed[m+1] = scalars
@@ -499,28 +242,6 @@ size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad) {
     off += (size_t)kProjLds * (val_dtype == DL_F32 ? sizeof(ProjT<float>) : sizeof(ProjT<double>));
     off += kLdsScratch;
     return off;
-}
-
-template <class T, class RowT, bool LAM, bool GRAD, bool DPP>
-static int launch_fused_inst(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
-    auto kern = matching_fused_kernel<T, RowT, LAM, GRAD, DPP>;
-    static std::atomic<uint64_t> attr_set{0};  // per instantiation, one bit per device (the opt-in to > 64 KB of LDS is per device)
-    const uint64_t bit = 1ull << (h->device & 63);
-    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-        DL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set.fetch_or(bit, std::memory_order_relaxed);
-    }
-    hipLaunchKernelGGL(kern, dim3(h->n_wg), dim3(kFusedThreads), h->lds_bytes, st, args);
-    DL_HIP(hipGetLastError());
-    return 0;
-}
-
-template <class T, class RowT>
-static int launch_fused_rt(const dl_matching* h, const FusedArgs<T>& args, hipStream_t st) {
-    const bool L = h->lam_lds, G = h->grad_lds, D = h->use_dpp;
-    if (L && G) return D ? launch_fused_inst<T, RowT, true, true, true>(h, args, st) : launch_fused_inst<T, RowT, true, true, false>(h, args, st);
-    if (!L && G) return D ? launch_fused_inst<T, RowT, false, true, true>(h, args, st) : launch_fused_inst<T, RowT, false, true, false>(h, args, st);
-    return D ? launch_fused_inst<T, RowT, false, false, true>(h, args, st) : launch_fused_inst<T, RowT, false, false, false>(h, args, st);
 }
 
 int launch_fused4_f32(const dl_matching* h, const FusedArgs<float>& args, hipStream_t st);   // matching_kernels4.hip
@@ -779,14 +500,13 @@ bool matching_can_fuse_apply(const dl_matching* h) {
     bool on = h->n_wg > 0 && (h->n_tiles + h->n_sell) < kFuseApplyRounds * (int64_t)h->n_wg * kFusedWaves;
     if (e && e[0] == '1') on = true;
     if (e && e[0] == '0') on = false;
-    return on && h->layout == 4 && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
+    return on && h->lam_lds && h->grad_lds && h->m_hot == 0 && !h->fair && (h->n_tiles > 0 || h->n_sell > 0) && h->n_wg > 0;
 }
 
 template <class T>
 static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x_out, hipStream_t st, uint64_t owner_uid, const dl_agd* agd, const PendingStep* pending) {
     FusedArgs<T> args;
     args.tiles32 = reinterpret_cast<const uint32_t*>(h->tiles);
-    args.wg_tile_begin = h->wg_tile_begin;
     args.rowidx = h->rowidx;
     args.a = static_cast<const T*>(h->a);
     args.c = static_cast<const T*>(h->c);
@@ -812,9 +532,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.slab_ovf = h->slab_ovf;
     args.slab_epoch = ++h->slab_epoch;
     args.n_proj = h->n_proj;
-    args.n_tiles = (uint32_t)(h->layout == 4 ? h->n_short : h->n_tiles);
-    args.n_long = (uint32_t)(h->layout == 4 ? h->n_tiles - h->n_short - h->n_xlong : 0);
-    args.n_xlong = (uint32_t)(h->layout == 4 ? h->n_xlong : 0);
+    args.n_tiles = (uint32_t)h->n_short;
+    args.n_long = (uint32_t)(h->n_tiles - h->n_short - h->n_xlong);
+    args.n_xlong = (uint32_t)h->n_xlong;
     args.desc_words = (uint32_t)h->desc_words;
     args.long32 = args.tiles32 + (size_t)h->n_short * (size_t)h->desc_words + 12;  // (after the windows and one all-zero descriptor)
     args.ablate = h->ablate;
@@ -881,8 +601,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
         }
     }
     int rc;
-    if (h->layout == 4) rc = launch_fused4(h, args, st);
-    else rc = h->row_bytes == 2 ? launch_fused_rt<T, uint16_t>(h, args, st) : launch_fused_rt<T, uint32_t>(h, args, st);
+    rc = launch_fused4(h, args, st);
     if (rc) return rc;
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)

@@ -8,7 +8,6 @@
 
 namespace dl {
 
-constexpr int kBatch = 2;      // tiles a wavefront advances in lock-step (independent dependency chains)
 constexpr int kProjLds = kProjLdsSlots;  // projection table slots in LDS; the last slot is the identity (columns in no entry)
 
 // Kernel-side projection record.  Point-wise operators are all clamp(v, lo, hi) with infinite bounds where absent
@@ -95,118 +94,7 @@ __device__ __forceinline__ LaneConst make_lane_const(int lane) {
     return c;
 }
 
-// Column segments of a short tile from its head mask (bit k <=> lane k starts a column; bit 0 must be set).
-__device__ __forceinline__ SegInfo make_seginfo_fast(uint64_t head, const LaneConst& c) {
-    SegInfo s;
-    const uint32_t hlo = (uint32_t)head, hhi = (uint32_t)(head >> 32);
-    // start: highest head bit at or below this lane
-    const uint32_t blo = hlo & c.le_lo, bhi = hhi & c.le_hi;
-    const int st_lo = 31 - __clz((int)blo);  // blo != 0 whenever bhi == 0 (bit 0 is a head)
-    const int st_hi = 63 - __clz((int)bhi);
-    s.start = bhi ? st_hi : st_lo;
-    // tail: lane before the next head strictly above this lane (63 if none)
-    const uint32_t alo = hlo & c.gt_lo, ahi = hhi & c.gt_hi;
-    const int nx_lo = __ffs((int)alo) - 1;  // -1 when alo == 0
-    const int nx_hi = ahi ? 32 + __ffs((int)ahi) - 1 : 64;
-    const int next = alo ? nx_lo : nx_hi;
-    s.tail = next - 1;
-    s.lane = c.lane;
-    s.d = c.lane - s.start;
-    // bits start..tail
-    const uint64_t upto_tail = (2ull << s.tail) - 1ull;
-    s.segmask = upto_tail & (~0ull << s.start);
-    // scan-step predicates: source lane (lane - o) must be inside the segment and inside this 16-lane DPP row
-    const int lim = s.start > c.row_base ? s.start : c.row_base;
-    s.p1 = c.lane - 1 >= lim;
-    s.p2 = c.lane - 2 >= lim;
-    s.p4 = c.lane - 4 >= lim;
-    s.p8 = c.lane - 8 >= lim;
-    s.pA = (c.lane & 16) && s.start < c.row_base;  // rows 1,3: segment continues from the previous row
-    s.pB = (c.lane & 32) && s.start < 32;          // rows 2,3: segment reaches back past lane 32
-    return s;
-}
-
-// Simplex projection of every column segment of kBatch short tiles in lock-step, one value per lane and tile.
-// Equals _duchi_proj (simplex.py:126-236) column by column: clamp at 0; (inequality) keep if sum <= z + 1e-6;
-// vertex z*e_argmax when only the maximum exceeds max - z (the reference's top-2 shortcut); else
-// x = max(u - theta, 0) with theta = (sum of the support - z) / |support|, found by the monotone Newton (Michelot)
-// iteration started from the lower bound theta_0 = max - z.
-// One segmented MAX scan serves every column; SUM scans run only while some column is neither a vertex nor done.
-// (The feasibility test uses the sum over {u > max - z}, which equals the full sum whenever max < z; for max >= z
-//  the two can differ by at most len * 1e-6 right at the decision boundary -- documented in DESIGN.md.)
-// smp[q] == false (tile absent or not a simplex tile): x[q] is left untouched.
-template <bool USE_DPP, class T>
-__device__ __forceinline__ void simplex_batch(const T (&v)[kBatch], const bool (&valid)[kBatch], const uint64_t (&head)[kBatch],
-                                              const ProjT<T> (&pj)[kBatch], const bool (&smp)[kBatch], const LaneConst& lc, T (&x)[kBatch],
-                                              const int32_t* const (&eq_row)[kBatch]) {
-    SegInfo sg[kBatch];
-    T u[kBatch], th[kBatch], v1[kBatch];
-    bool act[kBatch], proj[kBatch], onehot[kBatch], live[kBatch];
-    int cnt_prev[kBatch];
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-        sg[q] = make_seginfo_fast(head[q] | 1ull, lc);
-        live[q] = valid[q] && smp[q];
-        u[q] = live[q] ? relu(v[q]) : (T)0;
-    }
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) v1[q] = seg_allreduce<USE_DPP>(u[q], sg[q], (T)(-INFINITY), OpMax());
-    bool any_act = false;
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-        th[q] = (T)(v1[q] - pj[q].z);
-        const bool in = u[q] > th[q];
-        const int cnt = __popcll(__ballot(in && live[q]) & sg[q].segmask);
-        onehot[q] = live[q] && cnt == 1 && sg[q].tail > sg[q].start;  // only the maximum exceeds max - z: vertex (simplex.py:177-193)
-        proj[q] = false;
-        act[q] = live[q] && !onehot[q];
-        cnt_prev[q] = 0;
-        any_act = any_act || act[q];
-    }
-    // Newton (Michelot) passes.  Each pass costs one SUM scan per tile that still has an undecided column; whether a
-    // column is done is decided from the ballot alone (the support only shrinks, so an unchanged size means an
-    // unchanged set and th already is the fixed point) -- no extra scan to confirm convergence.
-    if (__any(any_act)) {
-        for (int it = 0; it < 2 * kTileLanes + 2; ++it) {
-            any_act = false;
-#pragma unroll
-            for (int q = 0; q < kBatch; ++q) {
-                if (!__any(act[q])) continue;  // wave-uniform: this tile has nothing left to do
-                const bool in = u[q] > th[q];
-                const int cnt = __popcll(__ballot(in && live[q]) & sg[q].segmask);
-                const bool conv = it > 0 && (cnt == cnt_prev[q] || cnt == 0);
-                act[q] = act[q] && !conv;
-                if (__any(act[q])) {
-                    const T sumA = seg_allreduce<USE_DPP>(in ? u[q] : (T)0, sg[q], (T)0, OpAdd());
-                    T den = (T)cnt;
-                    if (eq_row[q]) {  // simplex_eq compatibility mode (fused_common.h: eq_bucket): sum < z on the first pass means
-                                      // theta < 0, the support is the whole column (cnt = its length) plus the padding zeros
-                        const int b = cnt <= 2 ? 1 : 32 - __clz(cnt - 1);
-                        const T L = (T)eq_row[q][b > 0 ? b : 1];
-                        den = (it == 0 && sumA < pj[q].z) ? L : den;
-                    }
-                    const T th_new = div_exactish((T)(sumA - pj[q].z), den);
-                    // feasible after the clamp (simplex.py:153-158): only decided on the first pass
-                    const bool feas = it == 0 && pj[q].kind == DL_PROJ_SIMPLEX && !(sumA > pj[q].ztol);
-                    const bool upd = act[q] && !feas && cnt != 0;
-                    proj[q] = proj[q] || upd;
-                    th[q] = upd ? tmax(th_new, th[q]) : th[q];  // thresholds never decrease: nested supports, guaranteed termination
-                    cnt_prev[q] = upd ? cnt : cnt_prev[q];
-                    act[q] = upd;
-                }
-                any_act = any_act || act[q];
-            }
-            if (!__any(any_act)) break;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < kBatch; ++q) {
-        const T xg = relu((T)(u[q] - th[q]));             // general: threshold
-        const T xv = (u[q] > th[q]) ? pj[q].z : (T)0;    // vertex
-        T r = proj[q] ? xg : u[q];
-        r = onehot[q] ? xv : r;
-        x[q] = live[q] ? r : x[q];
-    }
-}
+// (The segmented scans of the 64-wide tile -- make_seginfo_fast, simplex_batch -- went with that layout in round 5; the 256-wide tile's are in
+//  simplex4.h, the column-per-lane slices' in sell.h.)
 
 }  // namespace dl

@@ -14,7 +14,7 @@ bytes per non-zero in fp32), adds ``f_k (s[K] - s[K+1])`` to v_k and returns ``s
 objective is then an ordinary matching objective with K + 2 rows: the whole AGD loop stays on the device, any projection
 map works, nothing is rewritten per iteration.
 
-FOLDED -- fallback without kernel support (64-wide tile layout, dual vector not in LDS): the two dense rows are folded into
+FOLDED -- fallback without kernel support (staged inputs -- unaligned or tiny value arrays --, dual vector not in LDS): the two dense rows are folded into
 the cost the fused pass sees.  With d = lambda_K - lambda_{K+1},
 
     v_k = a_k s[r_k] + (-1/gamma) (c_k + d f_k)

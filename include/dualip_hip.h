@@ -121,7 +121,7 @@ int dl_matching_update_values(dl_matching* h, dl_stream_t stream);
  * 11 single-column tiles long enough (> 1024 non-zeros; > 2048 for handles of the second binary) to be walked by a whole workgroup,
  * 12 column-per-lane slices (64 short columns of a simplex entry each, sorted by length; the handle owns a transposed copy of
  * their values and row indices), 13 columns in slices, 14 slice elements including padding, 15 non-zeros in slices,
- * 16 dwords per window descriptor (12; 2 when every window is point-wise: compact table; 4 for the 64-wide layout),
+ * 16 dwords per window descriptor (12; 2 when every window is point-wise: compact table),
  * 17 columns of slices that hold more than one column length (only their length bytes are read per launch),
  * 18 + w (w < 1024): rounds of workgroup w in the window tiles' cyclic deal (-1: no table; synchronous device read),
  * 2000 columns held in slices with K = 2 .. 32 lanes per column (counted in 13 too): those of 25 .. 512 non-zeros, and a handle's

@@ -62,7 +62,7 @@ def test_more_than_65536_rows(hot, monkeypatch):
     m, n = 70_000, 6_000
     p = _random_problem(m, n, 9, seed=5)
     lam = np.random.default_rng(1).uniform(0, 0.01, m)
-    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"
+    narrow = False  # (one tile layout since round 5)
     for dn in ("f32", "f64"):
         for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0})):
             f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
@@ -106,7 +106,7 @@ def test_unaligned_values_and_tiny_problems_are_staged_into_the_same_kernel():
     from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
 
-    forced_narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the suite can still be run with the narrow layout forced)
+    forced_narrow = False  # (the 64-wide layout and its switch are gone)
     p = _random_problem(120, 900, 7, seed=3, long_cols=((5, 100), (400, 90)), empty_every=37)
     lam = np.random.default_rng(4).uniform(0, 0.05, p["m"])
     pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
@@ -182,8 +182,6 @@ def test_pointwise_windows_cut_through_columns(host_pack, monkeypatch):
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from dualip_amd.projections.base import ProjectionEntry
 
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
-        pytest.skip("the 64-wide layout has no windows")
     if host_pack:
         monkeypatch.setenv("DUALIP_HIP_HOST_PACK", "1")
     m, n = 3_000, 5_000
@@ -292,7 +290,7 @@ def test_32_bit_gradient_slabs_are_the_same_exact_sums(monkeypatch):
     from dualip_amd.projections import create_projection_map
     from dualip_amd.projections.base import ProjectionEntry
 
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SLAB32") is not None or os.environ.get("DUALIP_HIP_LDS_MODE") in ("grad", "none"):
+    if os.environ.get("DUALIP_HIP_SLAB32") is not None or os.environ.get("DUALIP_HIP_LDS_MODE") in ("grad", "none"):
         pytest.skip("states the default plan of the 256-wide layout")
     m, n = 500, 120_000  # (enough tiles for >= 128 workgroups: smaller handles keep 64-bit slabs -- a workgroup's share would be most of a row)
     p = _random_problem(m, n, 10, seed=77, long_cols=[(11, 300), (39_000, 90)])
@@ -395,7 +393,7 @@ def test_hot_rows_plan(forced, monkeypatch):
     lam = np.random.default_rng(5).uniform(0, 0.02, m)
     import os
 
-    narrow = os.environ.get("DUALIP_HIP_LAYOUT") == "1"  # (the plan belongs to the 256-wide layout; the numbers must agree anyway)
+    narrow = False  # (one tile layout since round 5)
     for dn in ("f32", "f64"):
         f = _compare(p, pm, entries, col_proj, 0.05, dn, lam)
         info = f.info()
@@ -473,7 +471,7 @@ def test_columns_walked_by_a_whole_workgroup(forced, monkeypatch):
         for pt, pp in (("simplex", {"z": 1.0}), ("simplex", {"z": 40.0}), ("box", {"lower": 0.0, "upper": 0.5})):
             f = _compare(p, create_projection_map(pt, dict(pp), n), [(pt, pp)], None, 0.05, dn, lam)
             info = f.info()
-            assert info["long_columns"] >= 9 and (info["layout"] != 4 or info["workgroup_columns"] == want_of(info)), info  # (DUALIP_HIP_LAYOUT=1 runs: one walker only)
+            assert info["long_columns"] >= 9 and info["workgroup_columns"] == want_of(info), info
         # simplex_eq, exact mode (the oracle's padded blocks differ wherever a clamped column sums to less than z): every
         # non-empty column sums to z, and columns without a deficit agree with the oracle
         td = torch.float32 if dn == "f32" else torch.float64
@@ -574,8 +572,6 @@ def test_xcd_weighted_deal_keeps_every_tile(monkeypatch):
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
 
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1":
-        pytest.skip("the 64-wide layout deals contiguous ranges")
     n, m = 3_000_000, 2_000
     prob = generate_matching_problem(n, m, 5e-3, seed=5, device=torch.device(DEV), dtype=torch.float32)
     inp = prob["input_args"]
@@ -620,7 +616,7 @@ def test_two_phase_deal_of_the_slices_keeps_every_slice(monkeypatch):
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
 
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SELL") == "0":
+    if os.environ.get("DUALIP_HIP_SELL") == "0":
         pytest.skip("no column-per-lane slices under this switch")
     n, m = 1_500_000, 2_000
     prob = generate_matching_problem(n, m, 5e-3, seed=9, device=torch.device(DEV), dtype=torch.float32)
@@ -708,7 +704,7 @@ def test_release_inputs_makes_the_handle_self_contained(order):
     from dualip_amd.optimizers.agd import AcceleratedGradientDescent
     from dualip_amd.projections import create_projection_map
 
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SELL") == "0":
+    if os.environ.get("DUALIP_HIP_SELL") == "0":
         pytest.skip("what the handle keeps is stated for the 256-wide layout with slices")
     p = _random_problem(500, 60000, 9, seed=21, long_cols=[(7, 300), (59990, 400)])
     n, half = p["n"], p["n"] // 2

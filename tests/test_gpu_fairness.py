@@ -24,7 +24,7 @@ def _objective(p, dn, mn, delta, ratio, **kw):
 def _native_possible():
     import os
 
-    return os.environ.get("DUALIP_HIP_LAYOUT") != "1"  # the fairness stream belongs to the 256-wide tile layout
+    return True  # (one tile layout since round 5)
 
 
 @pytest.mark.parametrize("native", [True, False])

@@ -49,7 +49,7 @@ def _solve(f, iters, gamma0, decay):
 
 @pytest.mark.parametrize("kind", ["simplex_continuation", "mixed"])
 def test_ten_million_entities_through_the_device_loop(kind):
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SELL") == "0":
+    if os.environ.get("DUALIP_HIP_SELL") == "0":
         pytest.skip("asserts the default kernel plan (256-wide layout with slices)")
     from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
     from tests.helpers import verify_at_size
@@ -104,7 +104,7 @@ def test_movielens_shape_at_full_size_under_the_checker():
     in-place one-column slices, whole-workgroup columns, all at once in fp32.  50 iterations of the device loop, then the checker
     of bench.py (oracle slabs incl. a column of every length class, sums recomputed in float64, the two-handle route) at the
     solve's duals and at a stress dual vector that multiplies the Newton passes."""
-    if os.environ.get("DUALIP_HIP_LAYOUT") == "1" or os.environ.get("DUALIP_HIP_SELL") == "0":
+    if os.environ.get("DUALIP_HIP_SELL") == "0":
         pytest.skip("asserts the default kernel plan (256-wide layout with slices)")
     from benchmark.movielens_like import LENGTH_CLASSES, generate, stress_duals
     from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
@@ -142,13 +142,12 @@ def test_movielens_shape_at_full_size_under_the_checker():
         assert "recomputed from the primal" in names and "sharded route" in names
 
 
-@pytest.mark.parametrize("switch", [("DUALIP_HIP_LAYOUT", "1"), ("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0"),
+@pytest.mark.parametrize("switch", [("DUALIP_HIP_SELL", "0"), ("DUALIP_HIP_LANES_BINARY", "1"), ("DUALIP_HIP_LANES_BINARY", "0"), ("DUALIP_HIP_SELL_LANES", "0"),
                                     ("DUALIP_HIP_FLAT", "0"), ("DUALIP_HIP_FLAT", "1"), ("DUALIP_HIP_COMPACT", "0"), ("DUALIP_HIP_HOST_PACK", "1"), ("DUALIP_HIP_ROW32", "1"),
                                     ("DUALIP_HIP_XCD_BALANCE", "0"), ("DUALIP_HIP_LDS_MODE", "grad"), ("DUALIP_HIP_LDS_MODE", "none"), ("DUALIP_HIP_HOT_ROWS", "64")])
 def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
-    """The reference's golden ``calculate`` cases (fixture G1) with the 64-wide tile layout forced, and with the column-per-lane
-    slices switched off (every simplex column in window tiles): the plans a default run only reaches through unaligned or
-    tiny inputs; with the fused kernel's second binary (K-lane slices, in-place single-column slices, dynamic deal inside a workgroup)
+    """The reference's golden ``calculate`` cases (fixture G1) with the column-per-lane slices switched off (every simplex column in
+    window tiles); with the fused kernel's second binary (K-lane slices, in-place single-column slices, dynamic deal inside a workgroup)
     forced on and off for the handles free to use either; with one lane per column only; and under every other layout switch of
     INTEGRATION.md (whole-column / unaligned point-wise windows, 12-dword descriptors, host packing, 32-bit rows, the even deal, the
     smaller LDS plans, a forced hot-rows plan)."""
@@ -170,9 +169,7 @@ def test_goldens_under_the_alternative_kernel_plans(switch, monkeypatch):
                 pt, pp = SINGLE_MAPS[mk]
                 objs[(mk, dn)] = MatchingSolverDualObjectiveFunction(torch_args(p, dn, create_projection_map(pt, dict(pp), p["n"]), DEV), float(g))
                 info = objs[(mk, dn)].info()
-                if switch[0] == "DUALIP_HIP_LAYOUT":
-                    assert info["layout"] == 1, info
-                elif switch[0] == "DUALIP_HIP_SELL":
+                if switch[0] == "DUALIP_HIP_SELL":
                     assert info["slices"] == 0, info
                 elif switch[0] == "DUALIP_HIP_SELL_LANES":
                     assert info["slice_lane_columns"] == 0, info

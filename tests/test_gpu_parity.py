@@ -40,9 +40,9 @@ def _scal(res):
     )
 
 
-@pytest.fixture(params=["dpp", "bpermute"])
-def scan_mode(request, monkeypatch):
-    monkeypatch.setenv("DUALIP_HIP_NO_DPP", "0" if request.param == "dpp" else "1")
+@pytest.fixture(params=["dpp"])
+def scan_mode(request):
+    """(Rounds 1-4 ran these goldens under both scan implementations of the 64-wide tile; that layout is gone, the 256-wide tile has one.)"""
     return request.param
 
 

@@ -11,7 +11,7 @@ import torch
 import oracle
 from tests.helpers import NP_DT, RTOL, load, problem, relerr, torch_args
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("DUALIP_HIP_LAYOUT") == "1", reason="slices belong to the 256-wide tile layout")]
+pytestmark = [pytest.mark.gpu]
 DEV = "cuda:0"
 TD = {"f32": torch.float32, "f64": torch.float64}
 

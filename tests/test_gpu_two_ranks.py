@@ -123,9 +123,6 @@ def _worker(rank, world, port, kind, q):
 def test_two_ranks_share_one_gpu(kind):
     from tests.helpers import load, relerr
 
-    if kind == "fairness" and os.environ.get("DUALIP_HIP_LAYOUT") == "1":
-        pytest.skip("the fairness stream belongs to the 256-wide tile layout")
-
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
