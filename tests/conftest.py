@@ -10,7 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
-    config.addinivalue_line("markers", "world8: eight ranks sharing the one GPU of the test box (collected first: see pytest_collection_modifyitems)")
 
 
 def _has_gpu():
@@ -22,17 +21,7 @@ def _has_gpu():
         return False
 
 
-def _eight_ranks_on_one_gpu(item) -> bool:
-    """World-8 tests of the one-GPU harness: eight worker processes sharing cuda:0 (tests/test_gpu_comm.py, test_gpu_two_ranks.py)."""
-    cs = getattr(item, "callspec", None)
-    return ("gpu" in item.keywords) and ((cs is not None and cs.params.get("world") == 8) or "eight_ranks" in item.name)
-
-
 def pytest_collection_modifyitems(config, items):
-    # The world-8 tests run FIRST, before the runner itself holds a context on the GPU: with a ninth context on the device the eight workers
-    # of the sharded C loop sit in the exchange's first in-kernel waits until the bound -- measured on the GPU box, six runs each way
-    # (profiles/r05_world8_on_one_gpu.md); a runner without a context never showed it.  (A stable sort: every other test keeps its place.)
-    items.sort(key=lambda it: 0 if _eight_ranks_on_one_gpu(it) else 1)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

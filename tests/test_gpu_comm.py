@@ -31,17 +31,16 @@ def _free_port():
     return port
 
 
-def _eight_ranks_need_a_clean_parent(world) -> None:
-    """EIGHT ranks on ONE GPU (this box's stand-in for the 8-GPU node) are eight processes sharing the device.  Measured on the GPU box
-    (profiles/r05_world8_on_one_gpu.md): with a NINTH process holding a context on the same device -- the pytest runner itself once an earlier
-    test has touched the GPU, even when the workers' direct parent is a fresh interpreter -- the eight workers of the sharded C loop (every
-    kernel of their exchange is one block) sit in the first in-kernel waits of the exchange until the bound and report a timed-out
-    exchange, with 1000, 200 or 20 soak rounds alike; from a runner WITHOUT a context the same workers pass in 4 s, every time.  Capping the
-    runtime at two hardware queues per process made it worse; the stand-alone all-reduce workers (40 blocks per kernel) and bench.py's own
-    eight ranks pass either way.  A scheduling property of nine contexts on one device, which one process per GPU never meets.
-    tests/conftest.py therefore collects the world-8 tests FIRST; run out of order (a runner that already holds a context) they say so."""
-    if world >= 8 and torch.cuda.is_initialized():
-        pytest.skip("eight ranks on this one GPU need a test runner that holds no GPU context yet (tests/conftest.py runs them first; or run this test alone)")
+def _eight_ranks_on_one_gpu(world, monkeypatch) -> None:
+    """EIGHT ranks on ONE GPU (this box's stand-in for the 8-GPU node) are eight processes sharing the device -- nine with the test runner.
+    Root-caused on the GPU box (profiles/r05_world8_on_one_gpu.md, tools/world8_probe.py): once NINE processes have each used the device's
+    COPY ENGINES (any host <-> device copy creates a copy-engine queue; the device serves eight such processes), the driver's run list is
+    oversubscribed and the hardware scheduler time-slices it -- the one-block kernels of the sharded C loop's exchange then sit in their
+    in-kernel waits until the bound, and every rank reports a timed-out exchange.  Eight such processes, or nine of which one never
+    copied, are fine; so is one process per GPU.  The world-8 workers are therefore spawned with HSA_ENABLE_SDMA=0: their copies run as
+    blit kernels on their compute queues and create no copy-engine queue (2.3 s instead of a 60 s failure, whatever the runner did before)."""
+    if world >= 8:
+        monkeypatch.setenv("HSA_ENABLE_SDMA", "0")
 
 
 def _allreduce_worker(rank, world, port, q, backend="p2p", expect=None, fail=""):
@@ -83,12 +82,12 @@ def _allreduce_worker(rank, world, port, q, backend="p2p", expect=None, fail="")
 
 @pytest.mark.parametrize("world,backend,expect,fail", [(2, "p2p", "p2p", ""), (4, "p2p", "p2p", ""), (8, "p2p", "p2p", ""), (8, "p2p-fenced", "p2p-fenced", ""),
                                                         (2, "p2p-fenced", "p2p-fenced", ""), (2, "auto", "p2p-fenced", "p2p")])
-def test_p2p_allreduce_is_exact_under_uneven_load(world, backend, expect, fail):
+def test_p2p_allreduce_is_exact_under_uneven_load(world, backend, expect, fail, monkeypatch):
     """Both orderings of the exchange (comm.h): the default one and the fenced, by-the-book one; and the creation-time
     fallback auto -> p2p (soak test made to fail by the test hook) -> p2p-fenced, after which the exchange must be exact.
     World 8 is the target machine's (benchmark/run_matching_benchmark_dist.py:33-193): mail_sum's batch of eight loads in
     flight is only full there, and the mailbox holds eight slots per parity."""
-    _eight_ranks_need_a_clean_parent(world)
+    _eight_ranks_on_one_gpu(world, monkeypatch)
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
@@ -170,10 +169,10 @@ def _loop_worker(rank, world, port, kind, q):
 
 
 @pytest.mark.parametrize("kind,world", [("simplex", 2), ("mixed", 2), ("simplex", 4), ("simplex", 8), ("mixed", 8), ("simplex-nocomm", 2), ("simplex-emptyrank", 2)])
-def test_sharded_c_loop_matches_reference_goldens(kind, world):
+def test_sharded_c_loop_matches_reference_goldens(kind, world, monkeypatch):
     from tests.helpers import load, relerr
 
-    _eight_ranks_need_a_clean_parent(world)
+    _eight_ranks_on_one_gpu(world, monkeypatch)
 
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -355,10 +354,10 @@ def _fault_allreduce_worker(rank, world, port, q, flipper=1, flip_victim=0, stal
 
 
 @pytest.mark.parametrize("world,flipper,flip_victim,staler,stale_victim", [(2, 1, 0, 0, 1), (8, 7, 0, 3, 7)])
-def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops(world, flipper, flip_victim, staler, stale_victim):
+def test_a_corrupted_or_stale_slot_is_detected_and_every_rank_stops(world, flipper, flip_victim, staler, stale_victim, monkeypatch):
     """World 8: the damaged slot is the LAST one of a mailbox (rank 7's contribution, then rank 7's own mailbox) -- the end of the
     batch of eight loads of comm.h:mail_sum and of the flag line array."""
-    _eight_ranks_need_a_clean_parent(world)
+    _eight_ranks_on_one_gpu(world, monkeypatch)
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()

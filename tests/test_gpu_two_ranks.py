@@ -272,7 +272,7 @@ def test_bench_harness_with_eight_ranks_on_one_gpu():
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(DUALIP_BENCH_ONE_DEVICE="1", DUALIP_COMM_SOAK_ROUNDS="200")
+    env.update(DUALIP_BENCH_ONE_DEVICE="1", DUALIP_COMM_SOAK_ROUNDS="200", HSA_ENABLE_SDMA="0")  # (nine processes on one device: no copy-engine queues for the ranks, tests/test_gpu_comm.py)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--entities", "800000", "--steps", "4", "--warmup", "2", "--no-late"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
