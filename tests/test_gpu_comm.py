@@ -311,16 +311,26 @@ def _fault_allreduce_worker(rank, world, port, q, flipper=1, flip_victim=0, stal
         g = torch.Generator(device="cuda:0").manual_seed(99)
         events = []
 
+        seen = []  # (diagnostics of a wrong healthy round: which elements, by how much)
+
         def rounds(k):
             bad = 0
             for _ in range(k):
                 parts = torch.randint(-1000, 1000, (world, n), generator=g, device="cuda:0").double()
                 v = parts[rank].clone()
                 comm.all_reduce_(v)
-                bad += int((v != parts.sum(0)).sum())
+                wrong = v != parts.sum(0)
+                nb = int(wrong.sum())
+                if nb and len(seen) < 3:
+                    idx = torch.nonzero(wrong).flatten()[:6]
+                    diff = (v - parts.sum(0))[idx]
+                    who = [[int(r) for r in range(world) if float(parts[r, i]) == float(d) or float(parts[r, i]) == -float(d)] for i, d in zip(idx.tolist(), diff.tolist())]
+                    seen.append((comm.exchanges, nb, idx.tolist(), diff.tolist(), who, comm.status()))
+                bad += nb
             return bad
 
-        assert rounds(10) == 0
+        healthy = rounds(10)
+        assert healthy == 0, (rank, healthy, seen)
         comm.meet()  # healthy: passes on every rank
         # 1. rank `flipper` stores one element with a flipped bit into rank `flip_victim`'s mailbox: the victim must notice, EVERY rank must raise
         if rank == flipper:
