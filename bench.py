@@ -435,6 +435,10 @@ def respawn_under_torchrun(args):
 
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.pop("MASTER_PORT", None)
+    if os.environ.get("DUALIP_BENCH_ONE_DEVICE") == "1" and args.gpus >= 8:
+        # developer mode, eight or more ranks on ONE device: a ninth process with a copy-engine queue oversubscribes the driver's run list and the
+        # exchange's in-kernel waits stall (profiles/r05_world8_on_one_gpu.md); the ranks copy with blit kernels instead.  One rank per GPU: untouched.
+        env.setdefault("HSA_ENABLE_SDMA", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
