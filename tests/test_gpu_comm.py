@@ -43,6 +43,17 @@ def _eight_ranks_on_one_gpu(world, monkeypatch) -> None:
         monkeypatch.setenv("HSA_ENABLE_SDMA", "0")
 
 
+def _open_every_queue_first():
+    """A rank's first host <-> device copy, first random draw and first reduction make the runtime open queues and load code objects.  If
+    that happens while OTHER ranks of the one-GPU harness already sit in an in-kernel wait of the exchange, the newcomer's queue may find no
+    hardware slot (the spinning kernels never yield theirs) and everybody waits for everybody until the bound -- seen as a stall of the FIRST
+    exchange after the soak test (profiles/r05_world8_on_one_gpu.md).  So every worker touches all of it before its communicator exists."""
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    t = torch.randint(-5, 5, (2, 64), generator=g, device="cuda:0").double()
+    int((t.sum(0) != t[0].clone()).sum())
+    torch.cuda.synchronize()
+
+
 def _allreduce_worker(rank, world, port, q, backend="p2p", expect=None, fail=""):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -55,6 +66,7 @@ def _allreduce_worker(rank, world, port, q, backend="p2p", expect=None, fail="")
     try:
         from dualip_amd.utils.comm import Communicator
 
+        _open_every_queue_first()
         n = 10_002
         comm = Communicator(n, "cuda:0", backend=backend)
         assert comm.backend == (expect or backend) and comm.info()["world"] == world, comm.info()
@@ -305,6 +317,7 @@ def _fault_allreduce_worker(rank, world, port, q, flipper=1, flip_victim=0, stal
     try:
         from dualip_amd.utils.comm import CHECKSUM, Communicator, ExchangeError
 
+        _open_every_queue_first()
         n = 10_002
         comm = Communicator(n, "cuda:0", backend="auto")
         assert comm.backend == "p2p" and comm.info()["payload_checksums"] and comm.info()["distinct_devices"] == 1
