@@ -196,6 +196,38 @@ __global__ __launch_bounds__(1024) void read_stream3_deep_kernel(const read_vec4
     if (acc == 12345.678f) *sink = acc;
 }
 
+// ... and with the work CLAIMED instead of dealt: the XCDs of this part do not stream at the same speed (the fused kernel deals its window
+// tiles by measured shares for that reason, fused_common.h: Deal), so a static deal ends with the slow XCDs' tail while the fast ones idle --
+// which is how a kernel could beat the probe that judges it.  Every workgroup claims the next chunk of kDynSteps x 1024 lanes from a counter
+// (one atomic per 160 KB) until the arrays are exhausted.
+constexpr int kDynSteps = 4;
+__global__ __launch_bounds__(1024) void read_stream3_dyn_kernel(const read_vec4* __restrict__ pa, const read_vec4* __restrict__ pc, const read_vec2* __restrict__ pr, size_t n,
+                                                                unsigned long long* __restrict__ counter, float* __restrict__ sink) {
+    __shared__ unsigned long long chunk_s;
+    float acc = 0.f;
+    const size_t per = (size_t)kDynSteps * 1024;
+    for (;;) {
+        if (threadIdx.x == 0) chunk_s = atomicAdd(counter, 1ull);
+        __syncthreads();
+        const size_t base = (size_t)chunk_s * per;
+        __syncthreads();
+        if (base >= n) break;
+        read_vec4 a[kDynSteps], c[kDynSteps];
+        read_vec2 r[kDynSteps];
+#pragma unroll
+        for (int u = 0; u < kDynSteps; ++u) {
+            size_t i = base + (size_t)u * 1024 + threadIdx.x;
+            i = i < n ? i : n - 1;
+            a[u] = __builtin_nontemporal_load(pa + i);
+            c[u] = __builtin_nontemporal_load(pc + i);
+            r[u] = __builtin_nontemporal_load(pr + i);
+        }
+#pragma unroll
+        for (int u = 0; u < kDynSteps; ++u) acc += a[u][0] + c[u][0] + r[u][0];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
 static int grid_for(int64_t n, int threads) {
     const int64_t b = (n + threads - 1) / threads;
     return (int)(b > 8192 ? 8192 : (b > 0 ? b : 1));
@@ -224,17 +256,20 @@ int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, doub
     DL_HIP(hipMalloc((void**)&sink, sizeof(float)));
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    // four access shapes, the best one is reported: one stream of 16-byte loads; three streams side by side (40 bytes per lane and step), two,
+    // five access shapes, the best one is reported (the last: the three streams with dynamically claimed chunks): one stream of 16-byte loads; three streams side by side (40 bytes per lane and step), two,
     // four or eight steps of a lane in flight
     const size_t n3 = ((size_t)bytes / 40) & ~(size_t)((size_t)256 * 1024 * 8 - 1);  // lanes x steps of the three-stream shapes (whole rounds at every depth)
     const char* base = (const char*)buf;
     double best_gbps = 0.0;
-    for (int shape = 0; shape < 4 && e == hipSuccess; ++shape) {
+    unsigned long long* dyn_counter = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&dyn_counter, sizeof(unsigned long long));
+    for (int shape = 0; shape < 5 && e == hipSuccess; ++shape) {
         if (shape > 0 && n3 == 0) break;
         float best = 1e30f;
         const double moved = shape == 0 ? (double)bytes : (double)n3 * 40.0;
         for (int r = 0; r <= reps && e == hipSuccess; ++r) {  // (first pass untimed)
-            e = hipEventRecord(e0, st);
+            if (shape == 4) e = hipMemsetAsync(dyn_counter, 0, sizeof(unsigned long long), st);  // (ahead of the timed launch)
+            if (e == hipSuccess) e = hipEventRecord(e0, st);
             if (shape == 0)
                 hipLaunchKernelGGL(read_stream_kernel, dim3(256), dim3(1024), 0, st, (const read_vec4*)buf, (size_t)bytes / 16, sink);
             else if (shape == 1)
@@ -243,9 +278,12 @@ int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, doub
             else if (shape == 2)
                 hipLaunchKernelGGL(read_stream3_deep_kernel<4>, dim3(512), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
                                    (const read_vec2*)(base + n3 * 32), n3, sink);
-            else
+            else if (shape == 3)
                 hipLaunchKernelGGL(read_stream3_deep_kernel<8>, dim3(256), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
                                    (const read_vec2*)(base + n3 * 32), n3, sink);
+            else
+                hipLaunchKernelGGL(read_stream3_dyn_kernel, dim3(512), dim3(1024), 0, st, (const read_vec4*)base, (const read_vec4*)(base + n3 * 16),
+                                   (const read_vec2*)(base + n3 * 32), n3, dyn_counter, sink);
             if (e == hipSuccess) e = hipEventRecord(e1, st);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             float ms = 0.f;
@@ -257,6 +295,7 @@ int dl_measure_read_bandwidth(const void* buf, int64_t bytes, int32_t reps, doub
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (dyn_counter) (void)hipFree(dyn_counter);
     (void)hipFree(sink);
     if (e != hipSuccess) return hip_fail(e, "read bandwidth measurement");
     *gbps_out_host = best_gbps;
