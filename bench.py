@@ -193,8 +193,9 @@ def _cpu_sample(args, inp, pm_local, n_cols):
 
 
 def read_ceiling_gbps(device, nbytes=10 << 30, reps=5):
-    """Streaming READ rate of this box, best of four access shapes (16-byte non-temporal loads; one stream, or the fused kernel's three
-    streams side by side with two, four or eight steps of a lane in flight -- dl_measure_read_bandwidth): a PROBE, not a proven ceiling.
+    """Streaming READ rate of this box, best of five access shapes (16-byte non-temporal loads; one stream, or the fused kernel's three
+    streams side by side with two, four or eight steps of a lane in flight, or with chunks CLAIMED dynamically by the workgroups -- the XCDs
+    stream at different speeds, a static deal ends in the slow ones' tail -- dl_measure_read_bandwidth): a PROBE, not a proven ceiling.
     The default buffer is as large as the headline launch's stream (10 GiB; the 4 GiB, two-deep probe of round 4 read 5 % slower than the
     kernel it was held against).  `physical_frac` should be read against it besides the 8 TB/s of the data sheet."""
     import ctypes
