@@ -496,7 +496,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
-    from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction, MatchingSolverDualObjectiveFunctionDistributed
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction, MatchingSolverDualObjectiveFunctionDistributed
     from dualip_amd.optimizers.agd import AcceleratedGradientDescent
 
     n, m = args.entities, args.destinations

@@ -29,7 +29,6 @@ gradient scale is derived from max|c| only for unbounded projections, and the co
 The reference ships no runnable code for this extension; tests compare against oracle/fairness_oracle.py and against a
 fixture produced by composing the reference's own sparse operators (tests/golden/make_golden_fair.py).
 """
-import ctypes
 from typing import Optional
 
 import torch

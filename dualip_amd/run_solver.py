@@ -8,7 +8,6 @@ run_solver.py:60-67, so this is the intended behaviour rather than a copy of it)
 """
 import dataclasses
 import os
-from dataclasses import fields
 from typing import Optional
 
 import torch

@@ -2,7 +2,7 @@
 
   * more than 65 536 dual rows  -> 32-bit row indices, the dual vector and the gradient no longer fit the LDS (global-atomic plan)
   * more than 255 projection entries -> entries beyond the LDS table are served by the single-column path
-  * value arrays that are not 16-byte aligned, and tiny problems -> the 64-wide tile layout
+  * value arrays that are not 16-byte aligned, and tiny problems -> aligned, zero-padded copies owned by the handle
   * columns longer than a 256-element window, empty columns, an all-empty problem, a column range of one operator inside another
 Tolerance: RTOL of tests/helpers.py (2e-4 fp32 / 1e-9 fp64, relative to the largest magnitude).
 """
@@ -101,17 +101,14 @@ def test_unaligned_values_and_tiny_problems_are_staged_into_the_same_kernel():
     """Value arrays that are not 16-byte aligned, and problems of fewer than 1024 non-zeros, used to take a second (64-wide) kernel; since
     round 5 the handle reads its own aligned, zero-padded copies and every input takes the 256-wide layout: the unaligned handle returns
     the SAME BITS as the aligned one, value refreshes follow the caller's arrays, tiny problems agree with the oracle."""
-    import os
-
     from dualip_amd.objectives.matching import MatchingInputArgs, MatchingSolverDualObjectiveFunction
     from dualip_amd.projections import create_projection_map
 
-    forced_narrow = False  # (the 64-wide layout and its switch are gone)
     p = _random_problem(120, 900, 7, seed=3, long_cols=((5, 100), (400, 90)), empty_every=37)
     lam = np.random.default_rng(4).uniform(0, 0.05, p["m"])
     pm = create_projection_map("simplex", {"z": 1.0}, p["n"])
     ref = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=0.05)
-    assert ref.info()["layout"] == (1 if forced_narrow else 4)
+    assert ref.info()["layout"] == 4
     want = ref.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
     want_grad, want_x, want_obj = want.dual_gradient.clone(), want.primal_var.clone(), float(want.dual_objective)
     # the same values one element into a larger buffer: 4-byte aligned, not 16-byte aligned
@@ -125,26 +122,23 @@ def test_unaligned_values_and_tiny_problems_are_staged_into_the_same_kernel():
     C = torch.sparse_csc_tensor(colptr, rowidx, c_buf[1 : nnz + 1], size=(p["m"], p["n"]), check_invariants=False)
     if A.values().data_ptr() % 16 != 0:  # (torch may copy the slice into a fresh, aligned allocation: then there is nothing to test)
         f = MatchingSolverDualObjectiveFunction(MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=torch.from_numpy(p["b"]).float().to(DEV), equality_mask=None), gamma=0.05)
-        assert f.info()["layout"] == (1 if forced_narrow else 4)
+        assert f.info()["layout"] == 4
         got = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
-        if forced_narrow:  # (two kernel plans in fp32: the thresholds of a column are summed in different orders -- 16 fp32 ulps)
-            assert relerr(got.dual_gradient.cpu().numpy(), want_grad.cpu().numpy()) < 2e-6 and relerr(got.primal_var.cpu().numpy(), want_x.cpu().numpy()) < 4e-6
-        else:
-            assert torch.equal(got.dual_gradient, want_grad) and torch.equal(got.primal_var, want_x) and float(got.dual_objective) == want_obj
-            # the handle reads COPIES: an in-place change of the caller's arrays reaches it through values_changed(), as for every handle
-            a_buf[1 : nnz + 1].mul_(0.5)
-            f.values_changed()
-            half = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
-            q = dict(p, a=p["a"] * 0.5)
-            ax, obj0, ssq, x = oracle.matching_calculate(q["m"], q["n"], q["colptr"], q["rowidx"], q["a"].astype(np.float32), q["c"], lam, 0.05, [("simplex", {"z": 1.0})], dtype=np.float32)
-            grad, obj, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, q["b"], 0.05, np.float32)
-            assert relerr(half.dual_gradient.cpu().numpy(), grad) < RTOL["f32"] and relerr(half.primal_var.cpu().numpy(), x) < RTOL["f32"]
+        assert torch.equal(got.dual_gradient, want_grad) and torch.equal(got.primal_var, want_x) and float(got.dual_objective) == want_obj
+        # the handle reads COPIES: an in-place change of the caller's arrays reaches it through values_changed(), as for every handle
+        a_buf[1 : nnz + 1].mul_(0.5)
+        f.values_changed()
+        half = f.calculate(torch.from_numpy(lam).float().to(DEV), save_primal=True)
+        q = dict(p, a=p["a"] * 0.5)
+        ax, obj0, ssq, x = oracle.matching_calculate(q["m"], q["n"], q["colptr"], q["rowidx"], q["a"].astype(np.float32), q["c"], lam, 0.05, [("simplex", {"z": 1.0})], dtype=np.float32)
+        grad, obj, *_ = agd_oracle.epilogue(ax, obj0, ssq, lam, q["b"], 0.05, np.float32)
+        assert relerr(half.dual_gradient.cpu().numpy(), grad) < RTOL["f32"] and relerr(half.primal_var.cpu().numpy(), x) < RTOL["f32"]
     # fewer than 1024 non-zeros (down to a 5 x 5 problem and an empty one elsewhere in the suite): the same layout on a padded copy
     q = _random_problem(40, 60, 6, seed=8, empty_every=7)
     for dn in ("f32", "f64"):
         for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0}), ("simplex_eq", {"z": 1.0})):
             f = _compare(q, create_projection_map(pt, dict(pp), q["n"]), [(pt, pp)], None, 0.05, dn, np.random.default_rng(6).uniform(0, 0.05, q["m"]))
-            assert f.info()["layout"] == (1 if forced_narrow else 4)
+            assert f.info()["layout"] == 4
 
 
 def test_long_columns_empty_columns_and_nested_ranges():

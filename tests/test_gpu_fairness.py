@@ -21,18 +21,10 @@ def _objective(p, dn, mn, delta, ratio, **kw):
     return MatchingFairnessDualObjectiveFunction(args, gamma=0.02, group_ratio=ratio, **kw)
 
 
-def _native_possible():
-    import os
-
-    return True  # (one tile layout since round 5)
-
-
 @pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("dn", ["f32", "f64"])
 @pytest.mark.parametrize("mn", ["simplex1", "box01"])
 def test_calculate_matches_reference_operators(dn, mn, native):
-    if native and not _native_possible():
-        pytest.skip("64-wide layout forced")
     z = load("gf_fairness.npz")
     p = problem(load("g1_syn2000.npz"))
     f = _objective(p, dn, mn, float(z["delta"]), float(z["group_ratio"]), native=native)
@@ -54,8 +46,6 @@ def test_calculate_matches_reference_operators(dn, mn, native):
 def test_agd_solve_matches_reference_trace(mn, native):
     from dualip_amd.optimizers.agd import AcceleratedGradientDescent
 
-    if native and not _native_possible():
-        pytest.skip("64-wide layout forced")
     z = load("gf_fairness.npz")
     p = problem(load("g1_syn2000.npz"))
     f = _objective(p, "f64", mn, float(z["delta"]), float(z["group_ratio"]), native=native)
@@ -88,7 +78,7 @@ def test_custom_coefficients_against_the_oracle_and_argument_checks():
     short = args.b_vec
     args.b_vec = torch.from_numpy(b_full).float().to(DEV)
     grad, obj, reg, primal, x = fairness_oracle.fairness_calculate(p, fv, lam, 0.02, ("simplex", {"z": 1.0}), b_full, np.float32)
-    for native in ([True, False] if _native_possible() else [False]):
+    for native in (True, False):
         f = MatchingFairnessDualObjectiveFunction(args, gamma=0.02, A_fairness=torch.from_numpy(fv).to(DEV), native=native)
         r = f.calculate(torch.from_numpy(lam).to(DEV), save_primal=True)
         assert relerr(r.primal_var.cpu().numpy(), x) < RTOL["f32"]
@@ -101,11 +91,11 @@ def test_custom_coefficients_against_the_oracle_and_argument_checks():
     cone.b_vec = torch.from_numpy(b_full).float().to(DEV)
     with pytest.raises(NotImplementedError, match="bound x"):
         MatchingFairnessDualObjectiveFunction(cone, gamma=0.02, native=False)
-    if _native_possible():  # the kernel form has no such restriction: one-sided bounds against the oracle
-        f = MatchingFairnessDualObjectiveFunction(cone, gamma=0.02, A_fairness=torch.from_numpy(fv).to(DEV), native=True)
-        r = f.calculate(torch.from_numpy(lam).to(DEV), save_primal=True)
-        grad, obj, reg, primal, x = fairness_oracle.fairness_calculate(p, fv, lam, 0.02, ("cone", {"lower": 0.0}), b_full, np.float32)
-        assert relerr(r.primal_var.cpu().numpy(), x) < RTOL["f32"] and relerr(r.dual_gradient.cpu().numpy(), grad) < RTOL["f32"]
+    # the kernel form has no such restriction: one-sided bounds against the oracle
+    f = MatchingFairnessDualObjectiveFunction(cone, gamma=0.02, A_fairness=torch.from_numpy(fv).to(DEV), native=True)
+    r = f.calculate(torch.from_numpy(lam).to(DEV), save_primal=True)
+    grad, obj, reg, primal, x = fairness_oracle.fairness_calculate(p, fv, lam, 0.02, ("cone", {"lower": 0.0}), b_full, np.float32)
+    assert relerr(r.primal_var.cpu().numpy(), x) < RTOL["f32"] and relerr(r.dual_gradient.cpu().numpy(), grad) < RTOL["f32"]
 
 
 @pytest.mark.parametrize("hot", [False, True])
@@ -119,8 +109,6 @@ def test_kernel_form_through_single_column_tiles_and_the_hot_rows_plan(hot, monk
     from oracle import agd_oracle, fairness_oracle
     from tests.test_gpu_edge_cases import _random_problem
 
-    if not _native_possible():
-        pytest.skip("64-wide layout forced")
     if hot:
         monkeypatch.setenv("DUALIP_HIP_HOT_ROWS", "512")
     monkeypatch.setenv("DUALIP_HIP_FLAT", "0")  # the walkers are the subject: keep long point-wise columns out of the window stream

@@ -2,7 +2,6 @@
 tests/test_sparse_utils.py:10-250 re-expressed (same matrices, same expectations) plus kernel-form projection operators."""
 import operator
 
-import numpy as np
 import pytest
 import torch
 
