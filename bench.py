@@ -694,7 +694,7 @@ def main():
         try:
             if whole is not None and args.gamma_decay:
                 args.gamma = whole["gamma_last"]  # (the verification leg evaluates the objective at the solve's final gamma)
-            from tests.helpers import verify_at_size  # (the checker: oracle slabs, fp64 recomputation, exchange cross-checks)
+            from benchmark.verify import verify_at_size  # (the checker: oracle slabs, fp64 recomputation, exchange cross-checks)
 
             verified = verify_at_size(args.dtype, args.gamma, inp, pm_local, f, local, lam_late, rank, world, sharded, device, comm_backend=args.comm)
         except Exception as exc:  # a failed check must show in the line, not kill the measurement

@@ -56,10 +56,10 @@ def stress_duals(m, device, seed=11):
 
 
 def verify(f, inp, gamma, lam, device):
-    """tests/helpers.verify_at_size (the checker bench.py runs at the benchmark size) on this problem, at the solve's duals and at
+    """benchmark/verify.verify_at_size (the checker bench.py runs at the benchmark size) on this problem, at the solve's duals and at
     a stress dual vector: the oracle on slabs of columns -- incl. one slab around a column of every length class -- A x, c.x and
     sum x^2 recomputed in float64 from the primal, the two-handle sharded route against the single objective."""
-    from tests.helpers import verify_at_size
+    from benchmark.verify import verify_at_size
 
     ok = True
     for tag, lv in (("solve's duals", lam), ("stress duals", stress_duals(lam.numel(), device))):

@@ -52,6 +52,22 @@ def _param(params: dict, *names):
     return None
 
 
+def _box_bounds(params: dict):
+    """(lower, upper) of a ``box`` entry as floats, -inf / +inf where a bound is absent.  A bound whose key is MISSING takes the
+    operator's default -- ``BoxProjection(lower=0.0, upper=1.0)``, box.py:12-13: ``{"upper": 1}`` clamps to [0, 1] in the reference
+    (tests/test_equality_constraints.py:39) -- unless the entry uses the ``l`` / ``u`` spelling of the reference's bound reader
+    (miplib.py:111-121), where a missing key means "no bound"; a key that is present with NaN / None is an absent bound either way."""
+    short = "l" in params or "u" in params
+    out = []
+    for long_name, short_name, default, absent in (("lower", "l", 0.0, float("-inf")), ("upper", "u", 1.0, float("inf"))):
+        if long_name in params or short_name in params:
+            v = _param(params, long_name, short_name)
+            out.append(absent if v is None else v)
+        else:
+            out.append(absent if short else default)
+    return out[0], out[1]
+
+
 def _as_index_tensor(indices, device) -> torch.Tensor:
     if isinstance(indices, torch.Tensor):
         return indices.to(device=device, dtype=torch.long)
@@ -162,8 +178,8 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
             idx = _as_index_tensor(entry.indices, self.device)
             p = entry.proj_params
             lo, hi = _param(p, "l", "lower"), _param(p, "u", "upper")
-            if entry.proj_type == "box" and not any(k in p for k in ("lower", "l", "upper", "u")):
-                lo, hi = 0.0, 1.0
+            if entry.proj_type == "box":  # (missing keys: the operator's defaults, see _box_bounds)
+                lo, hi = (None if v in (float("-inf"), float("inf")) else v for v in _box_bounds(p))
             if lo is not None:
                 lower[idx] = lo
             if hi is not None:
@@ -184,10 +200,7 @@ class MIPLIB2017ObjectiveFunction(BaseObjective):
             seen[idx] += 1
             p = entry.proj_params
             if entry.proj_type == "box":
-                l, u = _param(p, "lower", "l"), _param(p, "upper", "u")
-                named = any(k in p for k in ("lower", "l", "upper", "u"))
-                lo[idx] = l if l is not None else (float("-inf") if named else 0.0)   # BoxProjection defaults 0 / 1 (box.py:7-13)
-                hi[idx] = u if u is not None else (float("inf") if named else 1.0)
+                lo[idx], hi[idx] = _box_bounds(p)  # (a missing key = BoxProjection's default 0 / 1, box.py:12-13)
             elif entry.proj_type == "cone":
                 l, u = _param(p, "lower", "l"), _param(p, "upper", "u")
                 if l is not None and u is not None:
@@ -376,17 +389,20 @@ class MIPLIB2017ObjectiveFunctionDistributed(BaseObjective):
 
 def _operator_for(entry: ProjectionEntry):
     """The registered operator of an entry.  For box/cone, ``l``/``u`` are accepted as spellings of ``lower``/``upper``
-    and NaN bounds are dropped; a box left with one bound becomes the corresponding cone (clamp with a missing bound)."""
+    and NaN bounds are dropped; a box whose bound is ABSENT (NaN, or an ``l`` / ``u`` entry without the key -- _box_bounds) becomes
+    the corresponding cone (clamp with a missing bound); a box that simply does not name a bound keeps the operator's default."""
     p = dict(entry.proj_params)
     kind = entry.proj_type
     if kind in ("box", "cone"):
-        named = any(k in p for k in ("lower", "l", "upper", "u"))
-        lo, hi = _param(p, "lower", "l"), _param(p, "upper", "u")
+        if kind == "box":
+            lo, hi = (None if v in (float("-inf"), float("inf")) else v for v in _box_bounds(p))
+        else:
+            lo, hi = _param(p, "lower", "l"), _param(p, "upper", "u")
         p = {k: v for k, v in p.items() if k not in ("l", "u", "lower", "upper")}
         if lo is not None:
             p["lower"] = lo
         if hi is not None:
             p["upper"] = hi
-        if kind == "box" and named and (lo is None or hi is None):
-            kind = "cone"
+        if kind == "box" and (lo is None or hi is None):
+            kind = "cone"  # (one bound: clamp on that side; none: the identity, cone.py:6-28)
     return project(kind, **p)

@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 from dualip_amd import _hip
 from dualip_amd.objectives.base import BaseInputArgs
-from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunction
+from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunction, MIPLIB2017ObjectiveFunctionDistributed, MIPLIBInputArgs
 from dualip_amd.objectives.matching import (
     MatchingInputArgs,
     MatchingSolverDualObjectiveFunction,
@@ -121,6 +121,27 @@ def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, p
     )
 
 
+def _local_lp_shard(input_args: MIPLIBInputArgs, rank: int, world: int, device) -> MIPLIBInputArgs:
+    """This rank's VARIABLES (columns of A, entries of c, projection entries re-based) of a generic LP and the full b_vec -- the
+    contiguous cut n // W (+1 for the first n % W ranks) of dist_utils.split_tensors_to_devices (dist_utils.py:53-57), applied to
+    the LP's columns.  Any layout of A the objective accepts (dense, COO, CSR, CSC); only this rank's columns are moved."""
+    A = input_args.A
+    n = int(A.shape[1])
+    cuts = contiguous_cuts(n, world, ())
+    lo, hi = cuts[rank], cuts[rank + 1]
+    if A.layout == torch.strided:
+        A_loc = A[:, lo:hi].contiguous()
+    else:
+        coo = (A if A.layout == torch.sparse_coo else A.to_sparse_coo()).coalesce()
+        idx, vals = coo.indices(), coo.values()
+        keep = (idx[1] >= lo) & (idx[1] < hi)
+        A_loc = torch.sparse_coo_tensor(torch.stack([idx[0][keep], idx[1][keep] - lo]), vals[keep], (int(A.shape[0]), hi - lo)).coalesce()
+    eq = input_args.equality_mask
+    return MIPLIBInputArgs(A=A_loc.to(device), c=input_args.c[lo:hi].contiguous().to(device), b_vec=input_args.b_vec.to(device),
+                           projection_map=global_to_local_projection_map(input_args.projection_map, range(lo, hi)),
+                           equality_mask=eq.to(device) if eq is not None else None)
+
+
 def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_args: ComputeArgs, objective_args: ObjectiveArgs):
     kind = objective_args.objective_type
     if kind == "matching":
@@ -146,7 +167,19 @@ def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_
         kwargs = dict(objective_args.objective_kwargs or {})
         if objective_args.use_jacobi_precondition:
             kwargs.setdefault("use_jacobi_precondition", True)
-        return MIPLIB2017ObjectiveFunction(miplib_input_args=input_args, **kwargs)
+        if compute_args.compute_device_num == 1:
+            return MIPLIB2017ObjectiveFunction(miplib_input_args=input_args, **kwargs)
+        # BASELINE config 5 on several GPUs: the LP sharded by variables, one process per GPU (the reference's MIPLIB objective is
+        # single-device; x_j depends on column j only and A x is a sum over columns, so the shards' packed partials add up exactly)
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("compute_device_num > 1 needs an initialised torch.distributed group (one process per GPU)")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world != compute_args.compute_device_num:
+            raise ValueError(f"compute_device_num={compute_args.compute_device_num} but the process group has {world} ranks")
+        if kwargs.get("use_jacobi_precondition"):
+            raise NotImplementedError("Jacobi preconditioning of the generic-LP objective is single-device (row norms of the whole A)")
+        device = torch.device("cuda", torch.cuda.current_device())
+        return MIPLIB2017ObjectiveFunctionDistributed(_local_lp_shard(input_args, rank, world, device), gamma=solver_args.gamma)
     raise ValueError(f"Objective type {kind} not supported")
 
 

@@ -13,7 +13,9 @@ import numpy as np
 
 def bounds_from_map(n, entries, dtype):
     """(lower, upper) clamp arrays, -inf / +inf where a bound is absent.  ``entries``: iterable of
-    (proj_type, params, indices); box defaults to [0, 1] when no bound is named (box.py:7-13), NaN means absent."""
+    (proj_type, params, indices).  A box bound whose key is missing takes BoxProjection's default (lower=0.0, upper=1.0: box.py:12-13 --
+    ``{"upper": 1}`` is [0, 1], tests/test_equality_constraints.py:39) unless the entry is spelled ``l`` / ``u`` (the bound reader's names,
+    miplib.py:111-121: a missing key is "no bound"); a key present with NaN / None is an absent bound."""
     lo = np.full(n, -np.inf, dtype=dtype)
     hi = np.full(n, np.inf, dtype=dtype)
 
@@ -27,9 +29,9 @@ def bounds_from_map(n, entries, dtype):
         idx = np.asarray(idx, dtype=np.int64)
         l, u = get(params, "lower", "l"), get(params, "upper", "u")
         if kind == "box":
-            named = any(k in params for k in ("lower", "l", "upper", "u"))
-            lo[idx] = l if l is not None else (-np.inf if named else 0.0)
-            hi[idx] = u if u is not None else (np.inf if named else 1.0)
+            short = "l" in params or "u" in params
+            lo[idx] = l if l is not None else (-np.inf if (short or "lower" in params) else 0.0)
+            hi[idx] = u if u is not None else (np.inf if (short or "upper" in params) else 1.0)
         elif kind == "cone":
             if l is not None:
                 lo[idx] = l

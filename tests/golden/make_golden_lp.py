@@ -168,7 +168,7 @@ def make_small():
     np.savez_compressed(os.path.join(HERE, "g6_lp_small.npz"), **out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # (make_golden_lp_warm.py imports this module for its helpers)
     make_small()
     make_miplib()
     for name in ("g6_lp_small.npz", "g6_miplib_v150.npz"):

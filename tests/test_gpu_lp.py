@@ -234,3 +234,88 @@ def test_miplib_instance_from_the_mps_file():
     assert relerr(log[:25], want[:25]) < 2e-5 and relerr(log, want) < 2e-2
     assert abs(27 - out.dual_objective) < 1  # the driver's own check
     assert abs(log[99] - 23.13099) < 0.05 and abs(log[999] - 25.60996) < 0.2 and abs(log[1999] - 27.01548) < 0.3
+
+
+def test_equality_constraint_known_answer():
+    """The reference's tests/test_equality_constraints.py re-expressed (same numbers, own code), on the device:
+    :8-15 the masked projection on the non-negative cone, exact; :18-61 min x1 + 2 x2 s.t. x1 + x2 = 4, 0 <= x1 <= 1 (a box entry that
+    only names ``upper``: BoxProjection's default lower bound 0 stays, box.py:12-13), x2 in no entry -- MIPLIB2017ObjectiveFunction +
+    AcceleratedGradientDescent(max_iter=1000, gamma=1e-5) reach 7.0 within torch.isclose(atol=1e-5), and walk the reference's own
+    trace (fixture g6_lp_warm.npz: the equality row's dual goes to -2, which only the masked projection allows)."""
+    from dualip_amd.objectives.miplib import MIPLIB2017ObjectiveFunction, MIPLIBInputArgs
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent, project_on_nn_cone
+    from dualip_amd.projections.base import create_projection_map
+
+    y = torch.tensor([-1.0, -1.0, 2.0, -3.0, 4.0], device=DEV)
+    mask = torch.tensor([False, True, False, True, False], device=DEV)
+    assert (project_on_nn_cone(y, mask) == torch.tensor([0.0, -1.0, 2.0, -3.0, 4.0], device=DEV)).all()
+
+    z = load("g6_lp_warm.npz")
+    for A_form in ("dense", "coo"):
+        A = torch.tensor([[1.0, 1.0]], device=DEV)
+        args = MIPLIBInputArgs(
+            A=A if A_form == "dense" else A.to_sparse_coo(), c=torch.tensor([1.0, 2.0], device=DEV), b_vec=torch.tensor([4.0], device=DEV),
+            projection_map=create_projection_map("box", {"upper": 1}, num_indices=2, indices=[0]), equality_mask=torch.tensor([True], device=DEV),
+        )
+        objective = MIPLIB2017ObjectiveFunction(miplib_input_args=args)
+        res = AcceleratedGradientDescent(max_iter=1000, gamma=1e-5, iteration_callback=False).maximize(objective, torch.tensor([0.0], device=DEV))
+        assert torch.isclose(torch.tensor(res.dual_objective), torch.tensor(7.0), atol=1e-5), res.dual_objective
+        assert relerr(res.dual_objective_log, z["eq2|obj_log"]) < 1e-5
+        assert relerr(res.step_size_log, z["eq2|step_log"]) < 1e-4
+        assert abs(float(res.dual_val[0]) - float(z["eq2|lam"][0])) < 1e-4 and float(res.dual_val[0]) < 0
+    # one calculate() at the optimal dual: x = (1, 3) up to the regularisation (x2 free: -(lambda + c2) / gamma)
+    r = objective.calculate(torch.tensor([-2.0 - 3e-5], device=DEV), 1e-5, save_primal=True)
+    assert float(r.primal_var[0]) == 1.0 and abs(float(r.primal_var[1]) - 3.0) < 0.2
+    r0 = objective.calculate(torch.tensor([5.0], device=DEV), 1e-5, save_primal=True)
+    assert float(r0.primal_var[0]) == 0.0  # the default lower bound of {"upper": 1}
+
+
+def _warm_args(z, zs, dn, which):
+    if which == "small":
+        from dualip_amd.objectives.miplib import MIPLIBInputArgs
+
+        dt = TD[dn]
+        return MIPLIBInputArgs(A=torch.from_numpy(zs["A"]).to(dt).to_sparse_coo(), c=torch.from_numpy(zs["c"]).to(dt), b_vec=torch.from_numpy(zs["b"]).to(dt),
+                               projection_map=_small_map(zs), equality_mask=torch.from_numpy(zs["eq"]))
+    return _miplib_args(zs, dn)
+
+
+@pytest.mark.parametrize("which", ["small", "v150"])
+def test_run_solver_generic_lp_warm_start_matches_reference_golden(which, tmp_path):
+    """BASELINE config 5 as worded -- the generic-LP objective WITH a warm start: ``run_solver(objective_type="miplib2017",
+    SolverArgs(initial_dual_path=...))`` (run_solver.py:127-132) from the duals the REFERENCE saved after its cold run walks the
+    reference's warm trace (fixture g6_lp_warm.npz: its own run_solver, cold then warm); and the chain cold -> save -> warm of this
+    package ends where the reference's chain ends."""
+    import contextlib
+    import io
+
+    from dualip_amd.run_solver import run_solver
+    from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
+
+    z = load("g6_lp_warm.npz")
+    zs = load("g6_lp_small.npz" if which == "small" else "g6_miplib_v150.npz")
+    n_cold, n_warm, gamma, s0 = z[f"{which}|params"]
+    for dn in NP_DT:
+        args = _warm_args(z, zs, dn, which)
+        path = str(tmp_path / f"ref_dual_{dn}.pt")
+        torch.save(torch.from_numpy(z[f"{which}|{dn}|cold_lam"]), path)
+        sa = SolverArgs(max_iter=int(n_warm), gamma=float(gamma), initial_step_size=float(s0), max_step_size=0.1, save_primal=True, initial_dual_path=path)
+        with contextlib.redirect_stdout(io.StringIO()):
+            warm = run_solver(args, sa, ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="miplib2017"))
+        want = z[f"{which}|{dn}|warm_obj_log"]
+        head = 25 if dn == "f32" else 40
+        # (same inputs, same computation: tight while round-off has not been amplified -- see test_lp_oracle_golden.py for the growth)
+        assert relerr(warm.dual_objective_log[:head], want[:head]) < (3e-5 if dn == "f32" else 1e-8), (which, dn)
+        assert relerr(warm.dual_objective_log, want) < (5e-2 if dn == "f32" else 5e-3), (which, dn)
+        assert relerr(warm.step_size_log[:head], z[f"{which}|{dn}|warm_step_log"][:head]) < (1e-3 if dn == "f32" else 1e-6)
+        assert warm.dual_objective_log[0] > z[f"{which}|{dn}|cold_obj_log"][0]  # it did start from the loaded duals
+        # own chain: cold run, torch.save of ITS duals, warm run
+        with contextlib.redirect_stdout(io.StringIO()):
+            cold = run_solver(args, SolverArgs(max_iter=int(n_cold), gamma=float(gamma), initial_step_size=float(s0), max_step_size=0.1), ComputeArgs(host_device=DEV),
+                              ObjectiveArgs(objective_type="miplib2017"))
+            own = str(tmp_path / f"own_dual_{dn}.pt")
+            torch.save(cold.dual_val.cpu(), own)
+            chained = run_solver(args, SolverArgs(max_iter=int(n_warm), gamma=float(gamma), initial_step_size=float(s0), max_step_size=0.1, initial_dual_path=own),
+                                 ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="miplib2017"))
+        assert relerr(cold.dual_objective_log, z[f"{which}|{dn}|cold_obj_log"]) < (5e-2 if dn == "f32" else 5e-3)
+        assert abs(chained.dual_objective_log[-1] - want[-1]) < 2e-2 * abs(want[-1]), (which, dn)

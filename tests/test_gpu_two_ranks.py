@@ -209,6 +209,62 @@ def test_generic_lp_sharded_by_variables():
     assert relerr(out[0][0], z["trace|plain|f64|obj_log"][:120]) < 1e-8
 
 
+def _lp_warm_worker(rank, world, port, path, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dualip_amd.objectives.miplib import MIPLIBInputArgs
+        from dualip_amd.projections.base import ProjectionEntry
+        from dualip_amd.run_solver import run_solver
+        from dualip_amd.types import ComputeArgs, ObjectiveArgs, SolverArgs
+        from tests.helpers import load, lp_small_entries
+
+        z, zw = load("g6_lp_small.npz"), load("g6_lp_warm.npz")
+        n_cold, n_warm, gamma, s0 = zw["small|params"]
+        pm = {f"e{k}": ProjectionEntry(kind, dict(params), indices=[int(i) for i in idx]) for k, (kind, params, idx) in enumerate(lp_small_entries(z))}
+        # every rank hands over the GLOBAL problem (CPU tensors), as for the matching objective
+        args = MIPLIBInputArgs(A=torch.from_numpy(z["A"]).to_sparse_coo(), c=torch.from_numpy(z["c"]), b_vec=torch.from_numpy(z["b"]), projection_map=pm,
+                               equality_mask=torch.from_numpy(z["eq"]))
+        res = run_solver(args, SolverArgs(max_iter=int(n_warm), gamma=float(gamma), initial_step_size=float(s0), max_step_size=0.1, initial_dual_path=path),
+                         ComputeArgs(host_device="cuda:0", compute_device_num=world), ObjectiveArgs(objective_type="miplib2017"))
+        q.put((rank, np.array(res.dual_objective_log), res.dual_val.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@retry_once_if_stalled
+def test_generic_lp_warm_start_two_ranks_through_run_solver(tmp_path):
+    """BASELINE config 5 on more than one GPU, as worded: ``run_solver(objective_type="miplib2017", compute_device_num=2,
+    initial_dual_path=...)`` -- the LP sharded by variables (run_solver._local_lp_shard), both ranks warm-started from the duals the
+    REFERENCE saved -- walks the reference's single-process warm trace (fixture g6_lp_warm.npz) with bit-identical ranks."""
+    from tests.helpers import load, relerr
+
+    zw = load("g6_lp_warm.npz")
+    path = str(tmp_path / "ref_dual.pt")
+    torch.save(torch.from_numpy(zw["small|f64|cold_lam"]), path)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lp_warm_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = {}
+    for rank, log, dual in gather_results(procs, q):
+        out[rank] = (log, dual)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    want = zw["small|f64|warm_obj_log"]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert relerr(out[0][0][:40], want[:40]) < 1e-8 and relerr(out[0][0], want) < 5e-3
+    assert out[0][0][0] > zw["small|f64|cold_obj_log"][0]
+
+
 @retry_once_if_stalled
 def test_bench_harness_with_two_ranks_on_one_gpu():
     """bench.py under torch.distributed.run with WORLD_SIZE=2 (developer mode: both ranks on cuda:0, gloo collectives): the

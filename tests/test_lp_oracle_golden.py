@@ -113,3 +113,43 @@ def test_miplib_instance_matches_reference():
     # the driver's loose sanity check (examples/miplib_2017/solve_miplib_dataset.py:74) holds on the stored full traces
     for dn in NP_DT:
         assert abs(27 - z[f"trace|{dn}|obj_log"][-1]) < 1
+
+
+def test_equality_known_answer_and_one_sided_box_default():
+    """The reference's tests/test_equality_constraints.py:18-61 (min x1 + 2 x2, x1 + x2 = 4, box {"upper": 1} on x1, x2 in no entry;
+    optimum 7.0): the oracle walks the reference's own 1000-iteration trace (fixture g6_lp_warm.npz) and ends at 7.0 +- 1e-5 * (1 + 7).
+    ``{"upper": 1}`` keeps BoxProjection's default lower bound 0 (box.py:12-13)."""
+    z = load("g6_lp_warm.npz")
+    A, c, b = np.array([[1.0, 1.0]]), np.array([1.0, 2.0]), np.array([4.0])
+    lo, hi = lp_oracle.bounds_from_map(2, [("box", {"upper": 1}, [0])], np.float32)
+    assert (lo[0], hi[0], lo[1], hi[1]) == (0.0, 1.0, -np.inf, np.inf)
+
+    def calc(lam, gamma):
+        grad, x, obj, reg, primal = lp_oracle.lp_calculate(A, c, b, lo, hi, lam, gamma, np.float32)
+        return grad, obj, x
+
+    r = agd_oracle.maximize(calc, np.zeros(1), 1000, 1e-5, eq_mask=np.array([True]), dtype=np.float32)
+    assert abs(r["dual_obj_log"][-1] - 7.0) < 1e-5 + 1e-5 * 7.0  # torch.isclose(atol=1e-5) of the reference's test (rtol 1e-5 default)
+    assert relerr(r["dual_obj_log"], z["eq2|obj_log"]) < 1e-5
+    assert relerr(r["dual_val"], z["eq2|lam"]) < 1e-5 and r["dual_val"][0] < 0  # an equality row's dual may be negative (agd.py:13-21)
+
+
+def test_lp_warm_start_matches_reference():
+    """BASELINE config 5 "with warm start": the optimiser restarted from the reference's saved duals (run_solver.py:127-132) walks the
+    reference's warm trace; fixture g6_lp_warm.npz, 40 x 60 LP with equality rows."""
+    z = load("g6_lp_warm.npz")
+    zs = load("g6_lp_small.npz")
+    n, m = int(zs["n"]), int(zs["m"])
+    n_cold, n_warm, gamma, s0 = z["small|params"]
+    for dn, dt in NP_DT.items():
+        lo, hi = lp_oracle.bounds_from_map(n, lp_small_entries(zs), dt)
+
+        def calc(lam, g):
+            grad, x, obj, reg, primal = lp_oracle.lp_calculate(zs["A"], zs["c"], zs["b"], lo, hi, lam, g, dt)
+            return grad, obj, x
+
+        r = agd_oracle.maximize(calc, z[f"small|{dn}|cold_lam"], int(n_warm), float(gamma), initial_step_size=float(s0), max_step_size=0.1, eq_mask=zs["eq"], dtype=dt)
+        want = z[f"small|{dn}|warm_obj_log"]
+        assert relerr(r["dual_obj_log"][:30], want[:30]) < (2e-4 if dn == "f32" else 1e-8), dn
+        assert relerr(r["dual_obj_log"], want) < (5e-2 if dn == "f32" else 1e-3), dn
+        assert want[0] > z[f"small|{dn}|cold_obj_log"][0]  # a warm start does not begin at the cold start's objective
