@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample-cols", type=int, default=4_000_000)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
+    ap.add_argument("--cpu-sample-only", action="store_true", help="CPU legs on bounded samples only (no whole-problem runs even when the host has the memory)")
     ap.add_argument("--cpu-ref-cols", type=int, default=10_000_000, help="entities of the sample the reference-path CPU leg runs on")
     ap.add_argument("--cpu-ref-iters", type=int, default=3)
     ap.add_argument("--cpu-ref-threads", type=int, default=32, help="torch threads of the reference-path CPU leg (its measured optimum on the GPU box's host)")
@@ -159,12 +160,24 @@ def copy_ceiling_gbps(device, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
 def _cpu_sample(args, inp, pm_local, n_cols):
-    """The first n_cols / #entries columns of EVERY projection entry, on the host (so a mixed map is sampled with its mix)."""
+    """The first n_cols / #entries columns of EVERY projection entry, on the host (so a mixed map is sampled with its mix); n_cols >= the
+    shard's columns: every entry whole, i.e. the WHOLE problem."""
     A = inp.A
     n_local = A.shape[1]
     entries = list(pm_local.items())
-    per = max(1, min(n_cols, n_local) // max(len(entries), 1))
+    per = n_local if n_cols >= n_local else max(1, min(n_cols, n_local) // max(len(entries), 1))
     colptr_dev = A.ccol_indices()
     parts, projs, col_proj_parts = [], [], []
     for q, (_, e) in enumerate(entries):
@@ -185,7 +198,7 @@ def _cpu_sample(args, inp, pm_local, n_cols):
         colptr[pos + 1 : pos + cnt + 1] = cp[1:] - k0 + off
         pos += cnt
         off += k1p - k0
-        rowidx_l.append(A.row_indices()[k0:k1p].cpu().numpy().astype(np.int64))
+        rowidx_l.append(np.asarray(A.row_indices()[k0:k1p].cpu().numpy(), dtype=np.int64))  # (no second copy when the indices are int64 already)
         a_l.append(A.values()[k0:k1p].cpu().numpy())
         c_l.append(inp.c.values()[k0:k1p].cpu().numpy())
     return dict(ncols=ncols, nnz=off, per=per, colptr=colptr, rowidx=np.concatenate(rowidx_l), a=np.concatenate(a_l), c=np.concatenate(c_l),
@@ -216,7 +229,7 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
       value   -- the reference's OP SEQUENCE restated in torch-on-CPU (oracle/torch_path.py: padded dense blocks per nnz bucket,
                  sort + cumsum simplex -- what device="cpu" executes in the reference; pinned to its goldens), >= 10M entities;
       c_port  -- the C oracle (oracle/matching_oracle.c, OpenMP), a per-column loop: much faster than the reference's path.
-    Both are scaled by nnz to whole-problem iterations/s and labelled extrapolated."""
+    Each leg runs on the WHOLE problem when the host has the memory (`extrapolated: false`), else on a sample scaled by nnz and labelled extrapolated."""
     import oracle
     from oracle import agd_oracle
 
@@ -225,12 +238,17 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
     host_cores = os.cpu_count() or 0  # (hardware threads of the host; `cores` below = the threads each leg actually used)
     out = {"unit": "iterations/s", "cores": threads, "host_cores": host_cores, "kind": "port", "extrapolated": True}
     # ---- C port -------------------------------------------------------------------------------------------------
-    smp = _cpu_sample(args, inp, pm_local, args.cpu_sample_cols)
+    # The WHOLE problem when the host has room for it (one device-to-host copy of the CSC arrays, 17 GB at the headline; BASELINE.md section 3:
+    # "100 M -- 2 iterations if host RAM allows"): measured, not extrapolated.  Otherwise the bounded sample, scaled by nnz and labelled so.
+    host_bytes = inp.A.values().numel() * (8 + 2 * inp.A.values().element_size()) + inp.A.shape[1] * 8
+    whole = not args.cpu_sample_only and _mem_available_gb() * 1e9 > 4.0 * host_bytes + 20e9
+    smp = _cpu_sample(args, inp, pm_local, inp.A.shape[1] if whole else args.cpu_sample_cols)
     m = smp["m"]
     lam = np.zeros(m, dtype=npdt)
     sizer = agd_oracle.StepSizer(npdt)
     times = []
-    for it in range(args.cpu_sample_iters + 1):
+    c_iters = 2 if whole else args.cpu_sample_iters
+    for it in range(c_iters + 1):
         t0 = time.perf_counter()
         ax, obj0, ssq, _ = oracle.matching_calculate(m, smp["ncols"], smp["colptr"], smp["rowidx"], smp["a"], smp["c"], lam, args.gamma, smp["projs"], col_proj=smp["col_proj"],
                                                      dtype=npdt, want_x=False, threads=threads)
@@ -239,10 +257,13 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
         lam = np.maximum(lam + grad * npdt(step), 0).astype(npdt)
         times.append(time.perf_counter() - t0)
     per_iter = float(np.mean(times[1:]))
+    is_whole = smp["nnz"] == total_nnz
     out["c_port"] = {
         "value": (1.0 / per_iter) * (smp["nnz"] / max(total_nnz, 1)),
-        "sample": f"oracle/matching_oracle.c (OpenMP {threads} threads) on {smp['ncols']} entities ({smp['nnz']} non-zeros; the first {smp['per']} of each of the "
-        f"{smp['n_entries']} projection blocks), {args.cpu_sample_iters} iterations at {per_iter * 1e3:.1f} ms = {args.cpu_sample_iters * per_iter * threads:.0f} core-seconds",
+        "extrapolated": not is_whole,
+        "sample": f"oracle/matching_oracle.c (OpenMP {threads} threads) on " + ("the WHOLE problem: " if is_whole else "") + f"{smp['ncols']} entities ({smp['nnz']} non-zeros"
+        + ("" if is_whole else f"; the first {smp['per']} of each of the {smp['n_entries']} projection blocks") + f"), {c_iters} iterations after one warm-up at {per_iter * 1e3:.1f} ms "
+        f"= {c_iters * per_iter * threads:.0f} core-seconds" + ("; measured, not extrapolated" if is_whole else "; value = sample it/s x sample_nnz / total_nnz"),
         "sample_ms_per_iteration": per_iter * 1e3,
     }
     # ---- the reference's op sequence (torch on CPU) --------------------------------------------------------------------
@@ -250,9 +271,11 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
 
     from oracle.torch_path import ReferencePathObjective
 
-    if args.cpu_ref_cols > args.cpu_sample_cols:
-        del smp
+    if smp["ncols"] != min(args.cpu_ref_cols, inp.A.shape[1]):
+        whole_smp = smp if smp["nnz"] == total_nnz else None  # (kept for the whole-problem attempt below)
         smp = _cpu_sample(args, inp, pm_local, args.cpu_ref_cols)
+    else:
+        whole_smp = None
     # thread count: measured on the 256-thread host of the GPU box (tools/cpu_path_threads.py, 2M entities): 8 threads 469 ms,
     # 32 -> 373 ms, 64 -> 749 ms, 128 -> 1592 ms, 256 -> 41 s per iteration -- the op sequence is made of many small
     # memory-bound tensor ops that stop scaling early.  The leg runs at its best setting and says so in `cores`.
@@ -279,6 +302,40 @@ def cpu_baseline(args, inp, pm_local, total_nnz):
         out["sample_ms_per_iteration"] = per_ref * 1e3
         out["cores"] = ref_threads
         out["c_port"]["cores"] = threads
+        # ---- the same op sequence on the WHOLE problem, ONE iteration, when the host has the memory (MemAvailable >= 150 GB) and the
+        #      sample predicts it fits a minute: then `value` is that measurement and nothing is extrapolated ----
+        predicted = per_ref * total_nnz / max(smp["nnz"], 1)
+        out["extrapolated"] = smp["nnz"] != total_nnz
+        if not out["extrapolated"]:
+            pass  # (the sample WAS the whole problem: nothing scaled)
+        elif whole_smp is not None and _mem_available_gb() >= 150.0 and predicted <= 60.0:
+            try:
+                del ref
+                w = whole_smp
+                bounds = np.cumsum([0] + [int((w["col_proj"] == q).sum()) for q in range(w["n_entries"])])
+                entries = [(pt, pp, np.arange(bounds[q], bounds[q + 1])) for q, (pt, pp) in enumerate(w["projs"])]
+                t0 = time.perf_counter()
+                ref = ReferencePathObjective(m, w["ncols"], w["colptr"], w["rowidx"], w["a"], w["c"], entries, args.gamma, dtype=lam_t.dtype)
+                t_setup = time.perf_counter() - t0
+                lam_w = _t.zeros(m, dtype=lam_t.dtype)
+                t0 = time.perf_counter()
+                ax, obj0, ssq, _ = ref.calculate(lam_w)
+                lam_w = (lam_w + (ax - b_t) * 1e-3).clamp(min=0)
+                t_one = time.perf_counter() - t0
+                out["sample_extrapolated_value"] = out["value"]
+                out["value"] = 1.0 / t_one
+                out["extrapolated"] = False
+                out["sample"] = (f"oracle/torch_path.py -- the reference's calculate() op sequence in torch on CPU, {_t.get_num_threads()} threads -- on the WHOLE problem "
+                                 f"({w['ncols']} entities, {w['nnz']} non-zeros): ONE iteration (the first, allocations included) at {t_one:.1f} s after {t_setup:.1f} s of bucket set-up; "
+                                 f"measured, not extrapolated.  The 10M-entity sample ({args.cpu_ref_iters} iterations at {per_ref * 1e3:.0f} ms) scaled by nnz predicts "
+                                 f"{out['sample_extrapolated_value']:.4f} it/s")
+                out["sample_ms_per_iteration"] = t_one * 1e3
+            except Exception as exc:  # (memory: keep the sample's figure, say why)
+                out["whole_problem_attempt"] = f"failed: {type(exc).__name__}: {str(exc)[:200]}"
+        elif whole_smp is None:
+            out["whole_problem_attempt"] = "not attempted: the C leg ran on a sample (host memory)"
+        else:
+            out["whole_problem_attempt"] = f"not attempted: MemAvailable {_mem_available_gb():.0f} GB, predicted {predicted:.0f} s per iteration"
     finally:
         _t.set_num_threads(old_threads)
     return out
@@ -445,6 +502,29 @@ def respawn_under_torchrun(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def rank_identities(device, rank, world, one_device):
+    """Which PHYSICAL GPU every rank runs on, gathered over the side channel before anything is timed: UUID, PCI address, ordinal, host, pid
+    (benchmark/run_matching_benchmark_dist.py:35-41 pins rank r to cuda:r and trusts it; a scaling line should prove it).  Raises unless the
+    ranks sit on `world` distinct devices -- except in the developer mode that shares one on purpose (DUALIP_BENCH_ONE_DEVICE=1)."""
+    import socket
+
+    props = torch.cuda.get_device_properties(device)
+    pci = None
+    if all(hasattr(props, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        pci = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+    mine = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device_ordinal": device.index, "name": props.name,
+            "uuid": str(getattr(props, "uuid", None)), "pci": pci, "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    keys = [(e["host"], e["uuid"] if e["uuid"] not in (None, "None") else (e["pci"] or e["device_ordinal"])) for e in everyone]
+    distinct = len(set(keys))
+    if distinct != world and not one_device:
+        raise RuntimeError(f"bench.py --gpus {world}: the ranks run on {distinct} distinct GPU(s), not {world} ({everyone}); set DUALIP_BENCH_ONE_DEVICE=1 "
+                           "for the developer mode that shares a device on purpose")
+    return {"ranks": everyone, "distinct_gpus": distinct, "one_device_mode": bool(one_device),
+            "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
+
+
 def collective_selftest(comm, m, device, rank, world):
     """Before anything is timed: this library's exchange (dl_allreduce_sum on the communicator the solve will use) against
     torch.distributed's all_reduce of the same random vector, on every rank.  Returns a dict for aux.collective."""
@@ -548,6 +628,7 @@ def main():
 
     t_setup = time.perf_counter()
     comm, collective = None, None
+    identities = rank_identities(device, rank, world, one_device) if sharded else None
     if sharded:
         for bi in block_inputs:
             bi.b_vec = None
@@ -660,6 +741,15 @@ def main():
             collective["repeated_after"] = str(exc)
         elapsed, launches, kernel_ms, xn, xms, result = headline(f, local, comm)
     avg_kernel_s, achieved, achieved_alg = roof(kernel_ms, launches)
+    per_rank = None
+    if sharded:  # every rank's own fused-kernel average and exchange bracket in the timed window (the headline is the max over ranks of the wall clock)
+        mine = torch.tensor([avg_kernel_s * 1e3, (xms / xn * 1e3) if xn else -1.0, float(nnz_local)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu()
+        kms_r, xus_r = rows[:, 0].tolist(), rows[:, 1].tolist()
+        per_rank = {"kernel_avg_ms": kms_r, "kernel_avg_ms_min": min(kms_r), "kernel_avg_ms_max": max(kms_r), "kernel_skew": (max(kms_r) / min(kms_r) - 1.0) if min(kms_r) > 0 else None,
+                    "us_per_exchange": [v if v >= 0 else None for v in xus_r], "nnz": [int(v) for v in rows[:, 2].tolist()]}
 
     # ---- the reference's whole solve (benchmark/config.py:16-18: max_iter 1000) and its late window ----------------
     late, whole, lam_late = None, None, result.dual_val
@@ -847,6 +937,11 @@ def main():
         out["roofline"]["frac_of_read_probe"] = achieved / rc_gbps if rc_gbps else None  # (same box, same run: what a plain streaming read reaches)
         fastest = max([achieved] + ([late["achieved_GBps"]] if (late and late.get("achieved_GBps")) else []))
         out["roofline"]["read_probe_beaten_by_kernel"] = bool(rc_gbps and fastest > rc_gbps)  # (true: the probe is a lower bound of the box's read rate, nothing more)
+        if sharded:
+            # the line proves by itself what took part: which GPUs (UUID / PCI address per rank), which exchange (p2p / p2p-fenced / rccl, whether
+            # it degraded mid-run), how far the ranks' kernels were apart (skew) and what one exchange bracket cost on the fastest / slowest rank
+            collective = {**(collective or {}), **(identities or {}), "state": (comm.backend if comm is not None else "torch.distributed"),
+                          "degrade_happened": bool(comm is not None and comm.degraded), "per_rank": per_rank}
         if comm is not None:
             out["aux"]["collective"] = {**(collective or {}), **comm.info(), "emulated_world": emu or None, "emulated_rank": emu_rank if emu else None,
                                         "exchanges": comm.exchanges, "us_per_exchange": (xms / xn * 1e3) if xn else None,

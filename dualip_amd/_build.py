@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdualip_hip.so")
-SOURCES = ["api.hip", "matching_kernels.hip", "matching_kernels4.hip", "matching_kernels4_f64.hip", "matching_kernels4_lanes.hip", "matching_kernels4_lanes_f64.hip", "agd_kernels.hip", "lp_kernels.hip", "comm.hip", "sell_build.hip", "csc_ops.hip", "pack_build.hip"]
+SOURCES = ["api.hip", "matching_kernels.hip", "matching_kernels4.hip", "matching_kernels4_f64.hip", "matching_kernels4_lanes.hip", "matching_kernels4_lanes_f64.hip", "agd_kernels.hip", "lp_kernels.hip", "comm.hip", "sell_build.hip", "csc_ops.hip", "pack_build.hip", "stage.hip"]
 HEADERS = ["common.h", "wave.h", "simplex.h", "simplex4.h", "fused_common.h", "comm.h", "sell.h", "fused4_kernel.h", "agd_step.h", os.path.join("..", "..", "include", "dualip_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950",
@@ -157,7 +157,7 @@ def _sgpr_pair_defects(asm_path: str):
         t = t.split(";")[0].strip()
         if t:
             instrs.append(("i", t))
-    pending = []  # suspicious reloaded pairs awaiting a 64-bit use: (P, description, expires at)
+    pending = []  # suspicious reloaded pairs awaiting a 64-bit use: (P, description, expires at, the STALE register of the pair: P or P + 1)
     for idx, (kind, t) in enumerate(instrs):
         if kind == "kernel":
             kernel = t
@@ -170,12 +170,12 @@ def _sgpr_pair_defects(asm_path: str):
             keep = []
             # (a scalar instruction's FIRST operand is its destination: `s_lshl_b64 s[6:7], s[0:1], 2` overwrites s[6:7], it does not read it)
             read_part = " ".join(ops[1:]) if (op.startswith("s_") and not op.startswith(_NO_SDST)) else t
-            for P, desc, until in pending:
+            for P, desc, until, stale in pending:
                 if f"s[{P}:{P + 1}]" in read_part:
                     out.append(f"{kernel} {desc}; the pair is then used as s[{P}:{P + 1}] by `{t}`")
                     continue
                 if idx < until:
-                    keep.append((P, desc, until))
+                    keep.append((P, desc, until, stale))
             pending = keep
         if op == "v_writelane_b32" and len(ops) >= 3:
             sr, vreg = _sreg(ops[1]), ops[0]
@@ -198,7 +198,7 @@ def _sgpr_pair_defects(asm_path: str):
                         if whole and whole[1] <= rl and rh <= whole[2] and dx is not None and dx != whole[0] and dx > whole[0] and str(ox).startswith(("s_load_dword ", "s_load_dword", "s_buffer_load_dword")) \
                                 and not str(ox).startswith(("s_load_dwordx", "s_buffer_load_dwordx")):
                             pending.append((P - 1, f"reloads s[{P - 1}:{P}] from lanes {lane - 1}/{lane} of {vreg}: s{rl}/s{rh} were defined together (registers s[{whole[1]}:{whole[2]}]) "
-                                                   f"but s{rx} had been overwritten alone by `{ox}` before the spill", idx + 400))
+                                                   f"but s{rx} had been overwritten alone by `{ox}` before the spill", idx + 400, (P - 1) if rx == rl else P))
                 reloads.append((idx, P, vreg, lane, org))
                 lastdef[P], lastop[P] = idx, "reload"
                 group.pop(P, None)
@@ -206,9 +206,24 @@ def _sgpr_pair_defects(asm_path: str):
         if op.startswith("s_") and not op.startswith(_NO_SDST) and ops:
             sr = _sreg(ops[0])
             if sr and pending:
-                # one half of a reloaded pair REDEFINED before any 64-bit use (the use of this very instruction was checked above): e.g. a reloaded
-                # 32-bit value zero-extended by `s_mov_b32 s7, 0` ahead of `s_lshl_b64 s[6:7], s[6:7], 3` -- the stale half never reaches the operand
-                pending = [(P, desc, until) for P, desc, until in pending if not (sr[0] <= P <= sr[1] or sr[0] <= P + 1 <= sr[1])]
+                # A pending pair is dropped when what reaches the 64-bit operand can no longer be "one value's half next to another value's half":
+                #  * the SUSPECT half -- the register reloaded from the lane of the half that had been overwritten alone -- is redefined (by anything), or
+                #  * the OTHER half is redefined by an EXTENSION of the suspect one: `s_mov_b32 sH, 0` (zero-extension: the lone scalar load WAS the
+                #    wanted 32-bit value, e.g. gridDim.x ahead of `s_lshl_b64 s[6:7], s[6:7], 3`) or `s_ashr_i32 sH, sL, 31` (sign extension).
+                # Any other redefinition of the other half clears nothing: the suspect half would still ride into the operand (round-5 review:
+                # the screen used to drop the report as soon as EITHER half was redefined).
+                def _heals(P, stale):
+                    other = P + 1 if stale == P else P
+                    if sr[0] <= stale <= sr[1]:
+                        return True
+                    if sr[0] == sr[1] == other:
+                        if op == "s_mov_b32" and len(ops) == 2 and ops[1] in ("0", "0x0"):
+                            return True
+                        if op == "s_ashr_i32" and len(ops) == 3 and ops[1] == f"s{stale}" and ops[2] == "31":
+                            return True
+                    return False
+
+                pending = [(P, desc, until, stale) for P, desc, until, stale in pending if not _heals(P, stale)]
             if sr:
                 for r in range(sr[0], sr[1] + 1):
                     lastdef[r], lastop[r] = idx, op

@@ -7,6 +7,7 @@ loaded (not built, hipcc missing) every entry point raises -- loudly -- instead 
 PyTorch-ROCm already loaded (same streams, same allocations).
 """
 import ctypes
+from typing import Optional
 import os
 
 import torch  # noqa: F401  (must precede the CDLL open, see module docstring)
@@ -17,7 +18,7 @@ DL_F32, DL_F64 = 0, 1
 DL_I32, DL_I64 = 0, 1
 PROJ_NONE, PROJ_BOX, PROJ_CONE_LOWER, PROJ_CONE_UPPER, PROJ_SIMPLEX, PROJ_SIMPLEX_EQ = range(6)
 LOG_COLS = 8
-ABI_VERSION = 301  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
+ABI_VERSION = 302  # dl_version(): bumped whenever an entry point's signature or a struct layout changes
 PROJ_FLAG_BISECTION = 1
 PROJ_FLAG_NO_SLICES = 2
 
@@ -40,6 +41,11 @@ _SIGNATURES = {
         _c_int,
         [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_int, ctypes.POINTER(ProjDesc), ctypes.c_int32, _c_vp, _c_vp],
     ),
+    "dl_matching_create2": (
+        _c_int,
+        [ctypes.POINTER(_c_vp), _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_int, _c_vp, _c_vp, _c_int, ctypes.POINTER(ProjDesc), ctypes.c_int32, _c_vp, _c_vp],
+    ),
+    "dl_stage_to_device": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(ctypes.c_double)]),
     "dl_matching_destroy": (_c_int, [_c_vp]),
     "dl_matching_update_costs": (_c_int, [_c_vp, _c_vp]),
     "dl_matching_update_values": (_c_int, [_c_vp, _c_vp]),
@@ -209,6 +215,20 @@ def compute_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def note_staging(what: str, src_device, device=None):
+    """The once-per-process log line of ``stage`` (and its "no GPU" error) WITHOUT copying anything: for callers that move a whole input
+    bundle themselves right afterwards (a ``stage(values)`` whose result is thrown away costs a second host-to-device copy of every value)."""
+    global _stage_logged
+    dev = compute_device() if device is None else device
+    if not _stage_logged:
+        _stage_logged = True
+        import logging
+
+        logging.getLogger("dualip_amd").warning("%s lives on '%s': staging CPU inputs to %s for the HIP path and returning results on the caller's device "
+                                                "(no CPU compute path exists; said once)", what, src_device, dev)
+    return dev
+
+
 def stage(t, what: str, device=None):
     """``t`` on a ROCm device.  The reference's callers default to ``host_device="cpu"`` (examples/movielens_matching/
     movies_lens_matching.py:227, examples/miplib_2017/solve_miplib_dataset.py:58) and its tests build CPU tensors: such inputs are COPIED
@@ -217,14 +237,47 @@ def stage(t, what: str, device=None):
     global _stage_logged
     if t is None or t.is_cuda:
         return t
-    dev = compute_device() if device is None else device
-    if not _stage_logged:
-        _stage_logged = True
-        import logging
+    return t.to(note_staging(what, t.device, device))
 
-        logging.getLogger("dualip_amd").warning("%s lives on '%s': staging CPU inputs to %s for the HIP path and returning results on the caller's device "
-                                                "(no CPU compute path exists; said once)", what, t.device, dev)
-    return t.to(dev)
+
+DL_U16 = 2  # dl_matching_create2: row indices narrowed to 16 bits on their way to the device
+STAGING_LOG = []  # one record per stage_array call: {"what", "bytes_host", "bytes_link", "seconds"} (tools/host_buffers_rate.py reads it)
+
+
+def stage_array(t: torch.Tensor, device, narrow_to: Optional[torch.dtype] = None, what: str = "array") -> torch.Tensor:
+    """A contiguous CPU tensor (ordinary pageable memory) -> a new device tensor through ``dl_stage_to_device``: host threads fill pinned
+    16 MB buffers and queue their DMAs back to back (include/dualip_hip.h).  ``narrow_to`` (int64/int32 input only): torch.int32, or
+    torch.uint16 (returned as an int16-typed tensor holding the 16-bit patterns -- torch has no arithmetic on uint16; only the C library reads
+    it): the integers are narrowed ON THE HOST, so an int64 index array crosses the link at half / a quarter of its size; a value that does
+    not fit raises ValueError."""
+    import time as _time
+
+    if t.is_cuda:
+        raise ValueError("stage_array takes a host tensor")
+    src = t.contiguous()
+    lib = load()
+    dev = torch.device(device)
+    if narrow_to is None:
+        out = torch.empty(src.shape, dtype=src.dtype, device=dev)
+        sb = db = src.element_size()
+        unsigned = 0
+    else:
+        if src.dtype not in (torch.int64, torch.int32):
+            raise ValueError("only integer tensors are narrowed")
+        out_dtype, db, unsigned = {torch.int32: (torch.int32, 4, 0), torch.uint16: (torch.int16, 2, 1)}[narrow_to]
+        sb = src.element_size()
+        if db >= sb:
+            raise ValueError(f"cannot narrow {src.dtype} to {narrow_to}")
+        out = torch.empty(src.shape, dtype=out_dtype, device=dev)
+    bad, secs = ctypes.c_int64(0), ctypes.c_double(0.0)
+    t0 = _time.perf_counter()
+    with torch.cuda.device(dev):
+        torch.cuda.current_stream(dev).synchronize()  # (`out` was allocated on torch's stream: nothing of an earlier owner of that memory may still be running)
+        check(lib.dl_stage_to_device(ptr(out), src.data_ptr(), src.numel(), sb, db, unsigned, int(os.environ.get("DUALIP_STAGE_THREADS", "0") or 0), ctypes.byref(bad), ctypes.byref(secs)))
+    if bad.value:
+        raise ValueError(f"{what}: {bad.value} value(s) do not fit {narrow_to}")
+    STAGING_LOG.append({"what": what, "bytes_host": src.numel() * sb, "bytes_link": src.numel() * db, "seconds": _time.perf_counter() - t0})
+    return out
 
 
 def result_to(res, device):

@@ -55,7 +55,7 @@ int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, vo
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
 int cold_xcd_selftest(hipStream_t st);
-int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, hipStream_t st);
+int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, double* minq_host, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
 size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype);
 int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const dl_proj_desc* projs, int32_t n_proj, double min_share,
@@ -352,17 +352,33 @@ using namespace dl;
 extern "C" {
 
 const char* dl_last_error_string(void) { return g_err; }
-int dl_version(void) { return 301; }  // ABI version: _hip.py ABI_VERSION must agree
+int dl_version(void) { return 302; }  // ABI version: _hip.py ABI_VERSION must agree
 
 // 32-bit slabs: what a workgroup's share of one row is expected to stay below, as a sum of |a| -- kSlabHeadroom mean shares of the largest row
 // L1 norm of A (deal-invariant: the grid, and with it every rounded sum, does not depend on who walks which tile), at least one max |a|.
+//
+// THE GRID MUST BE FINE ENOUGH FOR EVERY ROW, not only for the largest (round-5 review).  Every a x is rounded to the grid before its integer
+// add; the grid is ONE value for the whole matrix -- step <= slab_abound xmax 2^-29 -- so a row far smaller than the largest collects rounding
+// noise that is large against ITS sum: count_i roundings, RMS step sqrt(count_i / 12).  The reference adds such a row in fp32 (scatter_add_,
+// sparse_utils.py:236-243): relative to the row's own L1 norm its error is some 2^-24 sqrt(count_i).  The 32-bit slabs are therefore only taken
+// when, for EVERY row with a non-zero,      step sqrt(count_i / 12) <= 2^-18 L1_i xmax      i.e.   L1_i / sqrt(count_i) >= kSlabNoise slab_abound
+// -- the rounding a row collects stays below 2^-18 of its own L1 norm (times the bound of x), inside what fp32 accumulation of a few hundred
+// terms gives; otherwise the handle keeps the 64-bit slabs (2^50 grid: 2^20 finer).  Row scales that differ by orders of magnitude -- the
+// benchmark generator's log-normal destinations at >= 10M entities, any un-preconditioned matrix with rows in different units -- fail it;
+// Jacobi-preconditioned matrices (unit row norms) and the 1M-entity configuration pass.  dl_matching_info(h, 2010): 1 = gate passed.
+constexpr double kSlabNoise = 0.000140953;  // 2^-29 * 2^18 / sqrt(12)
 static int slab_refresh_bound(dl_matching* h, hipStream_t st) {
-    double l1 = -1.0;
-    int rc = launch_row_l1_max(h->nnz, h->rowidx, h->row_bytes, static_cast<const float*>(h->a), h->m, &l1, st);
+    double l1 = -1.0, minq = -1.0;
+    int rc = launch_row_l1_max(h->nnz, h->rowidx, h->row_bytes, static_cast<const float*>(h->a), h->m, &l1, &minq, st);
     if (rc) return rc;
+    const bool measured = l1 >= 0.0;
     if (l1 < 0.0) l1 = h->amax * (double)(h->row_count_max > 0 ? h->row_count_max : 1);  // (rows beyond the LDS table: the count-based bound)
     h->slab_abound = std::max(h->amax, kSlabHeadroom * l1 / (double)(h->n_wg > 0 ? h->n_wg : 1));
+    h->slab_minq = minq;
     const char* se = plan_env("DUALIP_HIP_SLAB32");
+    const bool forced = se && (se[0] == 'f' || se[0] == 't');  // "force": the grid whatever the rows (A/B of the gate, the overflow tests); "tiny": below
+    h->slab_rows_ok = measured && minq >= kSlabNoise * h->slab_abound;
+    if (!h->slab_rows_ok && !forced) h->slab32 = false;  // (64-bit slabs from here on: the allocation is sized for them; never switched back on)
     if (se && se[0] == 't') h->slab_abound = h->amax / 256.0;  // "tiny": the test hook -- every workgroup's shares overflow
     return 0;
 }
@@ -370,11 +386,19 @@ static int slab_refresh_bound(dl_matching* h, hipStream_t st) {
 int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx, int idx_dtype,
                        const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj, const int32_t* col_proj,
                        dl_stream_t stream) {
+    return dl_matching_create2(out, m, n, nnz, colptr, idx_dtype, rowidx, idx_dtype, a, c, val_dtype, projs_host, n_proj, col_proj, stream);
+}
+
+int dl_matching_create2(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const void* rowidx, int row_dtype,
+                        const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj, const int32_t* col_proj,
+                        dl_stream_t stream) {
     if (!out) return fail(DL_E_ARG, "out is null");
     *out = nullptr;
     if (m < 0 || n < 0 || nnz < 0) return fail(DL_E_ARG, "negative size");
     if (!colptr || (nnz > 0 && (!rowidx || !a || !c))) return fail(DL_E_ARG, "null CSC array");
     if (idx_dtype != DL_I32 && idx_dtype != DL_I64) return fail(DL_E_ARG, "bad idx_dtype %d", idx_dtype);
+    if (row_dtype != DL_I32 && row_dtype != DL_I64 && row_dtype != DL_U16) return fail(DL_E_ARG, "bad row_dtype %d", row_dtype);
+    if (row_dtype == DL_U16 && m > 65536) return fail(DL_E_ARG, "16-bit row indices with m = %lld rows", (long long)m);
     if (val_dtype != DL_F32 && val_dtype != DL_F64) return fail(DL_E_ARG, "bad val_dtype %d", val_dtype);
     if (n_proj < 0 || n_proj >= (int32_t)kNoProj || (n_proj > 0 && !projs_host)) return fail(DL_E_ARG, "bad projection table");
     if (m >= (1ll << 32)) return fail(DL_E_ARG, "m must be < 2^32");
@@ -764,7 +788,10 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         //  matching_kernels.hip: cold_xcd_selftest; DUALIP_HIP_COLD_XCD=0: the shared array with device-scope atomics)
         h->cold_per_xcd = !(plan_env("DUALIP_HIP_COLD_XCD") && plan_env("DUALIP_HIP_COLD_XCD")[0] == '0') && cold_xcd_selftest(st) == 1;
     }
-    if (plan_env("DUALIP_HIP_TIMELINE")) CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * 4 * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+    if (plan_env("DUALIP_HIP_TIMELINE")) {
+        CK(owned_malloc(h, (void**)&h->timeline, sizeof(unsigned long long) * kTimelineSlots * (size_t)(h->n_wg > 0 ? h->n_wg : 1)));
+        CKH(hipMemsetAsync(h->timeline, 0, sizeof(unsigned long long) * kTimelineSlots * (size_t)(h->n_wg > 0 ? h->n_wg : 1), st));
+    }
     int* bad_dev = nullptr;
     CKH(hipMalloc(&bad_dev, sizeof(int)));
     hipError_t e = hipMemsetAsync(bad_dev, 0, sizeof(int), st);
@@ -789,7 +816,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         return hip_fail(e, "row histogram");
     }
     if (nnz > 0) {
-        rc = idx_dtype == DL_I64 ? reencode_rows<int64_t>(h, rowidx, st, bad_dev, row_count_dev) : reencode_rows<int32_t>(h, rowidx, st, bad_dev, row_count_dev);
+        rc = row_dtype == DL_I64 ? reencode_rows<int64_t>(h, rowidx, st, bad_dev, row_count_dev)
+                                 : (row_dtype == DL_U16 ? reencode_rows<uint16_t>(h, rowidx, st, bad_dev, row_count_dev) : reencode_rows<int32_t>(h, rowidx, st, bad_dev, row_count_dev));
         if (rc) {
             (void)hipFree(bad_dev);
             (void)hipFree(row_count_dev);
@@ -910,11 +938,13 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         const bool can = val_dtype == DL_F32 && h->grad_lds && h->m_hot == 0 && !h->has_unbounded && h->n_wg >= kSlabMinWg && h->row_count_max <= kSlabMaxRow;
         h->slab32 = can && !(se && se[0] == '0');
         if (h->slab32) {
-            int rc_l1 = slab_refresh_bound(h, st);
+            int rc_l1 = slab_refresh_bound(h, st);  // (also the gate on the rows' scales: may clear h->slab32)
             if (rc_l1) {
                 matching_free(h);
                 return rc_l1;
             }
+        }
+        if (h->slab32) {
             // (the slab allocation was sized for int64: its first half holds the low words, its second half the high words)
             h->slab_hi = static_cast<int32_t*>(h->partial) + (size_t)h->n_wg * (size_t)h->mpad;
             CK(owned_malloc(h, (void**)&h->slab_ovf, sizeof(unsigned long long) * ((size_t)h->n_wg + 1)));
@@ -929,6 +959,8 @@ int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, con
         const int64_t rw = S > 0 ? (h->n_short + S - 1) / S : 0;
         if (const char* mr = plan_env("DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS")) h->bal_min_rounds = atoi(mr) > 1 ? atoi(mr) : 2;
         if (const char* gn = dev_env("DUALIP_HIP_BALANCE_GAIN")) h->bal_gain = atof(gn) > 0.0 ? atof(gn) : h->bal_gain;
+        if (const char* g0 = dev_env("DUALIP_HIP_BALANCE_GAIN0")) h->bal_gain0 = atof(g0) > 0.0 ? atof(g0) : h->bal_gain0;
+        if (const char* bl = dev_env("DUALIP_HIP_BALANCE_LAUNCHES")) h->bal_first = atoi(bl) > 0 ? atoi(bl) : h->bal_first;
         const bool adapt = !(be && be[0] == '0') && h->n_wg >= 2 && h->n_wg <= 1024 && rw >= h->bal_min_rounds;
         {   // (every handle has a table; only those that adapt have stamps)
             const size_t words = bal_table_words(h->n_wg > 0 ? h->n_wg : 1);
@@ -1004,10 +1036,12 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
             std::vector<unsigned long long> ep((size_t)h->n_wg + 1);
             if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(ep.data(), h->slab_ovf, sizeof(unsigned long long) * ep.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
             int64_t k = 0;
+            if (h->slab_epoch == 0) return 0;  // (no fused launch yet: the zeroed epochs are not overflows)
             for (int w = 0; w < h->n_wg; ++w) k += ep[(size_t)w] == h->slab_epoch ? 1 : 0;
             return k;
         }
         case 2100: return (int64_t)h->switches;
+        case 2010: return h->slab_rows_ok ? 1 : 0;  // 32-bit slabs: the grid is fine enough for every row (slab_refresh_bound); 0 with slab_bytes 8 = refused for that
         case 2009: return h->cold_per_xcd ? 1 : 0;  // hot-rows plan: one cold-row accumulator array per XCD (self-checked at creation) / 0: one shared array
         case 2101:
 #ifdef DL_DEVTOOLS
@@ -1136,6 +1170,17 @@ int dl_matching_own_inputs(dl_matching* h, dl_stream_t stream) {
     if (h->fair) return fail(DL_E_STATE, "a handle with the fairness stream borrows three arrays; release is not offered for it");
     hipStream_t st = (hipStream_t)stream;
     const size_t vs = h->val_dtype == DL_F32 ? 4 : 8;
+    if (h->stage_a) {
+        // A staged handle (unaligned or tiny inputs) already reads ONLY memory it owns: the aligned, zero-padded copies stage_a / stage_c and its
+        // re-encoded rows, all nnz_arr elements long -- which its windows' vector loads may touch up to their padded end.  Cutting new, shorter
+        // arrays out of them (as below) would put those loads past the new arrays' end; there is nothing to release but the link to the caller's
+        // arrays, so that is all that happens: a / c keep pointing at the staged copies, which are counted in owned_bytes since creation.
+        h->a_src = nullptr;
+        h->c_src = nullptr;
+        h->own_count = h->nnz_arr;
+        h->owns_inputs = true;
+        return 0;
+    }
     // the prefix window tiles (and the single-column tiles of entries without slices) read in place: [0, unsliced_end) -- plus one
     // window's width, because a window's loads cover 256 slots from its start (clamped to the arrays' end); never less than the 256
     // slots at index 0 that the padding descriptors' unconditional prefetches touch
@@ -1264,7 +1309,7 @@ int dl_matching_set_eq_padding(dl_matching* h, const int32_t* heights_host, int3
 int dl_matching_timeline_read(dl_matching* h, uint64_t* out_host, int64_t capacity) {
     if (!h || !out_host) return fail(DL_E_ARG, "null argument");
     if (!h->timeline) return fail(DL_E_ARG, "timeline not enabled (DUALIP_HIP_TIMELINE=1 at create)");
-    const int64_t n = (int64_t)h->n_wg * 4;
+    const int64_t n = (int64_t)h->n_wg * kTimelineSlots;
     if (capacity < n) return fail(DL_E_ARG, "timeline buffer too small");
     DL_HIP(hipDeviceSynchronize());
     DL_HIP(hipMemcpy(out_host, h->timeline, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));

@@ -73,6 +73,8 @@ constexpr double kSlabHeadroom = 4.0; // ... and how many mean shares of the ful
 constexpr int kBalMinRounds = 40;   // XCD balance: least rounds of a cyclic deal for its per-XCD table to be adapted (one round = 2.5 % then)
 constexpr int kBalTail = 64;       // balance: most rounds by which two workgroups may differ (fused_common.h: Deal, table layout)
 inline size_t bal_table_words(int n_wg) { return 4 + (size_t)n_wg + kBalTail + (size_t)kBalTail * (size_t)n_wg; }
+constexpr int kTimelineSlots = 8;  // developer timeline (DUALIP_HIP_TIMELINE): stamps per workgroup -- 0 start, 1 prologue done, 2 loop done, 3 end, 4 step derived (a launch
+                                   // that carries the optimiser step), 5 dual rows staged, 6-7 unused (a stamp inside the window loop cost the benchmark kernel 36 bytes of scratch)
 constexpr int kBalLaunches = 8;     // first launches of a handle, which all adapt the table ...
 constexpr int kBalEvery = 16;       // ... afterwards every kBalEvery-th launch does
 constexpr size_t kLdsBudget = 160 * 1024;      // gfx950 LDS per CU
@@ -124,6 +126,8 @@ struct dl_matching {
                                              // sell_balance_kernel) -- { slices dealt to everybody, wavefronts of the second phase, share in ppm, updates ; rank[n_wg] }
     bool sell_bal_frozen = false;            // (DUALIP_HIP_SELL_BALANCE_PPM: a fixed table, for tests)
     double bal_gain = 0.3;                   // (DUALIP_HIP_BALANCE_GAIN)
+    double bal_gain0 = 0.6;                  // gain of the handle's FIRST update; update k uses max(bal_gain, bal_gain0 * 0.85^k) (DUALIP_HIP_BALANCE_GAIN0): measured, profiles/r06c_balance_gain.txt
+    int bal_first = dl::kBalLaunches;            // first launches of the handle, which all adapt the table (DUALIP_HIP_BALANCE_LAUNCHES)
     int bal_launches = 0;                    // launches of the handle so far
     int bal_min_rounds = dl::kBalMinRounds;      // (DUALIP_HIP_XCD_BALANCE_MIN_ROUNDS: tests adapt small problems)
     int desc_words = 12;                // layout 4: dwords per WINDOW descriptor (2: compact, every window point-wise; single-column tiles always 12)
@@ -143,6 +147,8 @@ struct dl_matching {
     bool slab32 = false;
     double slab_abound = 0.0;                  // sum of |a| a workgroup's share of one row is expected to stay below: kSlabHeadroom mean shares of the
                                                // largest row L1 norm of A (a deal-invariant property of the matrix), at least max |a|
+    double slab_minq = -1.0;                   // min over the rows of L1_i / sqrt(count_i) (api.hip: slab_refresh_bound), -1: not measured
+    bool slab_rows_ok = false;                 // ... and whether the one grid is fine enough for every row (else the handle keeps 64-bit slabs)
     int32_t* slab_hi = nullptr;                // the second half of `partial`, [n_wg][mpad]: high words (written by a workgroup only in a launch where it overflowed)
     unsigned long long* slab_ovf = nullptr;    // owned, [n_wg + 1]: epoch of the last launch in which workgroup w overflowed; [n_wg]: any workgroup
     unsigned long long slab_epoch = 0;         // fused launches of this handle so far
@@ -199,7 +205,7 @@ struct dl_matching {
     void* sell_r = nullptr;           // owned, row indices (row_bytes wide)
     void* sell_f = nullptr;           // owned: fairness values in slice order (dl_matching_set_fairness)
     int32_t* eq_heights = nullptr;  // owned: simplex_eq reference-compatibility table [n_proj][32] or null (exact)
-    unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][4] wall-clock stamps of the last launch
+    unsigned long long* timeline = nullptr;  // developer-only (DUALIP_HIP_TIMELINE): [n_wg][kTimelineSlots] wall-clock stamps of the last launch
     // measurement hook (dl_matching_profile): event pairs around the fused-pass launches
     bool prof_on = false;
     int prof_stride = 1;      // bracket every prof_stride-th launch (the event records cost ~5 us per launch pair)

@@ -51,7 +51,7 @@ __device__ __forceinline__ void stamp(const FusedArgs<T>& g, int wg, int tid, in
             const unsigned int xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((32 - 1) << 11));
             t = (t & 0x0FFFFFFFFFFFFFFFull) | ((unsigned long long)(xcc & 0xFu) << 60);
         }
-        tl[4 * (size_t)wg + k] = t;
+        tl[(size_t)kTimelineSlots * (size_t)wg + k] = t;
     }
 }
 
@@ -281,7 +281,10 @@ __global__ __launch_bounds__(kFusedThreads) void matching_fused_kernel4(FusedArg
             }
         }
     } else {
-        for (uint32_t lt = (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + (uint32_t)wg; lt < g.n_long; lt += S)
+        // (... and from the LAST workgroup down: the cyclic deal of the window tiles ends in a partial round whose tiles go to the FIRST workgroups,
+        //  and workgroup 0 also writes the optimiser state when a launch carries the step -- a handle's one or two single-column tiles used to land
+        //  on exactly that workgroup: config 2's launch ended 3.5 us after its other 255 workgroups, tools/timeline.py)
+        for (uint32_t lt = (uint32_t)(kFusedWaves - 1 - wave) * (uint32_t)gridDim.x + ((uint32_t)gridDim.x - 1u - (uint32_t)wg); lt < g.n_long; lt += S)
             walk_long(byte_offset(kernarg_args(g).long32 + (size_t)lt * kDesc4Words, dlane * 4u)[0], kernarg_args(g).long32 + (size_t)lt * kDesc4Words);
     }
     // the slices of the long columns (K lanes per column), every wavefront, ahead of everything cheap (sell.h)

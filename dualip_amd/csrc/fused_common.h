@@ -44,7 +44,7 @@ struct FusedArgs {
     unsigned long long* bal_stamps;       // layout 4: [n_wg][4] wall-clock stamps the balance kernel reads, or null
     const int32_t* sell_bal;              // layout 4, first binary: two-phase deal of the one-lane slices (common.h), or null (one even deal)
     int ablate;  // developer-only timing ablations (DUALIP_HIP_ABLATE, libdualip_hip_dev.so only): bits 8, 32, 128, 1024, 12-13, 14-17 -- see their uses
-    unsigned long long* timeline;  // developer-only: [n_wg][4] wall-clock stamps (start, after prologue, after loop, end) or null
+    unsigned long long* timeline;  // developer-only: [n_wg][kTimelineSlots] wall-clock stamps (common.h) or null
     int64_t m_hot;                 // hot-rows plan: rows < m_hot (renumbered by frequency) have their GRADIENT accumulator in LDS; 0 = every row does
     int64_t m_lam;                 // hot-rows plan: rows < m_lam have their DUAL entry in LDS (m_hot <= m_lam <= m; m: no tile gathers from L2)
     long long* cold_grad;          // hot-rows plan: int64 accumulators of the rows >= m_hot (global atomics, pre-zeroed): [kColdCopies][mpad]
@@ -102,7 +102,13 @@ __device__ __forceinline__ uint32_t deal_slot(const Deal& d, const int32_t* tab,
     const uint32_t n_wg = gridDim.x, wg = blockIdx.x;
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (k < d.n_min) {  // (also the whole of an unweighted deal)
-        const uint32_t q = (k * n_wg + wg) * (uint32_t)kFusedWaves + v;
+        // Round k hands slots [k S, (k + 1) S) out workgroup-major: the sixteen wavefronts of a workgroup walk sixteen neighbouring tiles.  The LAST
+        // round of an even deal is partial -- N - k_last S tiles -- and workgroup-major it gives the first workgroups a whole extra tile per
+        // wavefront and the others none (1M entities: ten rounds, workgroups 0 .. 140 carry 160 tiles, the rest 144, and the launch ends with
+        // the former); wavefront-major -- slot k S + v G + w -- every workgroup gets its share of what is left (a few wavefronts each).
+        // (recognised without any state carried through the hot loop -- the round's first slot + S runs past N -- the kernel has no register to spare)
+        const uint32_t base = k * n_wg * (uint32_t)kFusedWaves;
+        const uint32_t q = base + (base + n_wg * (uint32_t)kFusedWaves > N ? v * n_wg + wg : wg * (uint32_t)kFusedWaves + v);
         return q < N ? q : N;
     }
     if (k >= d.n_mine) return N;
@@ -487,6 +493,18 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     off += (size_t)kProjLds * sizeof(ProjT<T>);
     w.red_s = reinterpret_cast<double*>(smem + off);
     w.s = (T)(-1.0 / g.gamma);
+    // The projection table's entries are requested FIRST (four wavefronts, one entry per thread): nothing depends on them until the table is
+    // filled after the duals, and where they stood -- behind the staging loop -- their round trip was a third dependent one at the head of every
+    // launch (tools/timeline.py, 1M entities: step derived 3.3 us, rows staged 6.3 us, prologue done 10.4 us).
+    ProjDev pd_early;
+    pd_early.kind = DL_PROJ_NONE;
+    pd_early.p0 = 0.0;
+    pd_early.p1 = 0.0;
+    if (wave < kProjLds / 64 && tid < g.n_proj && tid < kProjLds - 1) {
+        pd_early.kind = g.projs[tid].kind;
+        pd_early.p0 = g.projs[tid].p0;
+        pd_early.p1 = g.projs[tid].p1;
+    }
     double lmax = 0.0;
     // The optimiser step of the previous iteration, if this launch carries it (agd_step.h; opt-in, DUALIP_HIP_FUSE_APPLY=1): every
     // wavefront derives the same step and every workgroup forms the new iterate itself.  Measured on one box at the per-rank size
@@ -499,6 +517,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     if (applying) {
         const ApplyArgs<T>& ap = kernarg_args(g).apply;
         a_stp = (T)agd_step_scalars(ap, lane, wg == 0, tid);
+        if (kernarg_args(g).timeline && tid == 0) kernarg_args(g).timeline[(size_t)kTimelineSlots * (size_t)wg + 4] = wall_clock64();
         const float bt = ap.beta[ap.iter - 1];
         a_bb = (T)bt;
         a_omb = (T)(float)(1.0f - bt);
@@ -579,6 +598,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
             }
         }
     }
+    if (kernarg_args(g).timeline && tid == 0) kernarg_args(g).timeline[(size_t)kTimelineSlots * (size_t)wg + 5] = wall_clock64();  // (this wavefront's rows are in LDS)
     if constexpr (GRAD_LDS) {
         for (int64_t i = tid; i < m_lds; i += kFusedThreads) w.grad_s[i] = 0;
     }
@@ -587,8 +607,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     //  ahead of the exec restore of exactly this join)
     static_assert(kProjLds % 64 == 0 && kProjLds <= kFusedThreads, "projection table filled by whole wavefronts");
     if (wave < kProjLds / 64) {  // slot kProjLds-1 stays the identity (columns in no entry)
-        const int id = tid;
-        w.proj_s[id] = (id < g.n_proj && id < kProjLds - 1) ? make_proj<T>(g.projs[id].kind, g.projs[id].p0, g.projs[id].p1) : make_proj<T>(DL_PROJ_NONE, 0.0, 0.0);
+        w.proj_s[tid] = make_proj<T>(pd_early.kind, pd_early.p0, pd_early.p1);  // (slots past the map, and slot kProjLds - 1: the identity)
     }
     lmax = wave_allreduce(lmax, OpMax());
     if (lane == 0) w.red_s[wave] = lmax;

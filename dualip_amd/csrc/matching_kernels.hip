@@ -3,6 +3,7 @@
 // one-off measurements of handle creation (max |v|, row L1 norms, the self-check of the per-XCD accumulators), the balance kernels of the two
 // deals, and the launch glue (fused_typed).  The pass is matching_fused_kernel4 (fused4_kernel.h, four translation units); the 64-wide
 // kernel that used to live here served unaligned and tiny inputs until round 5 -- they are staged into the 256-wide layout now (api.hip).
+#include <cmath>
 #include <atomic>
 
 #include "comm.h"
@@ -179,48 +180,71 @@ int cold_xcd_selftest(hipStream_t st) {
     return ok ? 1 : 0;
 }
 
-// max_i sum_{k in row i} |a_k| (one-off, for handles with 32-bit slabs: the fixed-point grid is taken from it -- common.h: slab32).  A bound's
-// estimate, so float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused
-// kernel's LDS), flushed with float atomics, reduced to one maximum (floats >= 0 order like their bit patterns) by the last block.
+// max_i sum_{k in row i} |a_k| (one-off, for handles with 32-bit slabs: the fixed-point grid is taken from it -- common.h: slab32) and
+// min_i L1_i / sqrt(count_i) over the non-empty rows (what decides whether that grid is fine enough for EVERY row: api.hip, slab_refresh_bound).
+// Estimates, so float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused
+// kernel's LDS), flushed with float atomics, reduced to one maximum / minimum (floats >= 0 order like their bit patterns).
 constexpr int kRowL1Max = 16384;
-template <class RowT>
+template <class RowT, bool COUNT>
 __global__ __launch_bounds__(1024) void row_l1_kernel(int64_t nnz, const RowT* __restrict__ rows, const float* __restrict__ a, int m, float* __restrict__ sums) {
     __shared__ float acc[kRowL1Max];
     for (int i = threadIdx.x; i < m; i += blockDim.x) acc[i] = 0.f;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) atomicAdd(&acc[(uint32_t)rows[k]], fabsf(a[k]));
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
+        const float v = fabsf(a[k]);
+        atomicAdd(&acc[(uint32_t)rows[k]], COUNT ? (v != 0.f ? 1.f : 0.f) : v);  // (counts: exact in float up to 2^24 per row; slab32 handles have <= 65 536)
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < m; i += blockDim.x)
         if (acc[i] != 0.f) atomicAdd(&sums[i], acc[i]);
 }
-__global__ void row_l1_max_kernel(int m, const float* __restrict__ sums, unsigned int* __restrict__ out_bits) {
-    float mx = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) mx = fmaxf(mx, sums[i]);
+__global__ void row_l1_max_kernel(int m, const float* __restrict__ sums, const float* __restrict__ counts, unsigned int* __restrict__ out_bits) {
+    float mx = 0.f, mq = INFINITY;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        mx = fmaxf(mx, sums[i]);
+        if (counts[i] > 0.f && sums[i] > 0.f) mq = fminf(mq, sums[i] / sqrtf(counts[i]));
+    }
     mx = wave_allreduce(mx, OpMax());
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(mx));
+    mq = -wave_allreduce(-mq, OpMax());
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out_bits, __float_as_uint(mx));
+        atomicMin(out_bits + 1, __float_as_uint(mq));
+    }
 }
-// *out_host = the largest row L1 norm of the fp32 values `a` (rows: the handle's re-encoded indices); -1 when the rows do not fit the LDS table
-int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, hipStream_t st) {
+// *out_host = the largest row L1 norm of the fp32 values `a` (rows: the handle's re-encoded indices); -1 when the rows do not fit the LDS table.
+// *minq_host = the smallest L1_i / sqrt(non-zero count_i) over the rows that have a non-zero value (+inf when there is none).
+int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, double* minq_host, hipStream_t st) {
     *out_host = -1.0;
+    *minq_host = -1.0;
     if (m <= 0 || m > kRowL1Max || nnz <= 0) return 0;
-    float* sums = nullptr;
-    DL_HIP(hipMalloc((void**)&sums, sizeof(float) * ((size_t)m + 1)));
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * ((size_t)m + 1), st);
+    float* sums = nullptr;  // [m] L1 sums, [m] counts, [2] results
+    DL_HIP(hipMalloc((void**)&sums, sizeof(float) * (2 * (size_t)m + 2)));
+    float* counts = sums + m;
+    unsigned int* res = reinterpret_cast<unsigned int*>(sums + 2 * m);
+    const float init[2] = {0.f, INFINITY};
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)m, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, init, sizeof(init), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         const int64_t b64 = (nnz + 1023) / 1024;
         const int blocks = (int)(b64 > 256 ? 256 : b64);
-        if (row_bytes == 2) hipLaunchKernelGGL(row_l1_kernel<uint16_t>, dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, sums);
-        else hipLaunchKernelGGL(row_l1_kernel<uint32_t>, dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, sums);
-        hipLaunchKernelGGL(row_l1_max_kernel, dim3(16), dim3(256), 0, st, (int)m, sums, reinterpret_cast<unsigned int*>(sums + m));
+        if (row_bytes == 2) {
+            hipLaunchKernelGGL((row_l1_kernel<uint16_t, false>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, sums);
+            hipLaunchKernelGGL((row_l1_kernel<uint16_t, true>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, counts);
+        } else {
+            hipLaunchKernelGGL((row_l1_kernel<uint32_t, false>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, sums);
+            hipLaunchKernelGGL((row_l1_kernel<uint32_t, true>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, counts);
+        }
+        hipLaunchKernelGGL(row_l1_max_kernel, dim3(16), dim3(256), 0, st, (int)m, sums, counts, res);
         e = hipGetLastError();
     }
-    float mx = 0.f;
-    if (e == hipSuccess) e = hipMemcpyAsync(&mx, sums + m, sizeof(float), hipMemcpyDeviceToHost, st);
+    float out[2] = {0.f, INFINITY};
+    if (e == hipSuccess) e = hipMemcpyAsync(out, res, sizeof(out), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(sums);
     if (e != hipSuccess) return hip_fail(e, "row L1 norms");
-    *out_host = (double)mx;
+    *out_host = (double)out[0];
+    *minq_host = (double)out[1];
     return 0;
 }
 
@@ -565,7 +589,7 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     //  slices get slower as the Newton passes multiply, the windows do not)
     // (not with the fairness stream: its sum f.x is a per-workgroup double, so an adapting deal would put the measured timings into the
     //  last bits of the two dense rows; those handles keep the even deal and stay bit-reproducible like the others)
-    args.bal_stamps = (h->bal_stamps && !h->fair && (h->bal_launches < kBalLaunches || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
+    args.bal_stamps = (h->bal_stamps && !h->fair && (h->bal_launches < h->bal_first || h->bal_launches % kBalEvery == 0)) ? h->bal_stamps : nullptr;
     args.do_apply = 0;
     args.apply = ApplyArgs<T>();
     if (pending && pending->valid) {
@@ -606,7 +630,10 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     if (ev_stop) DL_HIP(hipEventRecord(ev_stop, st));
     if (args.bal_stamps) {  // adapt the per-XCD rounds to what this launch's stamps say (a few microseconds)
         if (h->bal_adapts) {  // (a table declared non-adapting holds 0x7FFFFFFF rounds: never rewritten from it)
-            hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, h->bal_gain);
+            // (the first updates move further: the even deal they start from is several per cent off -- XCDs differ by 5-8 % -- and a benchmark window,
+            //  or a short solve, is over before a gain of 0.3 has closed that)
+            const double gain_k = std::max(h->bal_gain, h->bal_gain0 * std::pow(0.85, (double)h->bal_launches));
+            hipLaunchKernelGGL(wg_balance_kernel, dim3(1), dim3(1024), 0, st, h->bal, h->bal_stamps, h->n_wg, (uint32_t)h->n_short, h->bal_min_rounds, gain_k);
             DL_HIP(hipGetLastError());
         }
         if (h->sell_bal && !h->sell_bal_frozen) {  // (handles whose windows do not adapt: the slices' two-phase deal does)

@@ -13,6 +13,7 @@ Differences from the reference, all deliberate:
     objective identically (the reference does 3 reduces + barrier and only rank 0 holds the result).
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -142,13 +143,35 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         if A.shape != c.shape or A.values().shape != c.values().shape:
             raise ValueError("A and c must share the same sparsity pattern")
         # CPU-resident inputs (the reference's default host_device, run_solver.py / its tests): copied to the current ROCm device; the
-        # arithmetic is libdualip_hip.so's either way and calculate() hands its results back on the device of the duals it was given
+        # arithmetic is libdualip_hip.so's either way and calculate() hands its results back on the device of the duals it was given.
+        # Both tensors on the host (what the reference's drivers hand over: run_matching_benchmark_dist.py:95-110): the ARRAYS the kernel
+        # needs are staged through dl_stage_to_device -- pinned, chunked, several DMA queues; the int64 row indices narrowed on the host to the
+        # 16 / 32 bits the handle stores anyway, so they cross the link at a quarter / half of their size and never sit in HBM as int64; an index
+        # array that A and c share crosses once -- and ``self.A`` / ``self.c`` stay the CALLER's tensors (as in the reference, whose objective
+        # keeps what it was given).  Maps with user-defined operators and Jacobi preconditioning work on whole device tensors: torch's copy.
+        self._host_arrays = None
         if not A.values().is_cuda or not c.values().is_cuda:
             dev = _hip.compute_device() if not (A.values().is_cuda or c.values().is_cuda) else (A.values().device if A.values().is_cuda else c.values().device)
-            A, c = _hip.stage(A, "A", dev), _hip.stage(c, "c", dev)
+            needs_tensors = use_jacobi_precondition or os.environ.get("DUALIP_HOST_STAGING", "native") == "torch" or any(
+                project(e.proj_type, **e.proj_params).descriptor() is None for e in matching_input_args.projection_map.values())
+            if not (A.values().is_cuda or c.values().is_cuda) and not needs_tensors and A.values().numel() > 0:
+                _hip.note_staging("A", A.values().device, dev)
+                m_rows = int(A.shape[0])
+                rows_src = A.row_indices()
+                narrow = torch.uint16 if m_rows <= 65536 else (torch.int32 if (rows_src.dtype == torch.int64 and m_rows < 2**31) else None)
+                self._host_arrays = {
+                    "colptr": _hip.stage_array(A.ccol_indices(), dev, what="ccol_indices"),
+                    "rows": _hip.stage_array(rows_src, dev, narrow_to=narrow, what="row_indices"),
+                    "row_code": _hip.DL_U16 if narrow == torch.uint16 else (_hip.DL_I32 if (narrow == torch.int32 or rows_src.dtype == torch.int32) else _hip.DL_I64),
+                    "a": _hip.stage_array(A.values(), dev, what="A.values"),
+                    "c": _hip.stage_array(c.values(), dev, what="c.values"),
+                }
+            else:
+                A, c = _hip.stage(A, "A", dev), _hip.stage(c, "c", dev)
+        compute_dev = self._host_arrays["a"].device if self._host_arrays is not None else A.values().device
         b_in = matching_input_args.b_vec
-        if b_in is not None and b_in.device != A.values().device:
-            b_in = _hip.stage(b_in, "b_vec", A.values().device) if not b_in.is_cuda else b_in.to(A.values().device)
+        if b_in is not None and b_in.device != compute_dev:
+            b_in = _hip.stage(b_in, "b_vec", compute_dev) if not b_in.is_cuda else b_in.to(compute_dev)
         # Jacobi pre-conditioning (run_solver.py:136-144 expects the objective to carry ``use_jacobi_precondition`` and
         # ``invert_jacobi_precondition``; preprocessing/precondition.py:8-28): rows of A and b scaled by 1 / ||A_i||_2 -- on
         # COPIES, the caller's tensors stay as they are.  ``row_norms`` given = the norms of the WHOLE matrix when this
@@ -175,7 +198,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         self.is_distributed = self.b_vec is None
         self.equality_mask = matching_input_args.equality_mask
         self.batching = batching
-        self.device = A.values().device
+        self.device = compute_dev
         self.dtype = A.values().dtype
         self.m, self.n = int(A.shape[0]), int(A.shape[1])
         self.nnz = int(A.values().shape[0])
@@ -184,14 +207,19 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
                 raise ValueError("b_vec must have the dtype of A")
 
         # keep the tensors the kernel reads alive and contiguous (values are referenced, not copied)
-        self._a_vals = A.values()
-        self._c_vals = c.values()
+        if self._host_arrays is not None:  # (the staged copies; self.A / self.c are the caller's host tensors)
+            self._a_vals, self._c_vals = self._host_arrays["a"], self._host_arrays["c"]
+            colptr, rowidx, row_code = self._host_arrays["colptr"], self._host_arrays["rows"], self._host_arrays["row_code"]
+        else:
+            self._a_vals = A.values()
+            self._c_vals = c.values()
+            colptr = A.ccol_indices().contiguous()
+            rowidx = A.row_indices().contiguous()
+            row_code = _hip.idx_code(rowidx.dtype)
         if not (self._a_vals.is_contiguous() and self._c_vals.is_contiguous()):
             raise ValueError("CSC value arrays must be contiguous")
         if self._c_vals.dtype != self.dtype:
             raise ValueError("A and c must have the same dtype")
-        colptr = A.ccol_indices().contiguous()
-        rowidx = A.row_indices().contiguous()
         descs, col_proj = _column_projection_table(self.projection_map, self.n, self.device)
         if not column_slices:  # keep every entry in window tiles (include/dualip_hip.h: DL_PROJ_FLAG_NO_SLICES)
             descs = [_hip.ProjDesc(d.kind, d.flags | _hip.PROJ_FLAG_NO_SLICES, d.p0, d.p1) for d in descs]
@@ -200,14 +228,15 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         lib = _hip.load()
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = lib.dl_matching_create(
+            rc = lib.dl_matching_create2(
                 ctypes.byref(handle),
                 self.m,
                 self.n,
                 self.nnz,
                 _hip.ptr(colptr),
-                _hip.ptr(rowidx),
                 _hip.idx_code(colptr.dtype),
+                _hip.ptr(rowidx),
+                row_code,
                 _hip.ptr(self._a_vals),
                 _hip.ptr(self._c_vals),
                 _hip.dtype_code(self.dtype),
@@ -219,6 +248,8 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         _hip.check(rc)
         self._handle = handle
         self._lib = lib
+        if self._host_arrays is not None:  # the index arrays were consumed by the handle (it owns re-encoded rows and its tile tables)
+            self._host_arrays = {"a": self._a_vals, "c": self._c_vals}
         self._packed = torch.zeros(self.m + 2, dtype=torch.float64, device=self.device)
         self._scal = torch.zeros(6, dtype=torch.float64, device=self.device)
         self._primal = None  # allocated on the first save_primal, then reused (the reference aliases its scratch too)
@@ -282,6 +313,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         info["slice_balance_updates"] = int(self._lib.dl_matching_info(self._handle, 2006))
         info["slab_bytes"] = int(self._lib.dl_matching_info(self._handle, 2007))  # per element of the per-workgroup gradient slabs (4: 32-bit fixed point)
         info["cold_per_xcd"] = int(self._lib.dl_matching_info(self._handle, 2009))  # hot-rows plan: per-XCD cold-row accumulators (self-checked) in use
+        info["slab_rows_ok"] = int(self._lib.dl_matching_info(self._handle, 2010))  # 1: the one grid of 32-bit slabs is fine enough for every row (0 + slab_bytes 8: refused for that)
         info["slab_overflows"] = int(self._lib.dl_matching_info(self._handle, 2008))  # workgroups that sent high words too in the last launch
         mask = int(self._lib.dl_matching_info(self._handle, 2100))  # plan switches honoured at creation (DUALIP_HIP_*)
         info["switches"] = [self._lib.dl_switch_name(i).decode() for i in range(32) if (mask >> i) & 1 and self._lib.dl_switch_name(i)]
@@ -319,12 +351,17 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         keeps in column-per-lane slices, plus max |a| / max |c| for its fixed-point scales.  After an in-place change call
         ``values_changed()`` (A, or both) or ``costs_changed()`` (c only) before the next ``calculate``; a changed sparsity
         pattern needs a new objective."""
+        if self._host_arrays is not None:  # (host-resident caller: the device copies follow its arrays first)
+            self._a_vals.copy_(self.A.values())
+            self._c_vals.copy_(self.c.values())
         with torch.cuda.device(self.device):
             _hip.check(self._lib.dl_matching_update_values(self._handle, _hip.stream_ptr(self.device)))
 
     def costs_changed(self) -> None:
         """Tell the kernel handle that the values of ``c`` were rewritten in place (same pattern): it refreshes what it
         derived from them.  ``A`` must stay as it was when the objective was built."""
+        if self._host_arrays is not None:
+            self._c_vals.copy_(self.c.values())
         with torch.cuda.device(self.device):
             _hip.check(self._lib.dl_matching_update_costs(self._handle, _hip.stream_ptr(self.device)))
 
@@ -340,11 +377,12 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         return int(cnt.value), float(ms.value)
 
     def timeline(self):
-        """Developer aid (DUALIP_HIP_TIMELINE=1 at construction): uint64[n_wg, 4] 100 MHz stamps of the last fused launch."""
+        """Developer aid (DUALIP_HIP_TIMELINE=1 at construction): uint64[n_wg, 8] 100 MHz stamps of the last fused launch -- columns 0 start,
+        1 prologue done, 2 loop done, 3 end, 4 optimiser step derived (launches that carry it), 5 dual rows staged; 0 where a stamp was not taken."""
         import numpy as np
 
         n_wg = self.info()["workgroups"]
-        out = np.zeros((n_wg, 4), dtype=np.uint64)
+        out = np.zeros((n_wg, 8), dtype=np.uint64)
         _hip.check(self._lib.dl_matching_timeline_read(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size))
         return out
 

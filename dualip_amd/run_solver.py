@@ -56,7 +56,7 @@ def _column_blocks(projection_map, n: int):
     return blocks
 
 
-def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, partition: str = "reference") -> MatchingInputArgs:
+def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, partition: str = "reference", stage_in_objective: bool = True) -> MatchingInputArgs:
     """This rank's columns of the global problem.
 
     ``partition="reference"``: one contiguous block, sizes as dist_utils.split_tensors_to_devices -- n // W (+1 for the first
@@ -87,6 +87,11 @@ def _local_shard(input_args: MatchingInputArgs, rank: int, world: int, device, p
         cuts = contiguous_cuts(n, world, projection_cost_blocks(input_args.projection_map) if partition == "cost" else ())
         pieces = [(cuts[rank], cuts[rank + 1])]
     colptr = A.ccol_indices()
+    if stage_in_objective and not A.values().is_cuda and not c.values().is_cuda:
+        # a host-resident problem (the reference's drivers: run_matching_benchmark_dist.py:95-110): the shard is cut on the HOST -- views of the
+        # caller's arrays for a contiguous block -- and the objective stages what the kernel needs through dl_stage_to_device (pinned, chunked,
+        # row indices narrowed on the way) instead of one pageable torch copy per field here
+        device = A.values().device
     ptrs, rows, a_vals, c_vals, cols, off = [torch.zeros(1, dtype=colptr.dtype, device=device)], [], [], [], [], 0
     for lo, hi in pieces:
         k0, k1 = (int(v) for v in colptr[torch.tensor([lo, hi], device=colptr.device)].tolist())
@@ -159,7 +164,7 @@ def build_objective(input_args: BaseInputArgs, solver_args: SolverArgs, compute_
         dist.all_gather_object(kinds, partition)
         if len(set(kinds)) != 1:
             raise ValueError(f"the ranks disagree on the partition of the entities ({kinds}): set ComputeArgs.partition / DUALIP_PARTITION identically on every rank")
-        local = _local_shard(input_args, rank, world, device, partition)
+        local = _local_shard(input_args, rank, world, device, partition, stage_in_objective=not jac)  # (Jacobi scales whole device tensors)
         return MatchingSolverDualObjectiveFunctionDistributed(
             local_matching_input_args=local, b_vec=input_args.b_vec, gamma=solver_args.gamma, host_device=compute_args.host_device, use_jacobi_precondition=jac
         )
@@ -210,7 +215,8 @@ def _run_solver(input_args, solver_args, compute_args, objective_args) -> Solver
         host_device = _hip.compute_device()
         _hip.stage(input_args.b_vec, "run_solver inputs (host_device='cpu')", host_device)  # (says it once in the log; raises without a GPU)
         compute_args = dataclasses.replace(compute_args, host_device=str(host_device))
-    if not sharded:
+    stages_itself = caller_device is not None and objective_args.objective_type == "matching" and not objective_args.use_jacobi_precondition
+    if not sharded and not stages_itself:  # (a host-resident matching problem: the objective stages the arrays the kernel needs -- dl_stage_to_device)
         input_args = transfer_tensors_to_device(input_args, host_device)
     objective = build_objective(input_args, solver_args, compute_args, objective_args)
     solver = AcceleratedGradientDescent(

@@ -28,7 +28,8 @@ extern "C" {
 typedef void* dl_stream_t; /* hipStream_t */
 
 enum { DL_F32 = 0, DL_F64 = 1 };  /* value dtype of A, c, lambda, b, x */
-enum { DL_I32 = 0, DL_I64 = 1 };  /* dtype of the caller's ccol_indices / row_indices (torch CSC gives int64) */
+enum { DL_I32 = 0, DL_I64 = 1, DL_U16 = 2 };  /* dtype of the caller's ccol_indices / row_indices (torch CSC gives int64); DL_U16: row indices only
+                                                  (dl_matching_create2: indices narrowed on the way to the device, dl_stage_to_device) */
 
 /* projection kinds: reference registry names (src/dualip/projections/{box,cone,simplex}.py) */
 enum {
@@ -90,7 +91,25 @@ int dl_version(void);
 int dl_matching_create(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, const void* rowidx,
                        int idx_dtype, const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host,
                        int32_t n_proj, const int32_t* col_proj, dl_stream_t stream);
+/* The same with the row indices in a type of their own: DL_I32 / DL_I64, or DL_U16 (m <= 65536) -- what dl_stage_to_device produces when it
+ * narrows a host-resident int64 index array on its way across the link; colptr keeps idx_dtype (DL_I32 / DL_I64).  dl_matching_create is
+ * this call with row_dtype = idx_dtype. */
+int dl_matching_create2(dl_matching** out, int64_t m, int64_t n, int64_t nnz, const void* colptr, int idx_dtype, const void* rowidx,
+                        int row_dtype, const void* a, const void* c, int val_dtype, const dl_proj_desc* projs_host, int32_t n_proj,
+                        const int32_t* col_proj, dl_stream_t stream);
 int dl_matching_destroy(dl_matching* h);
+
+/* HOST -> DEVICE staging for callers that keep the problem in host memory (the reference's drivers do: run_solver.py:17-32
+ * `transfer_tensors_to_device`, benchmark/run_matching_benchmark_dist.py:95-110 hand every rank CPU shards).  Copies `count` elements of
+ * `src_bytes` each from `src_host` -- ordinary pageable memory -- to `dst_dev`: `threads` host threads (0: a default) claim 16 MB chunks,
+ * copy them into pinned buffers of their own and queue each chunk's DMA as soon as it is filled, so the link runs back to back from several
+ * queues.  src_bytes == dst_bytes: a plain copy.  8 -> 4, 8 -> 2 or 4 -> 2: integers NARROWED on the host on their way into the pinned
+ * buffer (dst_unsigned != 0: to uint32 / uint16) -- torch's int64 CSC row indices cross the link at a quarter of their size and never
+ * exist in device memory in 64-bit form; *bad_out_host counts the values that did not fit (the caller treats > 0 as an error).
+ * SYNCHRONOUS (returns when the data are in device memory); works on the calling thread's current device; one call at a time per process.
+ * *seconds_out_host: wall clock of the call.  Not a replacement for anything the reference has native code for -- its copy is torch's. */
+int dl_stage_to_device(void* dst_dev, const void* src_host, int64_t count, int src_bytes, int dst_bytes, int dst_unsigned, int threads,
+                       int64_t* bad_out_host, double* seconds_out_host);
 
 /* Footprint: make the handle SELF-CONTAINED.  A handle borrows the caller's value arrays (window tiles, single-column tiles and in-place
  * slices read them every launch) although the columns it keeps in column-per-lane slices are never read from them again, and it owns

@@ -159,3 +159,68 @@ def test_sparse_utils_on_cpu_tensors_including_output_tensor():
     want = torch.where(want == 0, torch.ones_like(want), want)
     assert norms.device.type == "cpu" and torch.allclose(norms, want, atol=1e-13)
     assert torch.allclose(A2.to_dense(), A.to_dense() / want[:, None], atol=1e-13) and torch.allclose(b, b0 / want, atol=1e-13)
+
+
+def test_host_arrays_are_staged_natively_and_give_the_same_bits():
+    """``dl_stage_to_device`` (pinned, chunked, several DMA queues; int64 row indices narrowed on the host): a plain copy arrives bit for bit,
+    narrowing int64 -> uint16 / int32 gives the values, a value that does not fit is an error; an objective built from CPU tensors in the
+    reference's format (two int64 CSC tensors of one pattern) returns the SAME BITS as one built from device tensors -- ``calculate``, primal
+    and a 40-iteration solve -- keeps the caller's tensors as ``objective.A`` / ``.c``, and follows in-place changes of the host arrays
+    through ``values_changed()``."""
+    from dualip_amd import _hip
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections import create_projection_map
+
+    g = torch.Generator().manual_seed(5)
+    for n_el in (1, 1000, (16 << 20) // 4 + 17, 3 * (16 << 20) // 4 + 5):  # (below one chunk, exactly past one, several chunks with a ragged tail)
+        src = torch.randn(n_el, generator=g)
+        assert torch.equal(_hip.stage_array(src, "cuda:0").cpu(), src)
+    idx = torch.randint(0, 65536, (5_000_003,), generator=g, dtype=torch.int64)
+    u16 = _hip.stage_array(idx, "cuda:0", narrow_to=torch.uint16)
+    assert u16.dtype == torch.int16 and torch.equal(u16.cpu().to(torch.int64) & 0xFFFF, idx)
+    assert torch.equal(_hip.stage_array(idx, "cuda:0", narrow_to=torch.int32).cpu().to(torch.int64), idx)
+    idx[1234567] = 65536
+    with pytest.raises(ValueError, match="do not fit"):
+        _hip.stage_array(idx, "cuda:0", narrow_to=torch.uint16)
+    idx[1234567] = -1
+    with pytest.raises(ValueError, match="do not fit"):
+        _hip.stage_array(idx, "cuda:0", narrow_to=torch.uint16)
+
+    z = load("g2_syn2000.npz")
+    p = problem(z)
+    n = p["n"]
+    half = n // 2
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, None, indices=range(0, half)), **create_projection_map("simplex", {"z": 1.0}, None, indices=range(half, n))}
+    kw = dict(max_iter=40, gamma=0.02, initial_step_size=1e-3, max_step_size=0.1, iteration_callback=False)
+    lam = torch.from_numpy(np.random.default_rng(2).uniform(0, 0.02, p["m"]))
+    for dn in ("f32", "f64"):
+        dev_args, cpu_args = torch_args(p, dn, pm, "cuda:0"), torch_args(p, dn, pm, "cpu")
+        fd = MatchingSolverDualObjectiveFunction(dev_args, gamma=0.02)
+        before = len(_hip.STAGING_LOG)
+        fc = MatchingSolverDualObjectiveFunction(cpu_args, gamma=0.02)
+        staged = _hip.STAGING_LOG[before:]
+        assert [r["what"] for r in staged] == ["ccol_indices", "row_indices", "A.values", "c.values"], staged
+        assert staged[1]["bytes_link"] * 4 == staged[1]["bytes_host"]  # int64 row indices crossed the link as 16 bits (m <= 65536)
+        assert fc.A is cpu_args.A and fc.c is cpu_args.c and fc.A.values().device.type == "cpu" and fc.device.type == "cuda"
+        rd = fd.calculate(lam.to(TD[dn]).to("cuda:0"), save_primal=True)
+        rc = fc.calculate(lam.to(TD[dn]), save_primal=True)  # (CPU duals in, CPU results out)
+        assert rc.dual_gradient.device.type == "cpu" and torch.equal(rc.dual_gradient, rd.dual_gradient.cpu()) and torch.equal(rc.primal_var, rd.primal_var.cpu())
+        assert float(rc.dual_objective) == float(rd.dual_objective)
+        sd = AcceleratedGradientDescent(**kw).maximize(fd, torch.zeros(p["m"], dtype=TD[dn], device="cuda:0"))
+        sc = AcceleratedGradientDescent(**kw).maximize(fc, torch.zeros(p["m"], dtype=TD[dn]))
+        assert sc.dual_objective_log == sd.dual_objective_log and torch.equal(sc.dual_val, sd.dual_val.cpu())
+        # an in-place change of the caller's HOST arrays reaches the handle through values_changed(), as for device callers
+        cpu_args.A.values().mul_(0.5)
+        dev_args.A.values().mul_(0.5)
+        fc.values_changed()
+        fd.values_changed()
+        assert torch.equal(fc.calculate(lam.to(TD[dn])).dual_gradient, fd.calculate(lam.to(TD[dn]).to("cuda:0")).dual_gradient.cpu())
+    # torch's own copy stays available (and is what maps with user-defined operators / Jacobi preconditioning take)
+    os.environ["DUALIP_HOST_STAGING"] = "torch"
+    try:
+        before = len(_hip.STAGING_LOG)
+        ft = MatchingSolverDualObjectiveFunction(torch_args(p, "f64", pm, "cpu"), gamma=0.02)
+        assert len(_hip.STAGING_LOG) == before and ft.A.values().is_cuda
+    finally:
+        del os.environ["DUALIP_HOST_STAGING"]

@@ -135,6 +135,25 @@ def test_unaligned_values_and_tiny_problems_are_staged_into_the_same_kernel():
         assert relerr(half.dual_gradient.cpu().numpy(), grad) < RTOL["f32"] and relerr(half.primal_var.cpu().numpy(), x) < RTOL["f32"]
     # fewer than 1024 non-zeros (down to a 5 x 5 problem and an empty one elsewhere in the suite): the same layout on a padded copy
     q = _random_problem(40, 60, 6, seed=8, empty_every=7)
+    # release_inputs() on a STAGED handle (nnz < 1024, and nnz % 4 != 0 below): the handle already reads only its own padded copies, so the
+    # release is bookkeeping -- same bits before and after, the caller's tensors may go, value refreshes are refused afterwards
+    for qq in (q, _random_problem(60, 150, 5, seed=12)):
+        assert int(qq["colptr"][-1]) < 1024  # (staged: fewer non-zeros than one round of quads)
+        for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0})):
+            args = torch_args(qq, "f32", create_projection_map(pt, dict(pp), qq["n"]), DEV)
+            f = MatchingSolverDualObjectiveFunction(args, gamma=0.05)
+            lam_q = torch.from_numpy(np.random.default_rng(6).uniform(0, 0.05, qq["m"])).float().to(DEV)
+            before = f.calculate(lam_q, save_primal=True)
+            bg, bx, bo, owned = before.dual_gradient.clone(), before.primal_var.clone(), float(before.dual_objective), f.info()["owned_bytes"]
+            out = f.release_inputs()
+            del args
+            assert out["owned_bytes"] == owned and out["kept_elements"] >= int(qq["colptr"][-1]) and out["kept_elements"] % 4 == 0, out
+            junk = torch.full((1 << 16,), 7.0, device=DEV)  # (whatever takes the freed tensors' place)
+            after = f.calculate(lam_q, save_primal=True)
+            assert torch.equal(after.dual_gradient, bg) and torch.equal(after.primal_var, bx) and float(after.dual_objective) == bo
+            with pytest.raises((RuntimeError, ValueError), match="owns its inputs"):
+                f.values_changed()
+            del junk
     for dn in ("f32", "f64"):
         for pt, pp in (("simplex", {"z": 1.0}), ("box", {"lower": 0.0, "upper": 1.0}), ("simplex_eq", {"z": 1.0})):
             f = _compare(q, create_projection_map(pt, dict(pp), q["n"]), [(pt, pp)], None, 0.05, dn, np.random.default_rng(6).uniform(0, 0.05, q["m"]))
@@ -335,6 +354,60 @@ def test_32_bit_gradient_slabs_are_the_same_exact_sums(monkeypatch):
     q = _random_problem(300, 20_000, 8, seed=5)  # a handle that does not fill the chip
     small = MatchingSolverDualObjectiveFunction(torch_args(q, "f32", create_projection_map("box", {"lower": 0.0, "upper": 1.0}, q["n"]), DEV), gamma=0.02).info()
     assert small["workgroups"] < 128 and small["slab_bytes"] == 8, small
+
+
+def test_32_bit_slabs_are_refused_when_row_scales_differ(monkeypatch):
+    """The grid of the 32-bit slabs is ONE value for the whole matrix, taken from the largest row L1 norm: a row orders of magnitude smaller
+    would collect rounding noise that is large against its own sum (every a x is rounded to the grid before the integer add).  Handles whose
+    rows fail  L1_i / sqrt(count_i) >= kSlabNoise * slab_abound  (api.hip: slab_refresh_bound) therefore keep the 64-bit slabs: here rows
+    scaled 1e-3 .. 1e3 (beyond ~1e7 of spread the 2^50 grid of the 64-bit slabs is itself no longer at fp32 level for the smallest rows).
+    Checked PER ROW -- relative to the row's own sum of |a x|, not to the largest gradient entry -- against the float64 sum of the handle's
+    own fp32 products: the default plan stays within fp32 accumulation error on every row; the forced 32-bit grid (DUALIP_HIP_SLAB32=force)
+    does not, which is why it is refused.  The same pattern with unit row L1 norms (what Jacobi preconditioning produces) passes the gate."""
+    import os
+
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if os.environ.get("DUALIP_HIP_SLAB32") is not None or os.environ.get("DUALIP_HIP_LDS_MODE") in ("grad", "none"):
+        pytest.skip("states the default plan of the 256-wide layout")
+    m, n = 500, 120_000
+    p = _random_problem(m, n, 10, seed=78)
+    scale = 10.0 ** np.linspace(-3, 3, m)
+    np.random.default_rng(5).shuffle(scale)
+    p["a"] = p["a"] * scale[p["rowidx"]]
+    pm = {"box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=range(0, n // 2)), "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=range(n // 2, n))}
+    lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.02, m) / scale).float().to(DEV)  # (duals of rows in other units scale inversely: a lambda stays O(c))
+    gamma = 0.02
+    a32 = p["a"].astype(np.float32)
+
+    def row_errors(env=None):
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=gamma)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        ax = f.calculate_packed(lam, gamma, x_out=f._primal_buffer()).clone()[:m].cpu().numpy()  # A x as the slabs summed it (float64 of the integers)
+        x = f._primal_buffer().clone().cpu().numpy()
+        prod = (a32 * x).astype(np.float64)  # the fp32 products the kernel forms, added up in float64
+        want, mag = np.zeros(m), np.zeros(m)
+        np.add.at(want, p["rowidx"], prod)
+        np.add.at(mag, p["rowidx"], np.abs(prod))
+        live = mag > 0
+        return np.abs(ax - want)[live] / mag[live], scale[live], x, f.info()
+
+    err, sc, x_d, info_d = row_errors()
+    assert info_d["slab_bytes"] == 8 and info_d["slab_rows_ok"] == 0 and info_d["workgroups"] >= 128, info_d  # refused: 64-bit slabs
+    assert err.max() < 1e-6, err.max()  # every row within fp32-level error of ITS OWN magnitude
+    errf, scf, x_f, info_f = row_errors({"DUALIP_HIP_SLAB32": "force"})
+    assert info_f["slab_bytes"] == 4 and info_f["slab_rows_ok"] == 0 and np.array_equal(x_f, x_d), info_f
+    assert errf.max() > 1e-4 and errf.max() > 50 * err.max(), (errf.max(), err.max())  # the small rows on the forced grid: what the gate prevents
+    assert errf[scf >= 1.0].max() < 1e-6  # (the large rows are fine on either grid)
+    l1 = np.zeros(m)
+    np.add.at(l1, p["rowidx"], np.abs(p["a"]))
+    p["a"] = p["a"] / l1[p["rowidx"]]
+    ok = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=gamma).info()
+    assert ok["slab_bytes"] == 4 and ok["slab_rows_ok"] == 1, ok
 
 
 def _skewed_problem(m, n, mean_deg, seed):

@@ -315,6 +315,14 @@ def test_bench_spawns_its_own_ranks():
         assert d["n_gpus"] == 2 and d["config"]["partition"] == partition and d["aux"]["partition"]["kind"] == partition
         coll = d["aux"]["collective"]
         assert coll["backend"] in ("p2p", "p2p-fenced", "rccl", "torch.distributed") and coll["selftest"]["ok"] is True, coll
+        # the line is self-proving: who took part (one record per rank: UUID / PCI address / ordinal / pid), on how many distinct GPUs (one here,
+        # on purpose, and flagged), through which exchange, how far the ranks' kernels were apart, what one exchange bracket cost per rank
+        assert [r["rank"] for r in coll["ranks"]] == [0, 1] and all(r["uuid"] and r["pid"] > 0 and r["device_ordinal"] == 0 for r in coll["ranks"]), coll["ranks"]
+        assert coll["ranks"][0]["pid"] != coll["ranks"][1]["pid"] and coll["distinct_gpus"] == 1 and coll["one_device_mode"] is True
+        assert coll["process_group"] == {"backend": "gloo", "world_size": 2} and coll["state"] == coll["backend"] and coll["degrade_happened"] is False
+        pr = coll["per_rank"]
+        assert len(pr["kernel_avg_ms"]) == 2 and 0 < pr["kernel_avg_ms_min"] <= pr["kernel_avg_ms_max"] and pr["kernel_skew"] >= 0 and sum(pr["nnz"]) == d["config"]["nnz"]
+        assert len(pr["us_per_exchange"]) == 2 and coll["us_per_exchange"] > 0 and coll["world"] == 2
         assert d["aux"]["verified"]["ok_all_ranks"] is True, d["aux"]["verified"]
         r = d["roofline"]
         assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0

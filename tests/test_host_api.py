@@ -418,6 +418,23 @@ def test_build_screens_device_assembly_for_the_half_redefined_scalar_pair():
             assert _build._sgpr_pair_defects(fh.name) == [], name
         finally:
             os.unlink(fh.name)
+    # after the reload: redefining the STALE half (s11, reloaded from s55's lane) heals the pair; redefining the HEALTHY half (s10) does not --
+    # the stale one still rides into the 64-bit operand (round-5 review: the screen used to drop the report on either)
+    still_bad = {
+        "healthy half redefined after the reload": text.replace("\ts_mul_i32 s5, s11, s6\n", "\ts_mul_i32 s5, s11, s6\n\ts_add_i32 s10, s10, 1\n"),
+    }
+    healed = {
+        "stale half redefined after the reload": text.replace("\ts_mul_i32 s5, s11, s6\n", "\ts_mul_i32 s5, s11, s6\n\ts_mov_b32 s11, 0\n"),
+    }
+    for group, want_findings in ((still_bad, 1), (healed, 0)):
+        for name, var in group.items():
+            assert var != text, name
+            with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
+                fh.write(var)
+            try:
+                assert len(_build._sgpr_pair_defects(fh.name)) == want_findings, name
+            finally:
+                os.unlink(fh.name)
 
 
 def test_build_manifest_records_what_the_screens_saw():

@@ -56,7 +56,36 @@ def main():
     C = torch.sparse_csc_tensor(colptr, rowidx, c_cpu, size=inp.A.shape, check_invariants=False)
     host = MatchingInputArgs(A=A, c=C, projection_map=pm, b_vec=b_cpu, equality_mask=None)
     host_bytes = sum(t.numel() * t.element_size() for t in (colptr, rowidx, a_cpu, c_cpu, b_cpu))
-    create_cpu, solve_cpu, res_cpu = solve(host, torch.zeros(m, dtype=torch.float32))
+    from dualip_amd import _hip
+
+    def host_run(mode):
+        """One construction + solve from the host tensors; mode 'native': dl_stage_to_device (pinned, chunked, indices narrowed on the host),
+        'torch': one pageable tensor.to(device) per field (round 5).  Also: device memory in use right after the construction."""
+        os.environ["DUALIP_HOST_STAGING"] = mode
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free0, _ = torch.cuda.mem_get_info()
+        log0 = len(_hip.STAGING_LOG)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = MatchingSolverDualObjectiveFunction(matching_input_args=host, gamma=gamma)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        free1, _ = torch.cuda.mem_get_info()
+        solver = AcceleratedGradientDescent(max_iter=iters, gamma=gamma, initial_step_size=1e-3, max_step_size=1e-1, iteration_callback=False)
+        res = solver.maximize(f, torch.zeros(m, dtype=torch.float32))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        log = _hip.STAGING_LOG[log0:]
+        del f
+        return t1 - t0, t2 - t1, res, free0 - free1, log
+
+    host_run("native")  # (pinned pool, first use)
+    create_cpu, solve_cpu, res_cpu, resident_native, log_native = host_run("native")
+    create_t, solve_t, res_t, resident_torch, _ = host_run("torch")
+    os.environ.pop("DUALIP_HOST_STAGING", None)
+    link_bytes = sum(r["bytes_link"] for r in log_native) + b_cpu.numel() * b_cpu.element_size()
+    stage_call_s = sum(r["seconds"] for r in log_native)
 
     same = bool(torch.equal(res_cpu.dual_val, res_dev.dual_val.cpu())) and res_cpu.dual_val.device.type == "cpu"
     print(json.dumps({
@@ -65,7 +94,15 @@ def main():
         "host_buffers": {"bytes_handed_over": host_bytes, "create_s": round(create_cpu, 4), "solve_s": round(solve_cpu, 4),
                          "staging_s": round(create_cpu - create_dev, 4), "staging_GBps": round(host_bytes / max(create_cpu - create_dev, 1e-9) / 1e9, 2),
                          "iterations_per_s_solve_only": round(iters / solve_cpu, 1),
-                         "iterations_per_s_with_staging": round(iters / (solve_cpu + create_cpu - create_dev), 1)},
+                         "iterations_per_s_with_staging": round(iters / (solve_cpu + create_cpu - create_dev), 1),
+                         "bytes_over_the_link": link_bytes, "link_GBps_inside_the_staging_calls": round(link_bytes / max(stage_call_s, 1e-9) / 1e9, 2),
+                         "staging_calls": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in log_native],
+                         "device_memory_after_construction_bytes": int(resident_native),
+                         "note": "dl_stage_to_device: int64 row indices narrowed to 16 bits on the host (never in HBM as int64), index arrays shared by A and c cross once"},
+        "host_buffers_torch_copy": {"create_s": round(create_t, 4), "staging_s": round(create_t - create_dev, 4), "staging_GBps": round(host_bytes / max(create_t - create_dev, 1e-9) / 1e9, 2),
+                                    "iterations_per_s_with_staging": round(iters / (solve_t + create_t - create_dev), 1), "device_memory_after_construction_bytes": int(resident_torch),
+                                    "same_dual_bits": bool(torch.equal(res_t.dual_val, res_dev.dual_val.cpu())),
+                                    "note": "DUALIP_HOST_STAGING=torch: one pageable tensor.to(device) per field of both CSC tensors (round 5's path)"},
         "same_dual_bits": same,
         "device": torch.cuda.get_device_name(0),
     }))

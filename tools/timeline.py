@@ -38,6 +38,12 @@ print("balance table", [int(f._lib.dl_matching_info(f._handle, 18 + i)) for i in
 print("kernel span us", us[:, 3].max())
 for k, name in enumerate(["start", "prologue_done", "loop_done", "end"]):
     print(f"{name:14s} min {us[:, k].min():8.1f} mean {us[:, k].mean():8.1f} max {us[:, k].max():8.1f}")
+for k, name in ((4, "step derived (fused apply)"), (5, "dual rows staged")):
+    col = tl[:, k]
+    if (col > 0).any():
+        v = (col[col > 0] - t0) / 100.0
+        print(f"{name:34s} min {v.min():8.1f} mean {v.mean():8.1f} max {v.max():8.1f}   (workgroup 0: {(col[0] - t0) / 100.0 if col[0] > 0 else float('nan'):.1f})")
+print("workgroup 0: prologue done %.1f loop done %.1f end %.1f" % (us[0, 1], us[0, 2], us[0, 3]))
 d = us[:, 2] - us[:, 1]
 print("loop dur  min %.1f mean %.1f max %.1f" % (d.min(), d.mean(), d.max()))
 print("prologue dur mean %.1f max %.1f; epilogue dur mean %.1f max %.1f" % ((us[:, 1] - us[:, 0]).mean(), (us[:, 1] - us[:, 0]).max(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
