@@ -159,14 +159,21 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
                 m_rows = int(A.shape[0])
                 rows_src = A.row_indices()
                 narrow = torch.uint16 if m_rows <= 65536 else (torch.int32 if (rows_src.dtype == torch.int64 and m_rows < 2**31) else None)
-                self._host_arrays = {
-                    "colptr": _hip.stage_array(A.ccol_indices(), dev, what="ccol_indices"),
-                    "rows": _hip.stage_array(rows_src, dev, narrow_to=narrow, what="row_indices"),
-                    "row_code": _hip.DL_U16 if narrow == torch.uint16 else (_hip.DL_I32 if (narrow == torch.int32 or rows_src.dtype == torch.int32) else _hip.DL_I64),
-                    "a": _hip.stage_array(A.values(), dev, what="A.values"),
-                    "c": _hip.stage_array(c.values(), dev, what="c.values"),
-                }
-            else:
+                try:
+                    self._host_arrays = {
+                        "colptr": _hip.stage_array(A.ccol_indices(), dev, what="ccol_indices"),
+                        "rows": _hip.stage_array(rows_src, dev, narrow_to=narrow, what="row_indices"),
+                        "row_code": _hip.DL_U16 if narrow == torch.uint16 else (_hip.DL_I32 if (narrow == torch.int32 or rows_src.dtype == torch.int32) else _hip.DL_I64),
+                        "a": _hip.stage_array(A.values(), dev, what="A.values"),
+                        "c": _hip.stage_array(c.values(), dev, what="c.values"),
+                    }
+                except (RuntimeError, MemoryError) as exc:  # (a HIP error, e.g. no pinned memory to be had: the pageable copy still works -- said, not silent;
+                    # a ValueError -- an index that does not fit -- is the caller's and is raised)
+                    import warnings
+
+                    warnings.warn(f"dl_stage_to_device failed ({exc}); staging the host tensors with torch's pageable copy instead")
+                    self._host_arrays = None
+            if self._host_arrays is None:
                 A, c = _hip.stage(A, "A", dev), _hip.stage(c, "c", dev)
         compute_dev = self._host_arrays["a"].device if self._host_arrays is not None else A.values().device
         b_in = matching_input_args.b_vec

