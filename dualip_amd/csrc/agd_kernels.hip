@@ -92,6 +92,7 @@ struct StatsArgs {
     const int32_t* __restrict__ slab_hi;
     const unsigned long long* __restrict__ slab_ovf;
     unsigned long long slab_epoch;
+    const uint8_t* __restrict__ slab_wide;  // [mpad] 1 = a WIDE row: its high words come from every slab in every launch (common.h), or null
     int64_t mpad;
     // hot-rows plan of the matching handle (inv != null): slab column p is the caller's row inv[p]; columns >= m_hot are in `cold`
     const int32_t* __restrict__ inv;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
                 }
             }
             constexpr int kU = 16;  // (256 slabs / 16 slices: every load of a thread in flight at once)
-            auto sum_slabs = [&](auto* slabs) {
+            auto sum_slabs_into = [&](auto* slabs, long long& into) {
                 for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
                     long long v[kU];
 #pragma unroll
@@ -160,12 +161,36 @@ __global__ __launch_bounds__(kStatRows* kStatSlices) void agd_stats_kernel(Stats
                         v[u] = (long long)slabs[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
                     }
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) acc += (w0 + kStatSlices * u < p.n_slabs) ? v[u] : 0ll;
+                    for (int u = 0; u < kU; ++u) into += (w0 + kStatSlices * u < p.n_slabs) ? v[u] : 0ll;
                 }
             };
+            auto sum_slabs = [&](auto* slabs) { sum_slabs_into(slabs, acc); };
             if (p.slab32) {
-                sum_slabs(reinterpret_cast<const int32_t*>(p.partial));
-                if (in_slabs && p.slab_ovf[p.n_slabs] == p.slab_epoch) {  // (uniform, rare: fused_common.h, epilogue)
+                // (the wide flag is requested FIRST and the low words unconditionally behind it: the flag is back before they are, so a wide row's
+                //  high words are on their way while the low words still travel -- read behind them they were one more dependent trip for the block)
+                const bool is_wide = in_slabs && p.slab_wide && p.slab_wide[rc];
+                const int32_t* lo32 = reinterpret_cast<const int32_t*>(p.partial);
+                for (int w0 = ws; in_slabs && w0 < p.n_slabs; w0 += kStatSlices * kU) {
+                    long long v[kU], hw[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int w = w0 + kStatSlices * u;
+                        v[u] = (long long)lo32[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
+                    }
+                    if (is_wide) {
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const int w = w0 + kStatSlices * u;
+                            hw[u] = (long long)p.slab_hi[(int64_t)(w < p.n_slabs ? w : p.n_slabs - 1) * p.mpad + rc];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) hw[u] = 0ll;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) acc += (w0 + kStatSlices * u < p.n_slabs) ? v[u] + hw[u] * 4294967296ll : 0ll;
+                }
+                if (!is_wide && in_slabs && p.slab_ovf[p.n_slabs] == p.slab_epoch) {  // (uniform, rare: fused_common.h, epilogue)
                     for (int w0 = ws; w0 < p.n_slabs; w0 += kStatSlices)
                         if (p.slab_ovf[w0] == p.slab_epoch) acc += (long long)p.slab_hi[(int64_t)w0 * p.mpad + rc] * 4294967296ll;
                 }
@@ -516,6 +541,7 @@ static int agd_stats_typed(dl_agd* s, const StepSource& src, const void* b, hipS
         sa.slab32 = (f && f->slab32) ? 1 : 0;
         sa.slab_hi = f ? f->slab_hi : nullptr;
         sa.slab_ovf = f ? f->slab_ovf : nullptr;
+        sa.slab_wide = (f && f->slab32 && f->n_wide > 0) ? f->slab_wide : nullptr;
         sa.slab_epoch = f ? f->slab_epoch : 0;
         sa.mpad = f ? f->mpad : 0;
         sa.inv = (f && f->m_hot > 0) ? f->row_inv : nullptr;

@@ -55,7 +55,7 @@ int launch_project_dense(int64_t L, int64_t K, int val_dtype, const void* in, vo
 int launch_jacobi(int64_t m, int64_t nnz, const void* rowidx, int idx_dtype, void* a, void* b, void* norms, int val_dtype, hipStream_t st);
 int launch_absmax(int val_dtype, int64_t n, const void* v, unsigned long long* out_bits, hipStream_t st);
 int cold_xcd_selftest(hipStream_t st);
-int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, double* minq_host, hipStream_t st);
+int launch_row_stats(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, float* out_host, int* measured, hipStream_t st);
 size_t fused_lds_bytes(int64_t m, int val_dtype, bool lam, bool grad);
 size_t fused_lds_bytes2(int64_t rows_grad, int64_t rows_lam, int val_dtype);
 int sell_prepare(dl_matching* h, const void* colptr, int idx_dtype, const int32_t* col_proj, const dl_proj_desc* projs, int32_t n_proj, double min_share,
@@ -172,6 +172,9 @@ static void matching_free(dl_matching* h) {
     if (h->projs) (void)hipFree(h->projs);
     if (h->partial) (void)hipFree(h->partial);
     if (h->slab_ovf) (void)hipFree(h->slab_ovf);
+    if (h->slab_wide) (void)hipFree(h->slab_wide);
+    if (h->slab_wide_list) (void)hipFree(h->slab_wide_list);
+    if (h->slab_wide_bits) (void)hipFree(h->slab_wide_bits);
     if (h->partial_scal) (void)hipFree(h->partial_scal);
     if (h->shift_dev) (void)hipFree(h->shift_dev);
     if (h->absmax_dev) (void)hipFree(h->absmax_dev);
@@ -354,31 +357,82 @@ extern "C" {
 const char* dl_last_error_string(void) { return g_err; }
 int dl_version(void) { return 302; }  // ABI version: _hip.py ABI_VERSION must agree
 
-// 32-bit slabs: what a workgroup's share of one row is expected to stay below, as a sum of |a| -- kSlabHeadroom mean shares of the largest row
-// L1 norm of A (deal-invariant: the grid, and with it every rounded sum, does not depend on who walks which tile), at least one max |a|.
+// 32-bit slabs: the fixed-point grid and the list of WIDE rows (common.h).
 //
-// THE GRID MUST BE FINE ENOUGH FOR EVERY ROW, not only for the largest (round-5 review).  Every a x is rounded to the grid before its integer
-// add; the grid is ONE value for the whole matrix -- step <= slab_abound xmax 2^-29 -- so a row far smaller than the largest collects rounding
-// noise that is large against ITS sum: count_i roundings, RMS step sqrt(count_i / 12).  The reference adds such a row in fp32 (scatter_add_,
-// sparse_utils.py:236-243): relative to the row's own L1 norm its error is some 2^-24 sqrt(count_i).  The 32-bit slabs are therefore only taken
-// when, for EVERY row with a non-zero,      step sqrt(count_i / 12) <= 2^-18 L1_i xmax      i.e.   L1_i / sqrt(count_i) >= kSlabNoise slab_abound
-// -- the rounding a row collects stays below 2^-18 of its own L1 norm (times the bound of x), inside what fp32 accumulation of a few hundred
-// terms gives; otherwise the handle keeps the 64-bit slabs (2^50 grid: 2^20 finer).  Row scales that differ by orders of magnitude -- the
-// benchmark generator's log-normal destinations at >= 10M entities, any un-preconditioned matrix with rows in different units -- fail it;
-// Jacobi-preconditioned matrices (unit row norms) and the 1M-entity configuration pass.  dl_matching_info(h, 2010): 1 = gate passed.
-constexpr double kSlabNoise = 0.000140953;  // 2^-29 * 2^18 / sqrt(12)
+// Every a x is rounded to ONE grid before its integer add -- step <= slab_abound xmax 2^-29 -- and a workgroup flushes the low 32-bit words of its
+// sums.  Round 5 took the grid from the LARGEST row (slab_abound = kSlabHeadroom mean workgroup shares of the largest row L1 norm, so that every
+// share fits 32 bits): rows far smaller than the largest then collect rounding noise that is large against THEIR sums -- count_i roundings, RMS
+// step sqrt(count_i / 12) -- where the reference's fp32 scatter_add_ (sparse_utils.py:236-243) is accurate relative to each row (round-5 review).
+// Round 6 takes the grid from the row that needs the FINEST one:
+//      step sqrt(count_i / 12) <= 2^-20 L1_i xmax   for EVERY row with a non-zero value
+// (the rounding a row collects stays below 2^-20 = 1e-6 of its own L1 norm times the bound of x: what fp32 accumulation of a few hundred terms
+// gives, 2^-24 sqrt(count)), i.e. slab_abound = min over the rows of 2^29 2^-20 sqrt(12 / count_i) L1_i, never above round 5's value.  The rows whose workgroup
+// share may then NOT fit 32 bits -- min(L1_i, max(kSlabHeadroom L1_i / workgroups, max_i |a|)) > slab_abound: the few largest rows -- are WIDE:
+// every workgroup sends their high words in every launch (a static list; the dynamic path -- a workgroup some OTHER share of which overflows
+// sends all its high words, stamped with the launch's epoch -- remains).  The integer sums stay exact and deal-invariant either way; only
+// traffic depends on the list.  The handle keeps 64-bit slabs instead when more than one row in sixteen would be wide (nothing left to win: row
+// scales spread over many orders of magnitude), when an element would not fit the 2^51 of the float -> fixed conversion on that grid, or when the
+// rows could not be measured.  dl_matching_info(h, 2010) = 1: the criterion holds; (h, 2011): wide rows.
+// DUALIP_HIP_SLAB32=force: round 5's grid whatever the rows (A/B of the criterion, tests); =tiny: a grid on which every share overflows.
 static int slab_refresh_bound(dl_matching* h, hipStream_t st) {
-    double l1 = -1.0, minq = -1.0;
-    int rc = launch_row_l1_max(h->nnz, h->rowidx, h->row_bytes, static_cast<const float*>(h->a), h->m, &l1, &minq, st);
+    const double n_wg = (double)(h->n_wg > 0 ? h->n_wg : 1);
+    std::vector<float> rs(3 * (size_t)(h->m > 0 ? h->m : 1));
+    int measured = 0;
+    int rc = launch_row_stats(h->nnz, h->rowidx, h->row_bytes, static_cast<const float*>(h->a), h->m, rs.data(), &measured, st);
     if (rc) return rc;
-    const bool measured = l1 >= 0.0;
-    if (l1 < 0.0) l1 = h->amax * (double)(h->row_count_max > 0 ? h->row_count_max : 1);  // (rows beyond the LDS table: the count-based bound)
-    h->slab_abound = std::max(h->amax, kSlabHeadroom * l1 / (double)(h->n_wg > 0 ? h->n_wg : 1));
-    h->slab_minq = minq;
     const char* se = plan_env("DUALIP_HIP_SLAB32");
-    const bool forced = se && (se[0] == 'f' || se[0] == 't');  // "force": the grid whatever the rows (A/B of the gate, the overflow tests); "tiny": below
-    h->slab_rows_ok = measured && minq >= kSlabNoise * h->slab_abound;
-    if (!h->slab_rows_ok && !forced) h->slab32 = false;  // (64-bit slabs from here on: the allocation is sized for them; never switched back on)
+    const bool forced = se && (se[0] == 'f' || se[0] == 't');
+    double l1max = 0.0, need = INFINITY;
+    if (measured) {
+        for (int64_t i = 0; i < h->m; ++i) {
+            const double l1 = rs[(size_t)i], cnt = rs[(size_t)(h->m + i)];
+            l1max = std::max(l1max, l1);
+            if (cnt > 0.0 && l1 > 0.0) need = std::min(need, 512.0 * std::sqrt(12.0 / cnt) * l1);  // 2^29 * 2^-20 = 2^9
+        }
+    } else {
+        l1max = h->amax * (double)(h->row_count_max > 0 ? h->row_count_max : 1);  // (rows beyond the LDS table: the count-based bound)
+    }
+    const double coarse = std::max(h->amax, kSlabHeadroom * l1max / n_wg);  // round 5's grid: every share fits
+    h->n_wide = 0;
+    if (forced || !measured) {
+        h->slab_abound = coarse;
+        h->slab_rows_ok = measured && need >= coarse;
+        if (!forced) h->slab32 = false;  // (not measured: no criterion, no 32-bit slabs)
+    } else {
+        double ab = std::min(coarse, need);
+        const double floor_el = h->amax * ldexp(1.0, -19);  // an element a x <= amax xmax must stay below 2^50 grid units (fused_common.h: to_fixed)
+        h->slab_rows_ok = ab >= floor_el;
+        ab = std::max(ab, floor_el);
+        std::vector<uint8_t> wide((size_t)(h->mpad > 0 ? h->mpad : 1), 0);
+        std::vector<int32_t> list;
+        for (int64_t i = 0; i < h->m; ++i) {
+            const double l1 = rs[(size_t)i], mx = rs[(size_t)(2 * h->m + i)];
+            if (std::min(l1, std::max(kSlabHeadroom * l1 / n_wg, mx)) > ab) {
+                wide[(size_t)i] = 1;
+                list.push_back((int32_t)i);
+            }
+        }
+        if (!h->slab_rows_ok || (int64_t)list.size() * 16 > h->m || h->m > 32 * (int64_t)kFusedThreads) {
+            h->slab32 = false;  // (64-bit slabs from here on: the allocation is sized for them; never switched back on)
+            h->slab_rows_ok = false;
+            h->slab_abound = coarse;
+        } else {
+            h->slab_abound = ab;
+            h->n_wide = (int32_t)list.size();
+            if (!h->slab_wide) {
+                int rcw = owned_malloc(h, (void**)&h->slab_wide, wide.size());
+                if (!rcw) rcw = owned_malloc(h, (void**)&h->slab_wide_list, sizeof(int32_t) * wide.size());
+                if (!rcw) rcw = owned_malloc(h, (void**)&h->slab_wide_bits, sizeof(uint32_t) * kFusedThreads);
+                if (rcw) return rcw;
+            }
+            std::vector<uint32_t> bits((size_t)kFusedThreads, 0u);
+            for (int32_t i : list) bits[(size_t)(i % kFusedThreads)] |= 1u << ((i / kFusedThreads) & 31);
+            DL_HIP(hipMemcpyAsync(h->slab_wide_bits, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice, st));
+            DL_HIP(hipMemcpyAsync(h->slab_wide, wide.data(), wide.size(), hipMemcpyHostToDevice, st));
+            if (!list.empty()) DL_HIP(hipMemcpyAsync(h->slab_wide_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, st));
+            DL_HIP(hipStreamSynchronize(st));  // (host vectors)
+        }
+    }
     if (se && se[0] == 't') h->slab_abound = h->amax / 256.0;  // "tiny": the test hook -- every workgroup's shares overflow
     return 0;
 }
@@ -1041,6 +1095,7 @@ int64_t dl_matching_info(const dl_matching* h, int what) {
             return k;
         }
         case 2100: return (int64_t)h->switches;
+        case 2011: return h->slab32 ? h->n_wide : 0;  // 32-bit slabs: rows whose high words travel in every launch (the grid is the finest row's)
         case 2010: return h->slab_rows_ok ? 1 : 0;  // 32-bit slabs: the grid is fine enough for every row (slab_refresh_bound); 0 with slab_bytes 8 = refused for that
         case 2009: return h->cold_per_xcd ? 1 : 0;  // hot-rows plan: one cold-row accumulator array per XCD (self-checked at creation) / 0: one shared array
         case 2101:

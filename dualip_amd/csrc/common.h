@@ -147,8 +147,14 @@ struct dl_matching {
     bool slab32 = false;
     double slab_abound = 0.0;                  // sum of |a| a workgroup's share of one row is expected to stay below: kSlabHeadroom mean shares of the
                                                // largest row L1 norm of A (a deal-invariant property of the matrix), at least max |a|
-    double slab_minq = -1.0;                   // min over the rows of L1_i / sqrt(count_i) (api.hip: slab_refresh_bound), -1: not measured
-    bool slab_rows_ok = false;                 // ... and whether the one grid is fine enough for every row (else the handle keeps 64-bit slabs)
+    bool slab_rows_ok = false;                 // the grid is fine enough for EVERY row (api.hip: slab_refresh_bound); else the handle keeps 64-bit slabs
+    // WIDE rows (round 6): the grid is taken from the row that needs the FINEST one (so every row's rounding noise stays below 2^-20 of its own L1
+    // norm), and the rows whose workgroup shares do not fit 32 bits on that grid -- the few largest -- send their high words from every
+    // workgroup in every launch: a static list decided at creation, beside the dynamic overflow path (which remains for everything else).
+    uint8_t* slab_wide = nullptr;              // owned, [mpad]: 1 = wide row
+    int32_t* slab_wide_list = nullptr;         // owned, [mpad]: the wide rows' indices, n_wide of them
+    uint32_t* slab_wide_bits = nullptr;        // owned, [1024]: bit u of word t = row t + 1024 u is wide (what the fused kernel's epilogue reads: one word per thread)
+    int32_t n_wide = 0;
     int32_t* slab_hi = nullptr;                // the second half of `partial`, [n_wg][mpad]: high words (written by a workgroup only in a launch where it overflowed)
     unsigned long long* slab_ovf = nullptr;    // owned, [n_wg + 1]: epoch of the last launch in which workgroup w overflowed; [n_wg]: any workgroup
     unsigned long long slab_epoch = 0;         // fused launches of this handle so far

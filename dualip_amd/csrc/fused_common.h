@@ -34,6 +34,9 @@ struct FusedArgs {
     int32_t* slab_hi;                    //    [n_wg][mpad] high words
     unsigned long long* slab_ovf;        //    [n_wg + 1] epochs (common.h)
     unsigned long long slab_epoch;       //    this launch's
+    const uint32_t* slab_wide_bits;      //    [1024] bit u of word t: row t + 1024 u is a WIDE row (common.h: its high word is sent in every launch and is no overflow); or null
+    const int32_t* slab_wide_list;       //    the wide rows' indices ...
+    int32_t n_wide;                      //    ... and their number
     int32_t n_proj;
     uint32_t n_tiles;   // layout 4: window tiles of the launch (cyclic schedule); descriptor n_tiles is all-zero
     uint32_t n_long;    // layout 4: single-column tiles, descriptors n_tiles + 1 ... n_tiles + n_long
@@ -707,11 +710,31 @@ __device__ __forceinline__ void fused_epilogue(const FusedArgs<T>& g, const WgCt
                     const FusedArgs<T>& ga = REREAD ? kernarg_args(g) : g;
                     const int64_t m_lds = ga.m_hot > 0 ? ga.m_hot : ga.m;
                     int32_t* slab = reinterpret_cast<int32_t*>(ga.partial) + (int64_t)wg * ga.mpad;
-                    for (int64_t i = tid; i < m_lds; i += kFusedThreads) {
-                        const long long v = w.grad_s[i];
-                        const int32_t lo = (int32_t)v;
-                        slab[i] = lo;
-                        ovf |= (long long)lo != v;
+                    // wide rows (common.h): ONE word per thread says which of ITS rows -- tid, tid + 1024, ... -- are wide (bit u: row tid + 1024 u); it is
+                    // requested before the flush and used after it, so the flush of the low words runs while it travels.  (A flag byte per row read
+                    // inside the loop cost a memory round trip at the end of every launch: +1.3 us; thirteen byte loads up front were no better.)
+                    const uint32_t* wbits = kernarg_args(g).slab_wide_bits;  // (null: no wide rows)
+                    const bool wide = wbits != nullptr;
+                    const uint32_t wmask = wide ? wbits[tid] : 0u;
+                    uint32_t mism = 0u;
+                    {
+                        int u = 0;
+                        for (int64_t i = tid; i < m_lds; i += kFusedThreads, ++u) {  // (u < 32: a gradient that fits the LDS has < 13 312 rows)
+                            const long long v = w.grad_s[i];
+                            const int32_t lo = (int32_t)v;
+                            slab[i] = lo;
+                            mism |= ((long long)lo != v ? 1u : 0u) << (u & 31);
+                        }
+                    }
+                    ovf = (mism & ~wmask) != 0u;  // (a wide row's high word travels anyway, below)
+                    if (wide) {  // the wide rows' high words: a few dozen rows, every launch
+                        const FusedArgs<T>& gw = kernarg_args(g);
+                        int32_t* hi = gw.slab_hi + (int64_t)wg * gw.mpad;
+                        for (int32_t j = tid; j < gw.n_wide; j += kFusedThreads) {
+                            const int32_t i = gw.slab_wide_list[j];
+                            const long long v = w.grad_s[i];
+                            hi[i] = (int32_t)((v - (long long)(int32_t)v) / 4294967296ll);
+                        }
                     }
                 }
                 // (workgroup-wide OR through the scratch word zeroed above -- __syncthreads_or brings 256 bytes of static LDS of its own, which the

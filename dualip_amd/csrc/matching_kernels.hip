@@ -28,7 +28,8 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
                                                                       double* __restrict__ packed, const int32_t* __restrict__ inv, int64_t m_hot,
                                                                       const long long* __restrict__ cold, const double* __restrict__ dense, PushArgs push,
                                                                       int accumulate, int slab32, const int32_t* __restrict__ slab_hi,
-                                                                      const unsigned long long* __restrict__ slab_ovf, unsigned long long slab_epoch) {
+                                                                      const unsigned long long* __restrict__ slab_ovf, unsigned long long slab_epoch,
+                                                                      const uint8_t* __restrict__ slab_wide) {
     unsigned long long pushed_h = 0ull;  // hashes of what this thread pushed (comm.h: the payload checksum the flag will carry)
     auto emit = [&](int64_t i, double v) {
         if constexpr (MODE == 0) packed[i] = v;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
         }
         // latency bound: eight slabs are in flight before the first is added (slabs past the end re-read the last one)
         constexpr int kU = 8, kStride = kRedThreads / kRedRows;
-        auto sum_slabs = [&](auto* slabs) {  // (int32 slabs of handles with slab32, common.h; else int64)
+        auto sum_slabs_into = [&](auto* slabs, long long& into) {  // (int32 slabs of handles with slab32, common.h; else int64)
             for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
                 long long v[kU];
 #pragma unroll
@@ -60,12 +61,34 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const long
                     v[u] = (long long)slabs[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
                 }
 #pragma unroll
-                for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
+                for (int u = 0; u < kU; ++u) into += (w0 + kStride * u < n_slabs) ? v[u] : 0ll;
             }
         };
+        auto sum_slabs = [&](auto* slabs) { sum_slabs_into(slabs, acc); };
         if (slab32) {
-            sum_slabs(reinterpret_cast<const int32_t*>(partial));
-            if (in_slabs && slab_ovf[n_slabs] == slab_epoch) {  // (uniform, rare) some workgroup's shares left 32 bits in this launch: their high words
+            const bool is_wide = in_slabs && slab_wide && slab_wide[rc];  // (requested first: agd_kernels.hip, the statistics kernel)
+            const int32_t* lo32 = reinterpret_cast<const int32_t*>(partial);
+            for (int w0 = ws; in_slabs && w0 < n_slabs; w0 += kStride * kU) {
+                long long v[kU], hw[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int w = w0 + kStride * u;
+                    v[u] = (long long)lo32[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+                }
+                if (is_wide) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int w = w0 + kStride * u;
+                        hw[u] = (long long)slab_hi[(int64_t)(w < n_slabs ? w : n_slabs - 1) * mpad + rc];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) hw[u] = 0ll;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) acc += (w0 + kStride * u < n_slabs) ? v[u] + hw[u] * 4294967296ll : 0ll;
+            }
+            if (!is_wide && in_slabs && slab_ovf[n_slabs] == slab_epoch) {  // (uniform, rare) some workgroup's shares left 32 bits in this launch: their high words
                 for (int w0 = ws; w0 < n_slabs; w0 += kStride)
                     if (slab_ovf[w0] == slab_epoch) acc += (long long)slab_hi[(int64_t)w0 * mpad + rc] * 4294967296ll;
             }
@@ -180,12 +203,12 @@ int cold_xcd_selftest(hipStream_t st) {
     return ok ? 1 : 0;
 }
 
-// max_i sum_{k in row i} |a_k| (one-off, for handles with 32-bit slabs: the fixed-point grid is taken from it -- common.h: slab32) and
-// min_i L1_i / sqrt(count_i) over the non-empty rows (what decides whether that grid is fine enough for EVERY row: api.hip, slab_refresh_bound).
-// Estimates, so float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused
-// kernel's LDS), flushed with float atomics, reduced to one maximum / minimum (floats >= 0 order like their bit patterns).
+// Per-row statistics of the fp32 values `a` (one-off, for handles with 32-bit slabs -- common.h: slab32 -- whose fixed-point grid and list of
+// WIDE rows are decided from them, api.hip: slab_refresh_bound): L1 norm, number of non-zero values, largest |a|.  Estimates feeding bounds, so
+// float sums are plenty; accumulated per workgroup in LDS (rows <= kRowL1Max: every handle whose whole gradient fits the fused kernel's LDS),
+// flushed with float atomics (floats >= 0 order like their bit patterns: the maximum is an integer atomicMax).
 constexpr int kRowL1Max = 16384;
-template <class RowT, bool COUNT>
+template <class RowT, int WHAT>  // WHAT: 0 sum |a|, 1 count of non-zero values, 2 max |a|
 __global__ __launch_bounds__(1024) void row_l1_kernel(int64_t nnz, const RowT* __restrict__ rows, const float* __restrict__ a, int m, float* __restrict__ sums) {
     __shared__ float acc[kRowL1Max];
     for (int i = threadIdx.x; i < m; i += blockDim.x) acc[i] = 0.f;
@@ -193,58 +216,43 @@ __global__ __launch_bounds__(1024) void row_l1_kernel(int64_t nnz, const RowT* _
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
         const float v = fabsf(a[k]);
-        atomicAdd(&acc[(uint32_t)rows[k]], COUNT ? (v != 0.f ? 1.f : 0.f) : v);  // (counts: exact in float up to 2^24 per row; slab32 handles have <= 65 536)
+        if (WHAT == 2) atomicMax(reinterpret_cast<unsigned int*>(&acc[(uint32_t)rows[k]]), __float_as_uint(v));
+        else atomicAdd(&acc[(uint32_t)rows[k]], WHAT == 1 ? (v != 0.f ? 1.f : 0.f) : v);  // (counts: exact in float up to 2^24 per row; slab32 handles have <= 65 536)
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < m; i += blockDim.x)
-        if (acc[i] != 0.f) atomicAdd(&sums[i], acc[i]);
-}
-__global__ void row_l1_max_kernel(int m, const float* __restrict__ sums, const float* __restrict__ counts, unsigned int* __restrict__ out_bits) {
-    float mx = 0.f, mq = INFINITY;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        mx = fmaxf(mx, sums[i]);
-        if (counts[i] > 0.f && sums[i] > 0.f) mq = fminf(mq, sums[i] / sqrtf(counts[i]));
-    }
-    mx = wave_allreduce(mx, OpMax());
-    mq = -wave_allreduce(-mq, OpMax());
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(out_bits, __float_as_uint(mx));
-        atomicMin(out_bits + 1, __float_as_uint(mq));
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        if (acc[i] == 0.f) continue;
+        if (WHAT == 2) atomicMax(reinterpret_cast<unsigned int*>(&sums[i]), __float_as_uint(acc[i]));
+        else atomicAdd(&sums[i], acc[i]);
     }
 }
-// *out_host = the largest row L1 norm of the fp32 values `a` (rows: the handle's re-encoded indices); -1 when the rows do not fit the LDS table.
-// *minq_host = the smallest L1_i / sqrt(non-zero count_i) over the rows that have a non-zero value (+inf when there is none).
-int launch_row_l1_max(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, double* out_host, double* minq_host, hipStream_t st) {
-    *out_host = -1.0;
-    *minq_host = -1.0;
+// out_host[0 .. m) = row L1 norms, [m .. 2m) = counts of non-zero values, [2m .. 3m) = row maxima of |a| (rows: the handle's re-encoded indices).
+// *measured = 0 when the rows do not fit the LDS table (nothing written).
+int launch_row_stats(int64_t nnz, const void* rows, int row_bytes, const float* a, int64_t m, float* out_host, int* measured, hipStream_t st) {
+    *measured = 0;
     if (m <= 0 || m > kRowL1Max || nnz <= 0) return 0;
-    float* sums = nullptr;  // [m] L1 sums, [m] counts, [2] results
-    DL_HIP(hipMalloc((void**)&sums, sizeof(float) * (2 * (size_t)m + 2)));
-    float* counts = sums + m;
-    unsigned int* res = reinterpret_cast<unsigned int*>(sums + 2 * m);
-    const float init[2] = {0.f, INFINITY};
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)m, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(res, init, sizeof(init), hipMemcpyHostToDevice, st);
+    float* dev = nullptr;
+    DL_HIP(hipMalloc((void**)&dev, sizeof(float) * 3 * (size_t)m));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(float) * 3 * (size_t)m, st);
     if (e == hipSuccess) {
         const int64_t b64 = (nnz + 1023) / 1024;
         const int blocks = (int)(b64 > 256 ? 256 : b64);
         if (row_bytes == 2) {
-            hipLaunchKernelGGL((row_l1_kernel<uint16_t, false>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, sums);
-            hipLaunchKernelGGL((row_l1_kernel<uint16_t, true>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, counts);
+            hipLaunchKernelGGL((row_l1_kernel<uint16_t, 0>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, dev);
+            hipLaunchKernelGGL((row_l1_kernel<uint16_t, 1>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, dev + m);
+            hipLaunchKernelGGL((row_l1_kernel<uint16_t, 2>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint16_t*)rows, a, (int)m, dev + 2 * m);
         } else {
-            hipLaunchKernelGGL((row_l1_kernel<uint32_t, false>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, sums);
-            hipLaunchKernelGGL((row_l1_kernel<uint32_t, true>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, counts);
+            hipLaunchKernelGGL((row_l1_kernel<uint32_t, 0>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, dev);
+            hipLaunchKernelGGL((row_l1_kernel<uint32_t, 1>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, dev + m);
+            hipLaunchKernelGGL((row_l1_kernel<uint32_t, 2>), dim3(blocks), dim3(1024), 0, st, nnz, (const uint32_t*)rows, a, (int)m, dev + 2 * m);
         }
-        hipLaunchKernelGGL(row_l1_max_kernel, dim3(16), dim3(256), 0, st, (int)m, sums, counts, res);
         e = hipGetLastError();
     }
-    float out[2] = {0.f, INFINITY};
-    if (e == hipSuccess) e = hipMemcpyAsync(out, res, sizeof(out), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, dev, sizeof(float) * 3 * (size_t)m, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(sums);
-    if (e != hipSuccess) return hip_fail(e, "row L1 norms");
-    *out_host = (double)out[0];
-    *minq_host = (double)out[1];
+    (void)hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "row statistics");
+    *measured = 1;
     return 0;
 }
 
@@ -555,6 +563,9 @@ static int fused_typed(dl_matching* h, const void* lambda, double gamma, void* x
     args.slab_hi = h->slab_hi;
     args.slab_ovf = h->slab_ovf;
     args.slab_epoch = ++h->slab_epoch;
+    args.slab_wide_bits = (h->slab32 && h->n_wide > 0) ? h->slab_wide_bits : nullptr;
+    args.slab_wide_list = h->slab_wide_list;
+    args.n_wide = h->slab32 ? h->n_wide : 0;
     args.n_proj = h->n_proj;
     args.n_tiles = (uint32_t)h->n_short;
     args.n_long = (uint32_t)(h->n_tiles - h->n_short - h->n_xlong);
@@ -676,7 +687,7 @@ int matching_reduce(dl_matching* h, double* packed, int mode, const PushArgs* pu
     auto kern = mode == 0 ? reduce_partials_kernel<0> : (mode == 1 ? reduce_partials_kernel<1> : reduce_partials_kernel<2>);
     hipLaunchKernelGGL(kern, dim3(blocks + 1), dim3(kRedThreads), 0, st, static_cast<const long long*>(h->partial), h->partial_scal, h->shift_dev, n_slabs,
                        h->n_wg, h->m, h->mpad, packed, h->m_hot > 0 ? h->row_inv : nullptr, h->m_hot, h->cold_grad, h->fair ? h->dense_ax : nullptr, pa,
-                       push_accumulate, h->slab32 ? 1 : 0, h->slab_hi, h->slab_ovf, h->slab_epoch);
+                       push_accumulate, h->slab32 ? 1 : 0, h->slab_hi, h->slab_ovf, h->slab_epoch, h->slab32 && h->n_wide > 0 ? h->slab_wide : nullptr);
     DL_HIP(hipGetLastError());
     return 0;
 }

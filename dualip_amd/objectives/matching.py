@@ -321,6 +321,7 @@ class MatchingSolverDualObjectiveFunction(BaseObjective):
         info["slab_bytes"] = int(self._lib.dl_matching_info(self._handle, 2007))  # per element of the per-workgroup gradient slabs (4: 32-bit fixed point)
         info["cold_per_xcd"] = int(self._lib.dl_matching_info(self._handle, 2009))  # hot-rows plan: per-XCD cold-row accumulators (self-checked) in use
         info["slab_rows_ok"] = int(self._lib.dl_matching_info(self._handle, 2010))  # 1: the one grid of 32-bit slabs is fine enough for every row (0 + slab_bytes 8: refused for that)
+        info["slab_wide_rows"] = int(self._lib.dl_matching_info(self._handle, 2011))  # 32-bit slabs: rows (the few largest) whose high words every workgroup sends in every launch
         info["slab_overflows"] = int(self._lib.dl_matching_info(self._handle, 2008))  # workgroups that sent high words too in the last launch
         mask = int(self._lib.dl_matching_info(self._handle, 2100))  # plan switches honoured at creation (DUALIP_HIP_*)
         info["switches"] = [self._lib.dl_switch_name(i).decode() for i in range(32) if (mask >> i) & 1 and self._lib.dl_switch_name(i)]

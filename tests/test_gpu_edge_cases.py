@@ -410,6 +410,66 @@ def test_32_bit_slabs_are_refused_when_row_scales_differ(monkeypatch):
     assert ok["slab_bytes"] == 4 and ok["slab_rows_ok"] == 1, ok
 
 
+def test_32_bit_slabs_on_the_finest_rows_grid_with_wide_rows(monkeypatch):
+    """Row scales that differ by orders of magnitude but with only a FEW large rows: the grid of the 32-bit slabs is taken from the row that needs
+    the finest one (every row's rounding noise below 2^-20 of its own L1 norm), and the few rows whose workgroup shares do not fit 32 bits on that
+    grid are WIDE -- every workgroup sends their high words in every launch (api.hip: slab_refresh_bound).  Here: 10 rows at scale 1, 480 at 1e-3,
+    10 at 1e-6.  Checked: 32-bit slabs are on with the ten large rows wide and no dynamic overflow; EVERY row -- the 1e-6 ones included -- is within
+    fp32-level error of its own magnitude (round 5's grid, DUALIP_HIP_SLAB32=force, is not); the sums are bit-identical for another deal of the
+    tiles and within fp32 rounding of the 64-bit slabs; a solve logs the same numbers under both deals."""
+    import os
+
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.optimizers.agd import AcceleratedGradientDescent
+    from dualip_amd.projections.base import ProjectionEntry
+
+    if os.environ.get("DUALIP_HIP_SLAB32") is not None or os.environ.get("DUALIP_HIP_LDS_MODE") in ("grad", "none"):
+        pytest.skip("states the default plan of the 256-wide layout")
+    m, n = 500, 120_000
+    p = _random_problem(m, n, 10, seed=79)
+    scale = np.full(m, 1e-3)
+    scale[:10] = 1.0
+    scale[10:20] = 1e-6
+    np.random.default_rng(6).shuffle(scale)
+    p["a"] = p["a"] * scale[p["rowidx"]]
+    p["b"] = p["b"] * scale * 100.0
+    pm = {"box": ProjectionEntry("box", {"lower": 0.0, "upper": 1.0}, indices=range(0, n // 2)), "simplex": ProjectionEntry("simplex", {"z": 1.0}, indices=range(n // 2, n))}
+    lam = torch.from_numpy(np.random.default_rng(3).uniform(0, 0.02, m) / scale).float().to(DEV)
+    gamma = 0.02
+    a32 = p["a"].astype(np.float32)
+    kw = dict(max_iter=30, gamma=gamma, initial_step_size=1e-6, max_step_size=1e-4, iteration_callback=False)
+
+    def run(env=None):
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        f = MatchingSolverDualObjectiveFunction(torch_args(p, "f32", pm, DEV), gamma=gamma)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        ax = f.calculate_packed(lam, gamma, x_out=f._primal_buffer()).clone()[:m].cpu().numpy()
+        x = f._primal_buffer().clone().cpu().numpy()
+        info = f.info()
+        prod = (a32 * x).astype(np.float64)
+        want, mag = np.zeros(m), np.zeros(m)
+        np.add.at(want, p["rowidx"], prod)
+        np.add.at(mag, p["rowidx"], np.abs(prod))
+        live = mag > 0
+        res = AcceleratedGradientDescent(**kw).maximize(f, torch.zeros(m, dtype=torch.float32, device=DEV))
+        return ax, np.abs(ax - want)[live] / mag[live], scale[live], x, info, list(res.dual_objective_log), res.dual_val.clone()
+
+    ax, err, sc, x, info, log, dual = run()
+    assert info["slab_bytes"] == 4 and info["slab_rows_ok"] == 1 and info["slab_wide_rows"] == 10 and info["slab_overflows"] == 0, info
+    # every row, the tiny ones included: the criterion is noise <= 2^-20 of L1_i * xmax; relative to the row's sum of |a x| (x well below its bound) a few times that
+    assert err.max() < 2e-5 and err[sc >= 1e-3].max() < 1e-6, (err.max(), err[sc >= 1e-3].max())
+    ax_b, err_b, _, x_b, info_b, log_b, dual_b = run({"DUALIP_HIP_XCD_BALANCE": "0", "DUALIP_HIP_SELL_BALANCE": "0"})  # another deal: the same integers
+    assert np.array_equal(ax, ax_b) and np.array_equal(x, x_b) and log == log_b and torch.equal(dual, dual_b) and info_b["slab_wide_rows"] == 10
+    ax64, err64, _, x64, info64, log64, dual64 = run({"DUALIP_HIP_SLAB32": "0"})
+    assert info64["slab_bytes"] == 8 and np.array_equal(x, x64)
+    assert relerr(ax, ax64) < 2e-7 and relerr(log, log64) < 1e-6
+    axf, errf, scf, xf, info_f, *_ = run({"DUALIP_HIP_SLAB32": "force"})  # round 5's grid, from the largest row
+    assert info_f["slab_bytes"] == 4 and info_f["slab_wide_rows"] == 0 and info_f["slab_rows_ok"] == 0
+    assert errf[scf < 1e-4].max() > 5e-4 and errf[scf < 1e-4].max() > 20 * err[sc < 1e-4].max() and errf[scf >= 1.0].max() < 1e-6, (errf[scf < 1e-4].max(), err[sc < 1e-4].max())
+
+
 def _skewed_problem(m, n, mean_deg, seed):
     """Rows drawn from a heavy-tailed popularity law (a few destinations get most of the edges)."""
     rng = np.random.default_rng(seed)
