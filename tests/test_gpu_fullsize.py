@@ -77,6 +77,43 @@ def test_ten_million_entities_through_the_device_loop(kind):
     assert info["layout"] == 4 and info["slices"] > 0  # the benchmark's kernel plan, not a fallback
 
 
+def test_hundred_million_entities_headline_under_the_checker():
+    """BASELINE config 4's single-GPU size INSIDE the driver-run suite (round-5 review): 100M entities x 10k destinations, mixed box / simplex map,
+    generated on the device, 30 iterations of the device loop, then the checker bench.py runs at this size (benchmark/verify.py: oracle slabs of 5000
+    columns inside both projection blocks, straddling their boundary and at the END of the arrays -- non-zero offsets up to 10^9 -- A x, c.x and
+    sum x^2 recomputed in float64 from the primal, the sharded route against the single objective).  About half a minute and 25 GB of HBM."""
+    from benchmark.synthetic import CHUNK_COLS, generate_matching_problem
+    from dualip_amd.objectives.matching import MatchingSolverDualObjectiveFunction
+    from dualip_amd.projections import create_projection_map
+    from tests.helpers import verify_at_size
+
+    if os.environ.get("DUALIP_HIP_SELL") == "0":
+        pytest.skip("asserts the default kernel plan (256-wide layout with slices)")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs 60 GB of free device memory")
+    n = 100_000_000
+    prob = generate_matching_problem(n, M, 1e-3, seed=42, device=DEV, dtype=torch.float32)
+    inp = prob["input_args"]
+    half = (n // 2) // CHUNK_COLS * CHUNK_COLS
+    pm = {**create_projection_map("box", {"lower": 0.0, "upper": 1.0}, None, indices=range(0, half)), **create_projection_map("simplex", {"z": 1.0}, None, indices=range(half, n))}
+    inp.projection_map = pm
+    assert prob["nnz"] > 990_000_000
+    f = MatchingSolverDualObjectiveFunction(inp, 1e-3)
+    info = f.info()
+    assert info["layout"] == 4 and info["slices"] > 0 and info["workgroups"] == 256 and info["lambda_in_lds"] == 1 and info["grad_in_lds"] == 1, info
+    res, gamma_end = _solve(f, 30, 1e-3, False)
+    log = np.array(res.dual_objective_log)
+    assert len(log) == 30 and np.isfinite(log).all() and log[-1] > log[5]
+    out = verify_at_size("f32", gamma_end, inp, pm, f, f, res.dual_val, device=DEV)
+    bad = [c for c in out["checks"] if not c["ok"]]
+    assert out["ok"] and not bad, bad
+    names = " ".join(c["name"] for c in out["checks"])
+    assert "inside entry" in names and "straddling" in names and "last columns" in names and "recomputed from the primal" in names and "sharded route" in names
+    del f, inp, prob
+    torch.cuda.empty_cache()
+
+
 def test_logs_are_bit_identical_run_to_run_with_the_adaptive_deal():
     """Two independent handles, two solves each, of the 10M mixed problem: the deal of the window tiles adapts to wall-clock stamps
     (it does at this size: >= 40 rounds per wavefront), yet every logged dual objective, step size and the final duals agree bit
