@@ -517,13 +517,58 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     // before deriving the step (twelve per thread in registers) made the launch 12 us longer.  Kept as a tested route, not the default.
     const bool applying = g.do_apply != 0;
     T a_stp = (T)0, a_bb = (T)0, a_omb = (T)0;
+    int64_t applied_rows = 0;  // rows [0, applied_rows) of the new iterate are staged by the block below
     if (applying) {
+        // Round 6: ONE wavefront derives the step while the other fifteen have the rows in flight.  Before, every wavefront derived it
+        // (157 x 6 partial statistics each) and only then requested its rows: two dependent trips, the second queued behind sixteen copies of the
+        // first -- wavefront 0 had its rows at 6.7 us, wavefront 15 at 8.9 us of a launch whose plain form has them at 2.8 / 3.4 us (tools/timeline.py).
+        // Wavefront 0 takes the step (and, in workgroup 0, the state and the log row); wavefronts 1 .. 15 take the rows, 960 at a time.
         const ApplyArgs<T>& ap = kernarg_args(g).apply;
-        a_stp = (T)agd_step_scalars(ap, lane, wg == 0, tid);
-        if (kernarg_args(g).timeline && tid == 0) kernarg_args(g).timeline[(size_t)kTimelineSlots * (size_t)wg + 4] = wall_clock64();
+        constexpr int kRowThreads = kFusedThreads - 64;
+        constexpr int kUA = 14;  // 14 x 960 = 13 440 rows in one round trip: more than a gradient that fits the LDS has
         const float bt = ap.beta[ap.iter - 1];
+        T xx[kUA], gg[kUA], yy[kUA];
+        bool eq[kUA];
+        const int rt = tid - 64;
+        if (wave != 0) {
+#pragma unroll
+            for (int u = 0; u < kUA; ++u) {
+                const int64_t i = (int64_t)rt + (int64_t)u * kRowThreads;
+                const int64_t ic = i < g.m ? i : g.m - 1;
+                xx[u] = ap.x[ic];
+                gg[u] = ap.g_new[ic];
+                yy[u] = ap.y[ic];
+                eq[u] = ap.eq_mask && ap.eq_mask[ic];
+            }
+        } else {
+            const double st = agd_step_scalars(ap, lane, wg == 0, tid);
+            if (lane == 0) w.red_s[16] = st;
+            if (kernarg_args(g).timeline && tid == 0) kernarg_args(g).timeline[(size_t)kTimelineSlots * (size_t)wg + 4] = wall_clock64();
+        }
+        __syncthreads();
+        a_stp = (T)w.red_s[16];
         a_bb = (T)bt;
         a_omb = (T)(float)(1.0f - bt);
+        applied_rows = (int64_t)kUA * kRowThreads < g.m ? (int64_t)kUA * kRowThreads : g.m;
+        if (wave != 0) {
+#pragma unroll
+            for (int u = 0; u < kUA; ++u) {
+                const int64_t i = (int64_t)rt + (int64_t)u * kRowThreads;
+                T yn, xn;
+                agd_update_values(xx[u], gg[u], yy[u], eq[u], a_stp, a_bb, a_omb, yn, xn);
+                if (i < g.m) {
+                    if (wg == 0) {  // one workgroup stores the new iterate for the launches that follow
+                        ap.y_new[i] = yn;
+                        ap.x_next[i] = xn;
+                    }
+                    if constexpr (LAM_LDS) {
+                        if (i < (g.m_hot > 0 ? g.m_lam : g.m)) w.lam_s[i] = (T)(w.s * xn);
+                    }
+                    const double al = fabs((double)xn);
+                    lmax = al > lmax ? al : lmax;
+                }
+            }
+        }
     }
     // Rows to pull: all of them when their maximum matters (projections that do not bound x take their |v| bound from max |lambda|) or
     // when this launch applies the optimiser step (workgroup 0 stores every row of the new iterate); otherwise only the rows that live
@@ -555,6 +600,7 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
             }
             pulled = (int64_t)kW * kFusedThreads;
         }
+        if (applying) pulled = applied_rows;  // (longer dual vectors: the rest, by every thread, with the step in hand)
         for (int64_t i0 = pulled + tid; i0 < m_pull; i0 += (int64_t)kU * kFusedThreads) {
             T l[kU];
             if (!applying) {
