@@ -1,7 +1,8 @@
 // agd_step.h -- the arithmetic of one accelerated-gradient step (agd.py:163-187; agd_utils.py:12-89), shared by the stand-alone
 // apply kernel (agd_kernels.hip) and by the fused matching pass, which can run it in the prologue of the NEXT iteration's launch
 // (every workgroup stages the whole dual vector anyway, so it can form the new iterate itself instead of reading what a separate
-// launch wrote: one launch and one boundary less per iteration -- measured neutral, see fused_common.h, hence opt-in).
+// launch wrote: one launch and one boundary less per iteration -- on for handles below about 19M entities, see fused_common.h and
+// matching_kernels.hip: matching_can_fuse_apply).
 #pragma once
 #include "common.h"
 #include "wave.h"

@@ -509,12 +509,11 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
         pd_early.p1 = g.projs[tid].p1;
     }
     double lmax = 0.0;
-    // The optimiser step of the previous iteration, if this launch carries it (agd_step.h; opt-in, DUALIP_HIP_FUSE_APPLY=1): every
-    // wavefront derives the same step and every workgroup forms the new iterate itself.  Measured on one box at the per-rank size
-    // of an 8-GPU run (12.5M entities): the launch grows by 7 us -- the stats partials, then the rows, are two dependent memory
-    // latencies at the head of a launch whose CUs have nothing else to do yet -- which is what the separate apply launch and its
-    // boundary cost: 0.2317 / 0.2333 / 0.2314 ms per iteration with it, 0.2323 / 0.2313 / 0.2302 without.  Requesting the rows
-    // before deriving the step (twelve per thread in registers) made the launch 12 us longer.  Kept as a tested route, not the default.
+    // The optimiser step of the previous iteration, if this launch carries it (agd_step.h; matching_kernels.hip: matching_can_fuse_apply decides):
+    // every workgroup forms the new iterate itself instead of reading what a separate apply launch wrote -- one launch and one boundary less per
+    // iteration, against a longer head of this launch.  Rounds 3-5: every wavefront derived the step and then requested its rows (two dependent
+    // trips, +5.4 us of head): worth it only for small handles.  Requesting the rows before deriving the step IN EVERY WAVEFRONT (twelve per thread in
+    // registers next to the step's 48) had made the launch 12 us longer.  Round 6, below: the two trips run side by side in different wavefronts.
     const bool applying = g.do_apply != 0;
     T a_stp = (T)0, a_bb = (T)0, a_omb = (T)0;
     int64_t applied_rows = 0;  // rows [0, applied_rows) of the new iterate are staged by the block below

@@ -523,11 +523,13 @@ __global__ __launch_bounds__(256) void fair_finish_kernel(const double* __restri
 // the step of the previous iteration CAN ride this handle's launches when every dual entry the kernel reads comes from the
 // workgroup's own LDS copy (256-wide layout, whole dual vector and gradient in LDS, no fairness stream)
 bool matching_can_fuse_apply(const dl_matching* h) {
-    // DUALIP_HIP_FUSE_APPLY=1 / 0 forces it on / off.  Default: on for SMALL handles -- fewer than kFuseApplyRounds tiles per wavefront.
-    // The folded step saves one launch and its boundary (2.7 us, tools/gridsync_bench.hip) and costs the fused launch a second
-    // dependent memory latency at its head: measured -4.5 % per iteration at 1M entities (10 tiles per wavefront; 44.8 -> 42.8 us,
-    // four pairs on one box), +-1 % at 10M (95), neutral at 12.5M (fused_common.h: fused_prologue).
-    constexpr int64_t kFuseApplyRounds = 32;
+    // DUALIP_HIP_FUSE_APPLY=1 / 0 forces it on / off.  Default: on for handles of fewer than kFuseApplyRounds tiles per wavefront.
+    // The folded step saves one launch and its boundary (2.7 us, tools/gridsync_bench.hip) and costs the fused launch a longer head.  Round 3
+    // (every wavefront derived the step, then requested its rows: +5.4 us of head): -4.5 % per iteration at 1M entities, +-1 % at 10M, neutral at
+    // 12.5M -- on below 32 tiles per wavefront.  Round 6 (ONE wavefront derives the step while the others have the rows in flight, fused_common.h:
+    // +1.9 us of head): same box, three alternations of this switch (profiles/r06l_fuse_apply_by_size_same_box.txt) -- 3M entities -3.2 %, 10M
+    // mixed -1.5 % (whole solve +1.6 %), 10M simplex -1.4 %, the 12.5M-entity rank of eight -0.8 %, 100M neutral: on below 128 (about 19M entities).
+    constexpr int64_t kFuseApplyRounds = 128;
     const char* e = plan_env("DUALIP_HIP_FUSE_APPLY");
     bool on = h->n_wg > 0 && (h->n_tiles + h->n_sell) < kFuseApplyRounds * (int64_t)h->n_wg * kFusedWaves;
     if (e && e[0] == '1') on = true;
