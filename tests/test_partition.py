@@ -124,3 +124,49 @@ def test_run_solver_shards_cover_the_problem_with_re_based_maps(partition):
                 v = loc.A.values()
                 assert v.numel() == 0 or torch.equal(v, torch.arange(int(v[0]), int(v[0]) + v.numel(), dtype=v.dtype))  # contiguous
         assert torch.equal(torch.cat(seen).sort().values, vals)
+
+
+def test_generic_lp_is_sharded_by_variables_and_box_defaults_follow_the_reference():
+    """Host logic of BASELINE config 5 on several ranks (run_solver._local_lp_shard): the ranks' shards are a partition of the VARIABLES in the
+    reference's contiguous sizes n // W (+1 for the first n % W), every layout of A gives the same columns, c / projection entries are re-based,
+    b_vec and the equality mask stay whole.  And the bound semantics the kernel's clamp arrays are built from (objectives/miplib._box_bounds): a
+    box entry that does not name a bound keeps BoxProjection's default for it (box.py:12-13: ``{"upper": 1}`` is [0, 1]); ``l`` / ``u`` entries
+    (the reference's bound reader, miplib.py:111-121) treat a missing key as "no bound"; NaN / None is an absent bound."""
+    from dualip_amd.objectives.miplib import MIPLIBInputArgs, _box_bounds
+    from dualip_amd.projections.base import ProjectionEntry
+    from dualip_amd.run_solver import _local_lp_shard
+
+    inf = float("inf")
+    assert _box_bounds({}) == (0.0, 1.0) and _box_bounds({"upper": 1}) == (0.0, 1.0) and _box_bounds({"lower": -2}) == (-2.0, 1.0)
+    assert _box_bounds({"l": 0.0, "u": float("nan")}) == (0.0, inf) and _box_bounds({"l": 0.0}) == (0.0, inf) and _box_bounds({"u": 5}) == (-inf, 5.0)
+    assert _box_bounds({"lower": float("nan"), "upper": 3}) == (-inf, 3.0) and _box_bounds({"lower": 0.25, "upper": 2.0}) == (0.25, 2.0)
+
+    g = torch.Generator().manual_seed(3)
+    m, n = 7, 23
+    A = torch.where(torch.rand(m, n, generator=g) < 0.4, torch.randn(m, n, generator=g), torch.zeros(m, n)).double()
+    c, b = torch.randn(n, generator=g).double(), torch.rand(m, generator=g).double()
+    eq = torch.zeros(m, dtype=torch.bool)
+    eq[2] = True
+    pm = {"a": ProjectionEntry("box", {"lower": 0.0, "upper": 2.0}, indices=list(range(0, 9))),
+          "b": ProjectionEntry("cone", {"lower": 0.0}, indices=[9, 11, 13, 20, 22]),
+          "c": ProjectionEntry("box", {}, indices=range(14, 20))}
+    for world in (1, 2, 3, 8, 30):  # (30 ranks for 23 variables: seven empty shards)
+        for form in ("dense", "coo", "csr", "csc"):
+            Af = {"dense": A, "coo": A.to_sparse_coo(), "csr": A.to_sparse_csr(), "csc": A.to_sparse_csc()}[form]
+            args = MIPLIBInputArgs(A=Af, c=c, projection_map=pm, b_vec=b, equality_mask=eq)
+            cols, seen = [], {k: [] for k in pm}
+            for rank in range(world):
+                loc = _local_lp_shard(args, rank, world, "cpu")
+                width = loc.A.shape[1]
+                want = n // world + (1 if rank < n % world else 0)
+                assert width == want and loc.c.shape == (width,) and torch.equal(loc.b_vec, b) and torch.equal(loc.equality_mask, eq)
+                lo = sum(n // world + (1 if r < n % world else 0) for r in range(rank))
+                dense = loc.A.to_dense() if loc.A.layout != torch.strided else loc.A
+                assert torch.equal(dense, A[:, lo : lo + width]) and torch.equal(loc.c, c[lo : lo + width])
+                cols += list(range(lo, lo + width))
+                for k, e in loc.projection_map.items():
+                    assert e.proj_type == pm[k].proj_type and e.proj_params == pm[k].proj_params
+                    seen[k] += [int(i) + lo for i in e.indices]
+            assert cols == list(range(n))
+            for k in pm:
+                assert sorted(seen[k]) == sorted(int(i) for i in pm[k].indices), (world, form, k)
