@@ -172,6 +172,8 @@ def test_host_arrays_are_staged_natively_and_give_the_same_bits():
     from dualip_amd.optimizers.agd import AcceleratedGradientDescent
     from dualip_amd.projections import create_projection_map
 
+    if os.environ.get("DUALIP_HOST_STAGING") is not None:
+        pytest.skip("states the default staging route (the suite is also run with DUALIP_HOST_STAGING=torch set for every test)")
     g = torch.Generator().manual_seed(5)
     for n_el in (1, 1000, (16 << 20) // 4 + 17, 3 * (16 << 20) // 4 + 5):  # (below one chunk, exactly past one, several chunks with a ragged tail)
         src = torch.randn(n_el, generator=g)
