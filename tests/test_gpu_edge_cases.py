@@ -465,6 +465,25 @@ def test_32_bit_slabs_on_the_finest_rows_grid_with_wide_rows(monkeypatch):
     ax64, err64, _, x64, info64, log64, dual64 = run({"DUALIP_HIP_SLAB32": "0"})
     assert info64["slab_bytes"] == 8 and np.array_equal(x, x64)
     assert relerr(ax, ax64) < 2e-7 and relerr(log, log64) < 1e-6
+    # values_changed(): the grid and the list of wide rows follow the rows' norms -- a handle built on homogeneous rows (no wide row), its values
+    # rescaled in place to this problem's, must return what a fresh handle returns; and one more rescaling (spread 1e6) sends it to 64-bit slabs
+    q = dict(p, a=p["a"] / scale[p["rowidx"]])
+    args_q = torch_args(q, "f32", pm, DEV)
+    fq = MatchingSolverDualObjectiveFunction(args_q, gamma=gamma)
+    assert fq.info()["slab_bytes"] == 4 and fq.info()["slab_wide_rows"] == 0
+    rs = torch.from_numpy(scale).float().to(DEV)[args_q.A.row_indices()]
+    args_q.A.values().mul_(rs)
+    fq.values_changed()
+    assert fq.info()["slab_bytes"] == 4 and fq.info()["slab_wide_rows"] == 10, fq.info()
+    fresh = MatchingSolverDualObjectiveFunction(torch_args(dict(p, a=args_q.A.values().double().cpu().numpy()), "f32", pm, DEV), gamma=gamma)
+    assert fresh.info()["slab_wide_rows"] == 10 and torch.equal(fq.calculate_packed(lam, gamma)[:m], fresh.calculate_packed(lam, gamma)[:m])
+    assert relerr(fq.calculate_packed(lam, gamma)[:m].cpu().numpy(), ax) < 1e-6  # (the rescaled values are this problem's up to an fp32 rounding)
+    spread = torch.from_numpy(10.0 ** np.linspace(-3, 3, m)).float().to(DEV)[args_q.A.row_indices()]
+    args_q.A.values().mul_(spread)
+    fq.values_changed()
+    assert fq.info()["slab_bytes"] == 8 and fq.info()["slab_rows_ok"] == 0, fq.info()
+    fresh = MatchingSolverDualObjectiveFunction(torch_args(dict(p, a=args_q.A.values().double().cpu().numpy()), "f32", pm, DEV), gamma=gamma)
+    assert torch.equal(fq.calculate_packed(lam, gamma)[:m], fresh.calculate_packed(lam, gamma)[:m])
     axf, errf, scf, xf, info_f, *_ = run({"DUALIP_HIP_SLAB32": "force"})  # round 5's grid, from the largest row
     assert info_f["slab_bytes"] == 4 and info_f["slab_wide_rows"] == 0 and info_f["slab_rows_ok"] == 0
     assert errf[scf < 1e-4].max() > 5e-4 and errf[scf < 1e-4].max() > 20 * err[sc < 1e-4].max() and errf[scf >= 1.0].max() < 1e-6, (errf[scf < 1e-4].max(), err[sc < 1e-4].max())
