@@ -497,8 +497,8 @@ __device__ __forceinline__ WgCtx<T> fused_prologue(const FusedArgs<T>& g, unsign
     w.red_s = reinterpret_cast<double*>(smem + off);
     w.s = (T)(-1.0 / g.gamma);
     // The projection table's entries are requested FIRST (four wavefronts, one entry per thread): nothing depends on them until the table is
-    // filled after the duals, and where they stood -- behind the staging loop -- their round trip was a third dependent one at the head of every
-    // launch (tools/timeline.py, 1M entities: step derived 3.3 us, rows staged 6.3 us, prologue done 10.4 us).
+    // filled after the duals, so their round trip no longer stands behind the staging loop.  (Measured: no change of the prologue's length --
+    // what follows "rows staged" there is the skew between the sixteen wavefronts, tools/timeline.py -- kept because it cannot be slower.)
     ProjDev pd_early;
     pd_early.kind = DL_PROJ_NONE;
     pd_early.p0 = 0.0;
